@@ -1,0 +1,145 @@
+"""CPU: pin the oracle (oracle/colorneus_oracle.py) to golden vectors captured from the reference.
+
+Gates follow SURVEY.md 8(c):
+  G1 sampler      : final z_vals vs golden, atol 1e-3 (the reference's own fp32-vs-fp64 band is 6.7e-4)
+  G2 render_core  : all outputs + all parameter grads + d rays at the GOLDEN z_vals, rel 1e-4
+  G3 end-to-end   : color_fine/depth/weight_sum/gradient_error/loss at rel 1e-4 (init regime)
+"""
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+from oracle import colorneus_oracle as O
+
+TOL = 1e-4  # relative (max-abs normalised), the north_star tolerance
+
+
+def test_positional_encoding():
+    fx = G.load("functions")
+    for L in (4, 6):
+        y = O.positional_encoding(torch.from_numpy(fx[f"pe{L}:x"]), L)
+        assert torch.equal(y, torch.from_numpy(fx[f"pe{L}:y"]))
+
+
+def test_inverse_sigmoid_edges():
+    fx = G.load("functions")
+    y = O.inverse_sigmoid(torch.from_numpy(fx["isig:x"]))
+    assert torch.allclose(y, torch.from_numpy(fx["isig:y"]), rtol=1e-6, atol=0)
+
+
+def test_sample_pdf_edge_cases():
+    fx = G.load("functions")
+    bins, w = torch.from_numpy(fx["spdf:bins"]), torch.from_numpy(fx["spdf:w"])
+    for n in (16, 5):
+        y = O.sample_pdf_det(bins, w, n)
+        assert torch.allclose(y, torch.from_numpy(fx[f"spdf:out{n}"]), rtol=0, atol=1e-6)
+
+
+def test_up_sample_and_merge():
+    fx = G.load("functions")
+    cfg = O.tiny_config()
+    P = G.prefixed(fx, "tinyw:")
+    o, d, z, sdf = (torch.from_numpy(fx["ups:" + k]) for k in ("o", "d", "z", "sdf"))
+    for i in range(4):
+        nz = O.up_sample(o, d, z, sdf, 4, 64 * 2 ** i)
+        assert torch.allclose(nz, torch.from_numpy(fx[f"ups:new_z_{i}"]), rtol=0, atol=1e-5)
+    nz = O.up_sample(o, d, z, sdf, 4, 64.0)
+    zc, sc = O.merge_z(P, cfg, o, d, z, nz, sdf, last=False)
+    assert torch.allclose(zc, torch.from_numpy(fx["cat:z"]), atol=1e-5)
+    assert torch.allclose(sc, torch.from_numpy(fx["cat:sdf"]), atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mid"])
+def test_networks(tag):
+    fx = G.load("functions")
+    cfg = O.tiny_config() if tag == "tiny" else G.mid_config()
+    P = G.prefixed(fx, "tinyw:" if tag == "tiny" else "midw:")
+    pts, dirs = torch.from_numpy(fx[f"{tag}:pts"]), torch.from_numpy(fx[f"{tag}:dirs"])
+    sdf, feat, g = O.sdf_forward(P, cfg.sdf, pts, want_grad=True)
+    ref = torch.from_numpy(fx[f"{tag}:sdf_out"])
+    assert G.relerr(torch.cat([sdf, feat], -1), ref) < 1e-5
+    assert G.relerr(g, fx[f"{tag}:sdf_grad"]) < 1e-5
+    col = O.color_forward(P, cfg.color, pts, torch.from_numpy(fx[f"{tag}:sdf_grad"]), dirs, ref[:, 1:])
+    assert G.relerr(col, fx[f"{tag}:color"]) < 1e-5
+    if tag == "tiny":
+        rel, drgb = O.relight_forward(P, cfg.relight, torch.from_numpy(fx["tiny:color"]), pts, dirs,
+                                      torch.from_numpy(fx["tiny:sdf_grad"]))
+        assert G.relerr(rel, fx["tiny:relit"]) < 1e-5 and G.relerr(drgb, fx["tiny:drgb"]) < 1e-5
+
+
+def test_grid_and_vertex_colour():
+    fx = G.load("functions")
+    cfg = O.tiny_config()
+    P = G.prefixed(fx, "tinyw:")
+    lin = torch.linspace(-1.01, 1.01, 16)
+    xx, yy, zz = torch.meshgrid(lin, lin, lin, indexing="ij")
+    pts = torch.stack([xx, yy, zz], -1).reshape(-1, 3)
+    u = -O.sdf_value(P, cfg.sdf, pts).reshape(16, 16, 16)
+    assert G.relerr(u, fx["grid:u16"]) < 1e-5
+    v = torch.from_numpy(fx["vcol:verts"]).float()
+    sdf, feat, g = O.sdf_forward(P, cfg.sdf, v, want_grad=True)
+    rgb = O.color_forward(P, cfg.color, v, g, -g, feat)
+    assert G.relerr(rgb, fx["vcol:rgb"]) < 1e-5
+
+
+def test_loss_counterpart():
+    fx = G.prefixed(G.load("functions"), "loss:")
+    out = dict(color_fine=fx["cf"], gradient_error=fx["ge"], weight_sum=fx["ws"], delta_relight=fx["dr"])
+    l_on, _ = O.compute_loss(out, fx["gt"], fx["m"])
+    l_off, _ = O.compute_loss(out, fx["gt"], None, lambda_mask=0.0, include_mask=False)
+    assert abs(float(l_on) - float(fx["l_on"])) < 1e-6
+    assert abs(float(l_off) - float(fx["l_off"])) < 1e-6
+
+
+def _run_oracle(name, tag, fixed_z):
+    fx = G.load(name)
+    cfg, P = G.weights_of(name, fx)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    o = torch.from_numpy(fx["rays_o"]).requires_grad_(True)
+    d = torch.from_numpy(fx["rays_d"]).requires_grad_(True)
+    near, far = torch.from_numpy(fx[f"{tag}:near"]), torch.from_numpy(fx[f"{tag}:far"])
+    t_rand = torch.from_numpy(fx[f"{tag}:t_rand"]) if f"{tag}:t_rand" in fx else None
+    z = torch.from_numpy(fx[f"{tag}:z_vals"]) if fixed_z else None
+    out = O.render(P, cfg, o, d, near, far, t_rand=t_rand, z_vals=z)
+    loss, _ = O.compute_loss(out, torch.from_numpy(fx["rgb_gt"]), torch.from_numpy(fx["mask"]))
+    loss.backward()
+    return fx, cfg, P, o, d, out, loss
+
+
+E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "neus_dtu_sharp"]
+
+
+@pytest.mark.parametrize("name", E2E)
+@pytest.mark.parametrize("tag", ["det", "jit"])
+def test_g1_sampler(name, tag):
+    fx = G.load(name)
+    cfg, P = G.weights_of(name, fx)
+    o, d = torch.from_numpy(fx["rays_o"]), torch.from_numpy(fx["rays_d"])
+    near, far = O.near_far_from_sphere(o, d)
+    assert torch.allclose(near, torch.from_numpy(fx[f"{tag}:near"]), atol=1e-6)
+    t_rand = torch.from_numpy(fx[f"{tag}:t_rand"]) if f"{tag}:t_rand" in fx else None
+    z = O.sample_z(P, cfg, o, d, near, far, t_rand)
+    assert float((z - torch.from_numpy(fx[f"{tag}:z_vals"])).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("name", E2E)
+@pytest.mark.parametrize("tag", ["det", "jit"])
+def test_g2_render_core_at_golden_z(name, tag):
+    fx, cfg, P, o, d, out, loss = _run_oracle(name, tag, fixed_z=True)
+    for k in G.OUTPUT_KEYS:
+        if f"{tag}:out_{k}" in fx:
+            assert G.relerr(out[k].detach(), fx[f"{tag}:out_{k}"]) < TOL, k
+    assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
+    bad = G.check_param_grads(fx, tag, {k: p.grad for k, p in P.items()}, TOL)
+    assert not bad, bad
+    assert G.relerr(o.grad, fx[f"{tag}:grad_rays_o"]) < TOL
+    assert G.relerr(d.grad, fx[f"{tag}:grad_rays_d"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["tiny_init", "dtu_init"])
+def test_g3_end_to_end_init_regime(name):
+    fx, cfg, P, o, d, out, loss = _run_oracle(name, "jit", fixed_z=False)
+    for k in ("color_fine", "depth", "weight_sum", "gradient_error"):
+        assert G.relerr(out[k].detach(), fx[f"jit:out_{k}"]) < TOL, k
+    assert abs(float(loss.detach()) - float(fx["jit:loss"])) < TOL * abs(float(fx["jit:loss"]))

@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the imported upstream reference (THIS CONTAINER ONLY).
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+
+The reference has no tests / golden files of its own, so parity is
+pinned by running its unmodified code here (CPU, torch 2.10) on seeded inputs and
+committing inputs + outputs.  Fixtures are data only: inputs, weights (tiny model) or the
+weight *recipe* (seed + checksum, full-size model), outputs, gradients.
+
+Every fixture stores the z_vals the reference's sampler produced (captured by wrapping
+the instance's render_core) so that render_core parity can be gated at fixed z
+(gates G1 sampler / G2 render_core at golden z / G3 end-to-end).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+import ref_import  # noqa: E402
+from oracle import colorneus_oracle as O  # noqa: E402  (only for config dataclasses + weight recipe)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def node_from_config(cfg: O.RenderConfig, CN):
+    s, c, r = cfg.sdf, cfg.color, cfg.relight
+    d = dict(TYPE=cfg.type, N_SAMPLES=cfg.n_samples, N_IMPORTANCE=cfg.n_importance, UP_SAMPLE_STEPS=cfg.up_sample_steps,
+             PERTURB=cfg.perturb,
+             SDF=dict(D_IN=s.d_in, D_OUT=s.d_out, D_HIDDEN=s.d_hidden, N_LAYERS=s.n_layers, SKIP_IN=list(s.skip_in),
+                      MULTIRES=s.multires, BIAS=s.bias, SCALE=s.scale, GEOMETRIC_INIT=True, WEIGHT_NORM=s.weight_norm,
+                      INSIDE_OUTSIDE=False),
+             COLOR=dict(D_FEATURE=c.d_feature, MODE=c.mode, D_IN=c.d_in, D_OUT=c.d_out, D_HIDDEN=c.d_hidden,
+                        N_LAYERS=c.n_layers, WEIGHT_NORM=c.weight_norm, MULTIRES_VIEW=c.multires_view, SQUEEZE_OUT=True),
+             DEVIATION=dict(INIT_VAL=cfg.init_val))
+    if r is not None:
+        d["RELIGHT"] = dict(D_IN=r.d_in, D_OUT=r.d_out, D_HIDDEN=r.d_hidden, N_LAYERS=r.n_layers, Y_IN_LAYER=r.y_in_layer,
+                            MULTIRES_VIEW=r.multires_view, INCLUDE_GRAD=r.include_grad, INV_SIGMOID=r.inv_sigmoid)
+    return CN(d)
+
+
+def make_rays(R, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(R, 3, generator=g, dtype=torch.float64)
+    o = o / o.norm(dim=-1, keepdim=True) * (2.5 + 0.5 * torch.rand(R, 1, generator=g, dtype=torch.float64))
+    tgt = torch.randn(R, 3, generator=g, dtype=torch.float64) * 0.35
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    gt = torch.rand(R, 3, generator=g, dtype=torch.float64)
+    mask = (torch.rand(R, generator=g) < 0.7).to(torch.float64)
+    return o.to(dtype), d.to(dtype), gt.to(dtype), mask.to(dtype)
+
+
+def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0.1, rays_grad=True):
+    """Returns dict of numpy arrays: outputs, z_vals, loss, grads."""
+    r = cls(node)
+    r.load_state_dict(P)
+    captured = {}
+    orig = r.render_core
+
+    def wrapped(rays_o, rays_d, z_vals, *a, **k):
+        captured["z_vals"] = z_vals.detach().clone()
+        return orig(rays_o, rays_d, z_vals, *a, **k)
+
+    r.render_core = wrapped
+    o = o.clone().requires_grad_(rays_grad)
+    d = d.clone().requires_grad_(rays_grad)
+    near, far = mods["ray_utils"].near_far_from_sphere(o.detach(), d.detach())
+    res = {}
+    if jitter_seed is None:
+        out = r(o, d, near, far, perturb_overwrite=0)
+    else:
+        torch.manual_seed(jitter_seed)
+        res["t_rand"] = torch.rand([o.shape[0], 1]).numpy()
+        torch.manual_seed(jitter_seed)
+        out = r(o, d, near, far)
+    # NeuS_Trainer.compute_loss, DTU settings (NeuS_Trainer.py:129-171)
+    loss = torch.nn.functional.mse_loss(out["color_fine"], gt) + 0.1 * out["gradient_error"]
+    if lambda_mask != 0:
+        loss = loss + lambda_mask * torch.nn.functional.binary_cross_entropy(
+            out["weight_sum"].squeeze().clip(1e-3, 1.0 - 1e-3), mask)
+    if "delta_relight" in out:
+        dr = out["delta_relight"] * mask.unsqueeze(-1).unsqueeze(-1)
+        loss = loss + 1.0 * torch.nn.functional.mse_loss(torch.mean(dr), torch.tensor(0, dtype=torch.float32))
+    loss.backward()
+    res.update({"out_" + k: v.detach().numpy() for k, v in out.items()})
+    res["z_vals"] = captured["z_vals"].numpy()
+    res["near"], res["far"] = near.numpy(), far.numpy()
+    res["loss"] = loss.detach().numpy()
+    grads = {k: p.grad.detach().clone() for k, p in r.named_parameters()}
+    if rays_grad:
+        res["grad_rays_o"], res["grad_rays_d"] = o.grad.numpy(), d.grad.numpy()
+    return res, grads
+
+
+def e2e_fixture(name, cfg, cls, CN, mods, R, weight_seed, trained_like, store_weights, grad_stride):
+    node = node_from_config(cfg, CN)
+    P = O.init_params(cfg, seed=weight_seed, dtype=torch.float32, trained_like=trained_like)
+    o, d, gt, mask = make_rays(R, seed=1)
+    fx = dict(rays_o=o.numpy(), rays_d=d.numpy(), rgb_gt=gt.numpy(), mask=mask.numpy(),
+              weight_seed=np.int64(weight_seed), trained_like=np.int64(trained_like),
+              weight_checksum=np.float64(O.params_checksum(P)), grad_stride=np.int64(grad_stride))
+    if store_weights:
+        for k, v in P.items():
+            fx["w:" + k] = v.numpy()
+    for tag, js in (("det", None), ("jit", 2)):
+        res, grads = run_reference(cls, node, P, o, d, gt, mask, js, mods)
+        for k, v in res.items():
+            fx[f"{tag}:{k}"] = v
+        for k, g in grads.items():
+            flat = g.reshape(-1)
+            fx[f"{tag}:g:{k}"] = flat[::grad_stride].numpy().copy()
+            fx[f"{tag}:gsum:{k}"] = np.float64(flat.double().sum())
+            fx[f"{tag}:gabs:{k}"] = np.float64(flat.double().abs().sum())
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def function_fixture(CN, mods, Color_NeuS, NeuS):
+    fields, ray_utils, transform = mods["fields"], mods["ray_utils"], mods["transform"]
+    from lib.models.tools.PositionEncoding import get_embedder
+    from lib.models.renderers.NeuS import extract_fields, extract_color
+    g = torch.Generator().manual_seed(11)
+    fx = {}
+    # --- embedder
+    x = torch.randn(17, 3, generator=g)
+    for L in (4, 6):
+        fn, dim = get_embedder(L)
+        fx[f"pe{L}:x"], fx[f"pe{L}:y"] = x.numpy(), fn(x).numpy()
+    # --- inverse_sigmoid edge cases
+    xs = torch.tensor([0.0, 1.0, 1e-6, 1 - 1e-6, 1e-5, 0.5, 0.25, -0.1, 1.1, 0.999995])
+    fx["isig:x"], fx["isig:y"] = xs.numpy(), transform.inverse_sigmoid(xs).numpy()
+    # --- sample_pdf(det=True): generic, flat weights (ties), zero weights, spike
+    n = 24
+    bins = torch.sort(torch.rand(6, n, generator=g) * 2 + 1, dim=-1)[0]
+    w = torch.rand(6, n - 1, generator=g)
+    w[1] = 0.0                       # all-zero weights -> uniform pdf from the +1e-5
+    w[2] = 1.0                       # flat
+    w[3] = 0.0; w[3, 7] = 1.0        # spike: many flat cdf segments
+    w[4, :10] = 0.0                  # leading zeros
+    w[5] = torch.rand(n - 1, generator=g) * 1e-6   # tiny weights: denom < 1e-5 branch
+    fx["spdf:bins"], fx["spdf:w"] = bins.numpy(), w.numpy()
+    fx["spdf:out16"] = ray_utils.sample_pdf(bins, w, 16, det=True).numpy()
+    fx["spdf:out5"] = ray_utils.sample_pdf(bins, w, 5, det=True).numpy()
+    # --- up_sample + cat_z_vals on a tiny renderer (weights stored)
+    cfg = O.tiny_config()
+    node = node_from_config(cfg, CN)
+    P = O.init_params(cfg, seed=3, trained_like=True)
+    r = Color_NeuS(node); r.load_state_dict(P)
+    for k, v in P.items():
+        fx["tinyw:" + k] = v.numpy()
+    o, d, _, _ = make_rays(12, seed=5)
+    near, far = ray_utils.near_far_from_sphere(o, d)
+    z = near[:, None] + (far - near)[:, None] * torch.linspace(0, 1, 16)[None, :]
+    with torch.no_grad():
+        sdf = r.sdf_network.sdf((o[:, None] + d[:, None] * z[..., None]).reshape(-1, 3)).reshape(12, 16)
+        fx["ups:o"], fx["ups:d"], fx["ups:z"], fx["ups:sdf"] = o.numpy(), d.numpy(), z.numpy(), sdf.numpy()
+        for i in range(4):
+            fx[f"ups:new_z_{i}"] = r.up_sample(o, d, z, sdf, 4, 64 * 2 ** i).numpy()
+        nz = r.up_sample(o, d, z, sdf, 4, 64.0)
+        zc, sc = r.cat_z_vals(o, d, z, nz, sdf, last=False)
+        fx["cat:z"], fx["cat:sdf"] = zc.numpy(), sc.numpy()
+    # --- networks in isolation, DTU sizes would be big; use tiny + one mid-size (hidden 64, skip)
+    cfg2 = O.RenderConfig(type="NeuS", n_samples=16, n_importance=16,
+                          sdf=O.SDFConfig(d_out=65, d_hidden=64, n_layers=6, skip_in=[3]),
+                          color=O.ColorConfig(d_feature=64, mode="idr", d_in=9, d_hidden=64, n_layers=3, multires_view=4),
+                          relight=None)
+    node2 = node_from_config(cfg2, CN)
+    P2 = O.init_params(cfg2, seed=4, trained_like=True)
+    r2 = NeuS(node2); r2.load_state_dict(P2)
+    for k, v in P2.items():
+        fx["midw:" + k] = v.numpy()
+    pts = torch.randn(40, 3, generator=g) * 0.5
+    dirs = torch.nn.functional.normalize(torch.randn(40, 3, generator=g), dim=-1)
+    for tag, net in (("tiny", r), ("mid", r2)):
+        y = net.sdf_network(pts.clone())
+        gr = net.sdf_network.gradient(pts.clone()).squeeze()
+        fx[f"{tag}:pts"], fx[f"{tag}:dirs"] = pts.numpy(), dirs.numpy()
+        fx[f"{tag}:sdf_out"], fx[f"{tag}:sdf_grad"] = y.detach().numpy(), gr.detach().numpy()
+        col = net.color_network(pts, gr, dirs, y[:, 1:])
+        fx[f"{tag}:color"] = col.detach().numpy()
+    rel, drgb = r.relight_network(torch.from_numpy(fx["tiny:color"]), pts, dirs,
+                                  gradients=torch.from_numpy(fx["tiny:sdf_grad"]))
+    fx["tiny:relit"], fx["tiny:drgb"] = rel.detach().numpy(), drgb.detach().numpy()
+    # --- extract_fields on a 16^3 lattice (N=8 chunks) and extract_color on 100 vertices
+    bmin, bmax = torch.tensor([-1.01, -1.01, -1.01]), torch.tensor([1.01, 1.01, 1.01])
+    u = extract_fields(bmin, bmax, torch.device("cpu"), 16, lambda p: -r.sdf_network.sdf(p), N=8)
+    fx["grid:u16"] = u
+    verts = (torch.randn(100, 3, generator=g) * 0.3).numpy()
+    fx["vcol:verts"] = verts
+    fx["vcol:rgb"] = extract_color(verts, torch.device("cpu"), r.sdf_network, r.color_network, N=64)
+    # --- compute_loss harness counterpart: mask on / off (NeuS_Trainer.py:129-171), reproduced inline
+    R = 12
+    cf = torch.rand(R, 3, generator=g); gtc = torch.rand(R, 3, generator=g)
+    ge = torch.rand((), generator=g); ws = torch.rand(R, 1, generator=g) * 1.2 - 0.1
+    dr = torch.randn(R, 8, 3, generator=g) * 0.1; m = (torch.rand(R, generator=g) < 0.6).float()
+    F_ = torch.nn.functional
+    l_on = F_.mse_loss(cf, gtc) + 0.1 * ge + 0.1 * F_.binary_cross_entropy(ws.squeeze().clip(1e-3, 1 - 1e-3), m) \
+        + F_.mse_loss(torch.mean(dr * m[:, None, None]), torch.tensor(0.0))
+    l_off = F_.mse_loss(cf, gtc) + 0.1 * ge + F_.mse_loss(torch.mean(dr), torch.tensor(0.0))
+    for k, v in dict(cf=cf, gt=gtc, ge=ge, ws=ws, dr=dr, m=m, l_on=l_on, l_off=l_off).items():
+        fx["loss:" + k] = v.numpy()
+    path = os.path.join(OUT, "functions.npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    Color_NeuS, NeuS, CN, mods = ref_import.import_reference()
+    function_fixture(CN, mods, Color_NeuS, NeuS)
+    tiny = O.tiny_config()
+    e2e_fixture("tiny_init", tiny, Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=False, store_weights=True, grad_stride=1)
+    e2e_fixture("tiny_sharp", tiny, Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=True, store_weights=True, grad_stride=1)
+    tiny_neus = O.RenderConfig(type="NeuS", n_samples=16, n_importance=16,
+                               sdf=O.SDFConfig(d_out=65, d_hidden=64, n_layers=2, skip_in=[]),
+                               color=O.ColorConfig(d_feature=64, mode="idr", d_in=9, d_hidden=64, n_layers=2, multires_view=4),
+                               relight=None)
+    e2e_fixture("tiny_neus_sharp", tiny_neus, NeuS, CN, mods, R=32, weight_seed=0, trained_like=True, store_weights=True, grad_stride=1)
+    # C2-like: no importance sampling (z differentiable path not exercised: near/far detached by the harness)
+    tiny_noimp = O.tiny_config(); tiny_noimp.n_importance = 0
+    e2e_fixture("tiny_noimp_sharp", tiny_noimp, Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=True, store_weights=True, grad_stride=1)
+    dtu = O.dtu_config()
+    e2e_fixture("dtu_init", dtu, Color_NeuS, CN, mods, R=16, weight_seed=0, trained_like=False, store_weights=False, grad_stride=97)
+    e2e_fixture("dtu_sharp", dtu, Color_NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97)
+    neus_dtu = O.RenderConfig(type="NeuS", relight=None)  # config/NeuS_dtu.yml: idr, D_IN 9, MULTIRES_VIEW 4
+    e2e_fixture("neus_dtu_sharp", neus_dtu, NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97)
+
+
+if __name__ == "__main__":
+    main()
