@@ -1,0 +1,15 @@
+"""MI355X-native volume renderer for Color-NeuS (hand-written HIP kernels behind a C ABI).
+
+Public surface (mirrors the reference's RENDERER plug-in interface, lib/utils/builder.py:309):
+    ColorNeuSRenderer / NeuSRenderer   nn.Modules with NeuS.forward's signature and return dict
+    RENDERER, build_renderer            registry look-alike; register_into(reference_registry) for drop-in use
+    load_library                        the ctypes binding of libcolorneus_hip.so
+"""
+from .config import RenderConfig, config_from_node  # noqa: F401
+from ._lib import load_library, library_path, RenderLibrary  # noqa: F401
+from .renderer import ColorNeuSRenderer, NeuSRenderer, RENDERER, build_renderer, register_into  # noqa: F401
+from .loss import compute_loss  # noqa: F401
+from . import parallel  # noqa: F401
+
+__all__ = ["RenderConfig", "config_from_node", "load_library", "library_path", "RenderLibrary", "ColorNeuSRenderer",
+           "NeuSRenderer", "RENDERER", "build_renderer", "register_into", "compute_loss", "parallel"]

@@ -1,0 +1,132 @@
+"""ctypes binding of the C ABI declared in include/colorneus_render.h.
+
+The product library is ``libcolorneus_hip.so`` next to this file (built by ``__graft_entry__.build()`` /
+``make -C color-neus_amd/csrc hip``).  There is NO fallback: if it is missing, loading raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class CnrConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("type", "n_samples", "n_importance", "up_sample_steps", "sdf_d_hidden", "sdf_n_layers",
+                                         "sdf_d_out", "sdf_multires", "sdf_skip_mask", "sdf_weight_norm")] + \
+               [("sdf_scale", C.c_float)] + \
+               [(n, C.c_int32) for n in ("col_mode", "col_d_feature", "col_d_hidden", "col_n_layers", "col_multires_view",
+                                         "col_weight_norm", "col_squeeze_out", "rel_d_hidden", "rel_n_layers", "rel_y_in_layer",
+                                         "rel_multires_view", "rel_include_grad", "rel_inv_sigmoid")]
+
+
+_FP = C.c_void_p
+
+
+class CnrInputs(C.Structure):
+    _fields_ = [("rays_o", _FP), ("rays_d", _FP), ("near_", _FP), ("far_", _FP), ("t_rand", _FP), ("z_vals_override", _FP),
+                ("background_rgb", _FP), ("n_rays", C.c_int64), ("cos_anneal_ratio", C.c_float)]
+
+
+OUTPUT_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
+                 "inside_sphere", "depth", "global_color", "delta_relight", "z_vals"]
+OUT_GRAD_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
+                   "depth", "global_color", "delta_relight"]
+
+
+class CnrOutputs(C.Structure):
+    _fields_ = [(n, _FP) for n in OUTPUT_FIELDS]
+
+
+class CnrOutGrads(C.Structure):
+    _fields_ = [(n, _FP) for n in OUT_GRAD_FIELDS]
+
+
+class CnrInGrads(C.Structure):
+    _fields_ = [("d_params", C.POINTER(_FP)), ("d_rays_o", _FP), ("d_rays_d", _FP)]
+
+
+_MODE = {"idr": 0, "no_view_dir": 1, "no_normal": 2}
+
+
+def c_config(cfg) -> CnrConfig:
+    mask = 0
+    for l in cfg.sdf_skip_in:
+        mask |= 1 << int(l)
+    return CnrConfig(type=1 if cfg.type == "Color_NeuS" else 0, n_samples=cfg.n_samples, n_importance=cfg.n_importance,
+                     up_sample_steps=cfg.up_sample_steps, sdf_d_hidden=cfg.sdf_d_hidden, sdf_n_layers=cfg.sdf_n_layers,
+                     sdf_d_out=cfg.sdf_d_out, sdf_multires=cfg.sdf_multires, sdf_skip_mask=mask,
+                     sdf_weight_norm=int(cfg.sdf_weight_norm), sdf_scale=float(cfg.sdf_scale), col_mode=_MODE[cfg.col_mode],
+                     col_d_feature=cfg.col_d_feature, col_d_hidden=cfg.col_d_hidden, col_n_layers=cfg.col_n_layers,
+                     col_multires_view=cfg.col_multires_view, col_weight_norm=int(cfg.col_weight_norm),
+                     col_squeeze_out=int(cfg.col_squeeze_out), rel_d_hidden=cfg.rel_d_hidden, rel_n_layers=cfg.rel_n_layers,
+                     rel_y_in_layer=cfg.rel_y_in_layer, rel_multires_view=cfg.rel_multires_view,
+                     rel_include_grad=int(cfg.rel_include_grad), rel_inv_sigmoid=int(cfg.rel_inv_sigmoid))
+
+
+EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_count", "cnr_param_info", "cnr_ctx_bytes",
+           "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
+           "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color"]
+
+
+class RenderLibrary:
+    def __init__(self, path):
+        if not os.path.isfile(path):
+            raise RuntimeError(
+                f"Color-NeuS HIP library not found at {path}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C color-neus_amd/csrc hip`. There is no CPU/PyTorch fallback for the render path.")
+        self.path = path
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.cnr_abi_version.restype = C.c_int
+        L.cnr_backend_name.restype = C.c_char_p
+        L.cnr_last_error.restype = C.c_char_p
+        L.cnr_param_count.argtypes = [C.POINTER(CnrConfig)]
+        L.cnr_param_info.argtypes = [C.POINTER(CnrConfig), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        for f in ("cnr_ctx_bytes", "cnr_bwd_scratch_bytes", "cnr_sdf_eval_scratch_bytes", "cnr_vertex_color_scratch_bytes"):
+            getattr(L, f).restype = C.c_size_t
+            getattr(L, f).argtypes = [C.POINTER(CnrConfig), C.c_int64]
+        L.cnr_sdf_grid_scratch_bytes.restype = C.c_size_t
+        L.cnr_sdf_grid_scratch_bytes.argtypes = [C.POINTER(CnrConfig), C.c_int32]
+        L.cnr_render_forward.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(CnrInputs), C.POINTER(CnrOutputs),
+                                         _FP, C.c_size_t, _FP]
+        L.cnr_render_backward.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(CnrInputs), C.POINTER(CnrOutputs),
+                                          _FP, C.c_size_t, C.POINTER(CnrOutGrads), C.POINTER(CnrInGrads), _FP, C.c_size_t, _FP]
+        L.cnr_sdf_eval.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), _FP, C.c_int64, C.c_float, _FP, _FP, C.c_size_t, _FP]
+        L.cnr_sdf_grid.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32,
+                                   _FP, _FP, C.c_size_t, _FP]
+        L.cnr_vertex_color.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), _FP, C.c_int64, _FP, _FP, C.c_size_t, _FP]
+        if L.cnr_abi_version() != 1:
+            raise RuntimeError("colorneus library ABI mismatch")
+
+    @property
+    def backend(self) -> str:
+        return self.lib.cnr_backend_name().decode()
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {self.lib.cnr_last_error().decode()}")
+
+    def param_inventory(self, ccfg):
+        n = self.lib.cnr_param_count(C.byref(ccfg))
+        if n < 0:
+            raise RuntimeError(f"unsupported renderer configuration: {self.lib.cnr_last_error().decode()}")
+        out = []
+        buf = C.create_string_buffer(128)
+        r, c = C.c_int(), C.c_int()
+        for i in range(n):
+            self.check(self.lib.cnr_param_info(C.byref(ccfg), i, buf, 128, C.byref(r), C.byref(c)), "cnr_param_info")
+            out.append((buf.value.decode(), r.value, c.value))
+        return out
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libcolorneus_hip.so")
+
+
+_cached = {}
+
+
+def load_library(path=None) -> RenderLibrary:
+    """Load the HIP library (default) or an explicitly given build (tests pass the CPU-emulation build explicitly)."""
+    path = os.path.abspath(path or library_path())
+    if path not in _cached:
+        _cached[path] = RenderLibrary(path)
+    return _cached[path]

@@ -1,0 +1,155 @@
+// Kernel launch interface between the host orchestration (cnr_plan.cpp) and the kernels.
+// Implemented twice: cnr_kernels.hip (HIP, gfx950 -- the product) and cnr_kernels_emu.cpp (CPU emulation, tests only).
+#pragma once
+#include "cnr_common.h"
+#include "cnr_views.h"
+
+namespace cnr {
+
+constexpr int kMaxRaySamples = 256;   // per-ray kernels stage one ray in LDS: M <= 256
+
+struct Segment { int dst, src, len; };   // internal column [dst, dst+len) <- reference column [src, src+len)
+
+// effective-weight preparation (weight-norm, column permutation, padding, transpose)
+struct PrepWeight {
+  const float* g = nullptr;   // weight_g [n] or null (plain nn.Linear)
+  const float* v = nullptr;   // weight_v / weight [n][k_ref]
+  const float* b = nullptr;   // bias [n]
+  int n = 0, k_ref = 0;
+  int nseg = 0; Segment seg[4];
+  float* W = nullptr; int ldw = 0; int npad = 0;      // [npad][ldw]
+  float* Wt = nullptr; int ldwt = 0; int kpad = 0;    // [kpad][ldwt]
+  float* bias = nullptr;                              // [npad]
+};
+
+// dW partial reduction + weight-norm backward + un-permutation
+struct FinishWeight {
+  const float* partial = nullptr; int nchunk = 0; int npad = 0; int ldk = 0;   // [nchunk][npad][ldk]
+  const float* colsum = nullptr;                                             // [nchunk][npad] or null
+  const float* g = nullptr; const float* v = nullptr;
+  int n = 0, k_ref = 0;
+  int nseg = 0; Segment seg[4];
+  float* dg = nullptr; float* dv = nullptr; float* db = nullptr;   // outputs (dg null for plain Linear; dv = d weight)
+};
+
+struct EmbedZ {   // E[r*m + j][0..kEmb) = PE(scale * (o_r + d_r * z[r*ldz + j])), optional coarse-z generation
+  const float* o; const float* d; long R; int m;
+  float* z; int ldz;            // when make_z: written; else read
+  int make_z;                   // 1: z = near + (far-near)*lin(j) (+ (t_rand-0.5)*2/S)          (NeuS.py:311-326)
+  const float* near_; const float* far_; const float* t_rand;
+  float scale; int multires;
+  float* E;                     // [R*m][kEmb]
+};
+
+struct EmbedPts {  // E (and optionally AUX[.,0:3]) from explicit points or from a lattice (NeuS.py:15-24)
+  const float* pts; long n;            // pts [n][3] or null -> lattice
+  int res; float bmin[3], bmax[3]; long start;   // lattice point index = start + i, order x-major (x, y, z)
+  float scale; int multires;
+  float* E; float* AUX;
+};
+
+struct UpSample {   // NeuS.py:136-181 + ray_utils.py:123-154 (det=True)
+  const float* o; const float* d; long R;
+  const float* z; int ldz; const float* sdf; int lds; int n;   // current samples per ray
+  int m;                                             // new samples per ray
+  float inv_s;
+  float* new_z;                                      // [R][m]
+};
+
+struct MergeZ {     // NeuS.py:183-197
+  long R; float* z; int ldz; const float* sdf_in; int lds_in; float* sdf_out; int lds_out; int n;   // z merged in place
+  const float* new_z; const float* new_sdf; int m;   // new_sdf null on the last step (sdf not updated)
+};
+
+struct FineSetup {  // Color_NeuS.py:41-50: section midpoints, PE input of the SDF net, auxiliary inputs
+  const float* o; const float* d; const float* z; long R; int M; float sample_dist;
+  float scale; int multires; int multires_view;
+  float* E;      // [P][kEmb]
+  float* AUX;    // [P][kAux] = [p(3) g(3) PE(dir)(3+6*mv) 0...]
+};
+
+struct GradFinish { // g = scale * J_PE^T (ce0 + ce_skip)
+  long P; const float* E; const float* ce0; const float* ces; float scale; int multires;
+  float* grad_out;   // [P][3] (the 'gradients' output tensor)
+  float* AUX;        // g copied to AUX[.,3:6]
+  int neg_g_as_view; int multires_view;   // vertex colouring (NeuS.py:60): view_dirs = -g -> AUX[.,6:] = PE(-g)
+};
+
+struct CompositeFwd {   // Color_NeuS.py:66-123, NeuS.py:382-399
+  const float* o; const float* d; const float* z; long R; int M; float sample_dist;
+  const float* sdf; const float* g; const float* color; int ldcolor; const float* gcolor; int ldg;   // gcolor null for plain NeuS
+  const float* variance; float cos_anneal; const float* background_rgb;
+  float* color_fine; float* s_val; float* cdf_fine; float* weight_sum; float* weight_max; float* weights;
+  float* inside_sphere; float* depth; float* global_color;
+  float* eik_partial;    // [R][2]
+};
+
+struct ReduceEik { const float* partial; long R; float* sums /*[2]*/; float* gradient_error; };
+
+struct CompositeBwd {
+  const float* o; const float* d; const float* z; long R; int M; float sample_dist;
+  const float* sdf; const float* g; const float* color; int ldcolor; const float* gcolor; int ldg;
+  const float* variance; float cos_anneal; const float* background_rgb; const float* eik_sums; float sdf_scale;
+  int inv_sigmoid; int has_relight;
+  // upstream gradients (any may be null)
+  const float* d_color_fine; const float* d_s_val; const float* d_cdf; const float* d_weight_sum; const float* d_weight_max;
+  const float* d_gradients; const float* d_weights; const float* d_gradient_error; const float* d_depth;
+  const float* d_global_color; const float* d_delta_relight;
+  // per-point cotangents
+  float* ztop; int ldztop;     // ztop[pt][0] = d sdf / scale
+  float* gbar;                 // [P][4] d loss / d g through alpha, eikonal and the 'gradients' output
+  float* dtop;                 // [P][4] cotangent of the last relight (or colour) layer output, pre-activation
+  float* gc_a;                 // [P][4] cotangent of the global colour (post-sigmoid): direct + inverse-sigmoid path
+  float* dinvs_partial;        // [R]
+  float* d_rays_d;             // [R][3] (null when rays need no grad): sum_j d tc_j * g_j
+  float* d_z;                  // [R][M] cotangent of z through dists/depth (null unless needed)
+};
+
+struct ColTopBwd {  // cotangent of the colour net's last pre-activation
+  long P; const float* gc_a; const float* gc_b /* may be null */; const float* gcolor; int squeeze; float* out; /*[P][4]*/
+};
+
+struct GbarFinish { // total d g, then tangent of the embedding: cbar = J_PE (scale * gbar)
+  long P; const float* gbar_alpha; const float* daux_c; const float* daux_r; const float* E; float scale; int multires;
+  float* gbar_total /*[P][4]*/; float* cbar /*[P][kEmb]*/;
+};
+
+struct VarianceFinish { const float* partial; long R; const float* variance; float* d_variance; };
+
+struct RaysGradFinish {  // d rays_o / d rays_d from the point cotangents (only when rays require grad)
+  long R; int M; const float* d; const float* z; float sample_dist;
+  const float* pbar;      // [P][4] total cotangent of p
+  const float* daux_dir_c; const float* daux_dir_r; int lddir; int multires_view;   // cotangent of PE(dir) parts (may be null)
+  const float* d_rays_d_alpha;   // [R][3] from CompositeBwd
+  float* d_o; float* d_d;
+};
+
+struct PbarFinish {   // total cotangent of p: colour/relight aux inputs + SDF value path + gradient path (PE second derivative)
+  long P; const float* daux_c; const float* daux_r; const float* ebar0; const float* ebars; const float* E;
+  const float* ce0; const float* ces; const float* gbar_total; float scale; int multires; float* pbar;
+};
+
+void be_layer_gemm(const LayerGemm& g, cnr_stream s);
+void be_dw_gemm(const DwGemm& g, cnr_stream s);
+void be_prep_weight(const PrepWeight& p, cnr_stream s);
+void be_finish_weight(const FinishWeight& p, cnr_stream s);
+void be_embed_z(const EmbedZ& p, cnr_stream s);
+void be_embed_pts(const EmbedPts& p, cnr_stream s);
+void be_upsample(const UpSample& p, cnr_stream s);
+void be_merge(const MergeZ& p, cnr_stream s);
+void be_fine_setup(const FineSetup& p, cnr_stream s);
+void be_grad_finish(const GradFinish& p, cnr_stream s);
+void be_composite_fwd(const CompositeFwd& p, cnr_stream s);
+void be_reduce_eik(const ReduceEik& p, cnr_stream s);
+void be_composite_bwd(const CompositeBwd& p, cnr_stream s);
+void be_coltop_bwd(const ColTopBwd& p, cnr_stream s);
+void be_gbar_finish(const GbarFinish& p, cnr_stream s);
+void be_variance_finish(const VarianceFinish& p, cnr_stream s);
+void be_pbar_finish(const PbarFinish& p, cnr_stream s);
+void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s);
+void be_memset_zero(void* p, size_t bytes, cnr_stream s);
+void be_grid_points(float* pts /*unused*/, cnr_stream s);
+const char* be_name();
+int be_check_last_error(char* msg, size_t n);   // 0 ok
+
+}  // namespace cnr

@@ -1,0 +1,167 @@
+// Per-element bodies of the point-wise kernels (host+device; shared by the HIP and CPU-emulation backends).
+#pragma once
+#include "cnr_backend.h"
+#include "cnr_raymath.h"
+
+namespace cnr {
+
+// one (ray, sample) element of EmbedZ
+CNR_HD void body_embed_z(const EmbedZ& p, long idx) {
+  long r = idx / p.m;
+  int j = (int)(idx - r * p.m);
+  float zz;
+  if (p.make_z) {
+    float nr = p.near_[r], fr = p.far_[r];
+    zz = nr + (fr - nr) * linspace_at(0.0f, 1.0f, p.m, j);
+    if (p.t_rand) zz = zz + (p.t_rand[r] - 0.5f) * 2.0f / (float)p.m;
+    p.z[r * p.ldz + j] = zz;
+  } else {
+    zz = p.z[r * p.ldz + j];
+  }
+  float x[3];
+  for (int c = 0; c < 3; ++c) x[c] = (p.o[r * 3 + c] + p.d[r * 3 + c] * zz) * p.scale;
+  float row[kEmb];
+  for (int c = 0; c < kEmb; ++c) row[c] = 0.0f;
+  pe_row(x, p.multires, row);
+  float* out = p.E + idx * kEmb;
+  for (int c = 0; c < kEmb; ++c) out[c] = row[c];
+}
+
+CNR_HD void body_embed_pts(const EmbedPts& p, long i) {
+  float pp[3];
+  if (p.pts) {
+    pp[0] = p.pts[i * 3]; pp[1] = p.pts[i * 3 + 1]; pp[2] = p.pts[i * 3 + 2];
+  } else {
+    long idx = p.start + i;
+    long r2 = (long)p.res * p.res;
+    int ix = (int)(idx / r2), iy = (int)((idx / p.res) % p.res), iz = (int)(idx % p.res);
+    pp[0] = linspace_at(p.bmin[0], p.bmax[0], p.res, ix);
+    pp[1] = linspace_at(p.bmin[1], p.bmax[1], p.res, iy);
+    pp[2] = linspace_at(p.bmin[2], p.bmax[2], p.res, iz);
+  }
+  float x[3] = {pp[0] * p.scale, pp[1] * p.scale, pp[2] * p.scale};
+  float row[kEmb];
+  for (int c = 0; c < kEmb; ++c) row[c] = 0.0f;
+  pe_row(x, p.multires, row);
+  float* e = p.E + i * kEmb;
+  for (int c = 0; c < kEmb; ++c) e[c] = row[c];
+  if (p.AUX) {
+    float* a = p.AUX + i * kAux;
+    for (int c = 0; c < kAux; ++c) a[c] = 0.0f;
+    a[0] = pp[0]; a[1] = pp[1]; a[2] = pp[2];
+  }
+}
+
+CNR_HD void body_fine_setup(const FineSetup& p, long pt) {
+  long r = pt / p.M;
+  int j = (int)(pt - r * p.M);
+  float z0 = p.z[r * p.M + j];
+  float dist = (j + 1 < p.M) ? p.z[r * p.M + j + 1] - z0 : p.sample_dist;
+  float mid = z0 + dist * 0.5f;
+  float pp[3], x[3], dd[3];
+  for (int c = 0; c < 3; ++c) {
+    dd[c] = p.d[r * 3 + c];
+    pp[c] = p.o[r * 3 + c] + dd[c] * mid;
+    x[c] = pp[c] * p.scale;
+  }
+  float row[kEmb];
+  for (int c = 0; c < kEmb; ++c) row[c] = 0.0f;
+  pe_row(x, p.multires, row);
+  float* e = p.E + pt * kEmb;
+  for (int c = 0; c < kEmb; ++c) e[c] = row[c];
+  float aux[kAux];
+  for (int c = 0; c < kAux; ++c) aux[c] = 0.0f;
+  aux[0] = pp[0]; aux[1] = pp[1]; aux[2] = pp[2];
+  if (p.multires_view > 0) pe_row(dd, p.multires_view, aux + 6);
+  else { aux[6] = dd[0]; aux[7] = dd[1]; aux[8] = dd[2]; }
+  float* a = p.AUX + pt * kAux;
+  for (int c = 0; c < kAux; ++c) a[c] = aux[c];
+}
+
+// g = scale * J^T ce with J = d PE / d x0; E holds sin/cos of the encoding
+CNR_HD void body_grad_finish(const GradFinish& p, long pt) {
+  const float* e = p.E + pt * kEmb;
+  const float* c0 = p.ce0 + pt * kEmb;
+  const float* cs = p.ces ? p.ces + pt * kEmb : nullptr;
+  for (int c = 0; c < 3; ++c) {
+    float acc = c0[c] + (cs ? cs[c] : 0.0f);
+    float f = 1.0f;
+    for (int k = 0; k < p.multires; ++k) {
+      float csin = c0[3 + 6 * k + c] + (cs ? cs[3 + 6 * k + c] : 0.0f);
+      float ccos = c0[6 + 6 * k + c] + (cs ? cs[6 + 6 * k + c] : 0.0f);
+      acc = acc + f * (e[6 + 6 * k + c] * csin - e[3 + 6 * k + c] * ccos);
+      f *= 2.0f;
+    }
+    float g = acc * p.scale;
+    p.grad_out[pt * 3 + c] = g;
+    p.AUX[pt * kAux + 3 + c] = g;
+  }
+  if (p.neg_g_as_view) {
+    float v[3] = {-p.AUX[pt * kAux + 3], -p.AUX[pt * kAux + 4], -p.AUX[pt * kAux + 5]};
+    float row[kAux];
+    for (int c = 0; c < kAux; ++c) row[c] = 0.0f;
+    if (p.multires_view > 0) pe_row(v, p.multires_view, row);
+    else { row[0] = v[0]; row[1] = v[1]; row[2] = v[2]; }
+    int npe = p.multires_view > 0 ? 3 + 6 * p.multires_view : 3;
+    for (int c = 0; c < npe; ++c) p.AUX[pt * kAux + 6 + c] = row[c];
+  }
+}
+
+CNR_HD void body_coltop_bwd(const ColTopBwd& p, long pt) {
+  for (int c = 0; c < 3; ++c) {
+    float gc = p.gc_a[pt * 4 + c] + (p.gc_b ? p.gc_b[pt * 4 + c] : 0.0f);
+    float y = p.gcolor[pt * 4 + c];
+    p.out[pt * 4 + c] = p.squeeze ? gc * y * (1.0f - y) : gc;
+  }
+  p.out[pt * 4 + 3] = 0.0f;
+}
+
+CNR_HD void body_gbar_finish(const GbarFinish& p, long pt) {
+  const float* e = p.E + pt * kEmb;
+  float* cb = p.cbar + pt * kEmb;
+  for (int c = 0; c < kEmb; ++c) cb[c] = 0.0f;
+  for (int c = 0; c < 3; ++c) {
+    float gb = p.gbar_alpha[pt * 4 + c];
+    if (p.daux_c) gb += p.daux_c[pt * kAux + 3 + c];
+    if (p.daux_r) gb += p.daux_r[pt * kAux + 3 + c];
+    p.gbar_total[pt * 4 + c] = gb;
+    float t = gb * p.scale;
+    cb[c] = t;
+    float f = 1.0f;
+    for (int k = 0; k < p.multires; ++k) {
+      cb[3 + 6 * k + c] = f * e[6 + 6 * k + c] * t;     // d g / d ce_sin = 2^k cos(2^k x0)
+      cb[6 + 6 * k + c] = -f * e[3 + 6 * k + c] * t;    // d g / d ce_cos = -2^k sin(2^k x0)
+      f *= 2.0f;
+    }
+  }
+  p.gbar_total[pt * 4 + 3] = 0.0f;
+}
+
+// total cotangent of the sample position p (only evaluated when rays require grad)
+CNR_HD void body_pbar_finish(const PbarFinish& p, long pt) {
+  const float* e = p.E + pt * kEmb;
+  for (int c = 0; c < 3; ++c) {
+    float eb = p.ebar0[pt * kEmb + c] + (p.ebars ? p.ebars[pt * kEmb + c] : 0.0f);
+    float x0bar = eb;
+    float second = 0.0f;
+    float f = 1.0f;
+    for (int k = 0; k < p.multires; ++k) {
+      float s = e[3 + 6 * k + c], co = e[6 + 6 * k + c];
+      float ebs = p.ebar0[pt * kEmb + 3 + 6 * k + c] + (p.ebars ? p.ebars[pt * kEmb + 3 + 6 * k + c] : 0.0f);
+      float ebc = p.ebar0[pt * kEmb + 6 + 6 * k + c] + (p.ebars ? p.ebars[pt * kEmb + 6 + 6 * k + c] : 0.0f);
+      x0bar += f * (co * ebs - s * ebc);
+      float ces = p.ce0[pt * kEmb + 3 + 6 * k + c] + (p.ces ? p.ces[pt * kEmb + 3 + 6 * k + c] : 0.0f);
+      float cec = p.ce0[pt * kEmb + 6 + 6 * k + c] + (p.ces ? p.ces[pt * kEmb + 6 + 6 * k + c] : 0.0f);
+      second += f * f * (-s * ces - co * cec);
+      f *= 2.0f;
+    }
+    x0bar += p.gbar_total[pt * 4 + c] * p.scale * second;
+    float pb = x0bar * p.scale;
+    if (p.daux_c) pb += p.daux_c[pt * kAux + c];
+    if (p.daux_r) pb += p.daux_r[pt * kAux + c];
+    p.pbar[pt * 4 + c] = pb;
+  }
+  p.pbar[pt * 4 + 3] = 0.0f;
+}
+
+}  // namespace cnr

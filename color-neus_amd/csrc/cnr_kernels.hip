@@ -1,0 +1,631 @@
+// HIP kernels for gfx950 (MI355X / CDNA4).  No CUDA compatibility layer, no dual paths: wave = 64 lanes,
+// FP32 MFMA (v_mfma_f32_32x32x2_f32) for every fully-connected layer, LDS-staged tiles, per-ray kernels
+// with one wavefront per ray and shuffle scans.
+//
+// Kernels
+//   layer_gemm_kernel<NT>   C[P x N] = epilogue(A[P x K] * W[N x K]^T), 128-point tile x full N per workgroup,
+//                           K streamed in 16-wide slabs through double-buffered LDS, fused prologue (operand view)
+//                           and fused epilogue (bias / softplus' / relu mask / second-order terms / split stores)
+//   dw_gemm_kernel<...>     dW[N x K] = sum_pts X[pt][n] * Y[pt][k]  (weight gradients; reduce dimension = points)
+//   upsample / merge / composite_fwd / composite_bwd: one wavefront per ray, ray state staged in LDS
+//   point-wise kernels: positional encodings, PE Jacobians, weight preparation (weight-norm) and its backward
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "cnr_backend.h"
+#include "cnr_bodies.h"
+#include "cnr_hip_util.h"
+
+namespace cnr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+hipError_t g_first_error = hipSuccess;
+const char* g_first_error_where = "";
+
+const char* be_name() { return "hip-gfx950"; }
+
+int be_check_last_error(char* msg, size_t n) {
+  if (g_first_error == hipSuccess) return 0;
+  snprintf(msg, n, "HIP error in %s: %s", g_first_error_where, hipGetErrorString(g_first_error));
+  g_first_error = hipSuccess;
+  return -1;
+}
+
+void be_memset_zero(void* p, size_t bytes, cnr_stream s) {
+  hipError_t e = hipMemsetAsync(p, 0, bytes, s);
+  if (e != hipSuccess && g_first_error == hipSuccess) { g_first_error = e; g_first_error_where = "memset"; }
+}
+
+// ================================================================================================
+// point-wise kernels
+// ================================================================================================
+#define CNR_PW_KERNEL(NAME, PARAM, BODY)                                                    \
+  __global__ __launch_bounds__(256) void NAME##_kernel(const PARAM p, long n) {              \
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)   \
+      BODY(p, i);                                                                            \
+  }                                                                                          \
+  static void NAME##_launch(const PARAM& p, long n, cnr_stream s) {                          \
+    if (n <= 0) return;                                                                      \
+    long blocks = (n + 255) / 256;                                                           \
+    if (blocks > 8192) blocks = 8192;                                                        \
+    hipLaunchKernelGGL(NAME##_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n);        \
+    CNR_LAUNCH_CHECK(#NAME);                                                                 \
+  }
+
+CNR_PW_KERNEL(embed_z, EmbedZ, body_embed_z)
+CNR_PW_KERNEL(embed_pts, EmbedPts, body_embed_pts)
+CNR_PW_KERNEL(fine_setup, FineSetup, body_fine_setup)
+CNR_PW_KERNEL(grad_finish, GradFinish, body_grad_finish)
+CNR_PW_KERNEL(coltop_bwd, ColTopBwd, body_coltop_bwd)
+CNR_PW_KERNEL(gbar_finish, GbarFinish, body_gbar_finish)
+CNR_PW_KERNEL(pbar_finish, PbarFinish, body_pbar_finish)
+
+void be_embed_z(const EmbedZ& p, cnr_stream s) { embed_z_launch(p, p.R * p.m, s); }
+void be_embed_pts(const EmbedPts& p, cnr_stream s) { embed_pts_launch(p, p.n, s); }
+void be_fine_setup(const FineSetup& p, cnr_stream s) { fine_setup_launch(p, p.R * p.M, s); }
+void be_grad_finish(const GradFinish& p, cnr_stream s) { grad_finish_launch(p, p.P, s); }
+void be_coltop_bwd(const ColTopBwd& p, cnr_stream s) { coltop_bwd_launch(p, p.P, s); }
+void be_gbar_finish(const GbarFinish& p, cnr_stream s) { gbar_finish_launch(p, p.P, s); }
+void be_pbar_finish(const PbarFinish& p, cnr_stream s) { pbar_finish_launch(p, p.P, s); }
+
+// ------------------------------------------------------------------------------------------------
+// block reductions
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x = fmaxf(x, __shfl_xor(x, d));
+  return x;
+}
+__device__ __forceinline__ int wave_min_int(int x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { int y = __shfl_xor(x, d); x = y < x ? y : x; }
+  return x;
+}
+// sum over a 256-thread block; result valid in every thread
+__device__ __forceinline__ float block_sum_256(float x, float* sh4 /*>= 4 floats*/) {
+  x = wave_sum(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+
+__device__ __forceinline__ double block_sum_256d(double x, double* sh4) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+
+// effective weights: weight-norm, column permutation, zero padding, transpose copy.  One block per padded row.
+__global__ __launch_bounds__(256) void prep_weight_kernel(const PrepWeight p) {
+  __shared__ double redd[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const bool real = n < p.n;
+  float scale = 1.0f;
+  if (p.g != nullptr) {
+    double ss = 0.0;   // row norm in double: weight_norm is the most rounding-sensitive step (x inv_s downstream)
+    if (real)
+      for (int c = tid; c < p.k_ref; c += 256) { double x = p.v[(long)n * p.k_ref + c]; ss += x * x; }
+    ss = block_sum_256d(ss, redd);
+    if (real) scale = p.g[n] / (float)sqrt(ss);
+  }
+  for (int j = tid; j < p.kpad; j += 256) {
+    float val = 0.0f;
+    if (real && j < p.ldw) {
+      int src = -1;
+      for (int q = 0; q < p.nseg; ++q)
+        if (j >= p.seg[q].dst && j < p.seg[q].dst + p.seg[q].len) src = p.seg[q].src + (j - p.seg[q].dst);
+      if (src >= 0) val = p.v[(long)n * p.k_ref + src] * scale;
+    }
+    if (j < p.ldw) p.W[(long)n * p.ldw + j] = val;
+    if (n < p.ldwt) p.Wt[(long)j * p.ldwt + n] = val;
+  }
+  if (tid == 0) p.bias[n] = real && p.b ? p.b[n] : 0.0f;
+}
+void be_prep_weight(const PrepWeight& p, cnr_stream s) {
+  hipLaunchKernelGGL(prep_weight_kernel, dim3(p.npad), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("prep_weight");
+}
+
+// reduce dW partials, undo the column permutation, weight-norm backward.  One block per output row.
+__global__ __launch_bounds__(256) void finish_weight_kernel(const FinishWeight p) {
+  __shared__ float red[4];
+  __shared__ double redd[4];
+  __shared__ float dwi[512];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int j = tid; j < p.ldk; j += 256) {
+    float s = 0.0f;
+    for (int c = 0; c < p.nchunk; ++c) s += p.partial[((long)c * p.npad + n) * p.ldk + j];
+    dwi[j] = s;
+  }
+  __syncthreads();
+  // gather into reference column order (held in registers: <= 2 columns per thread for k_ref <= 512)
+  float dref[2] = {0.f, 0.f};
+  int cref[2] = {-1, -1};
+  int cnt = 0;
+  for (int c = tid; c < p.k_ref && cnt < 2; c += 256, ++cnt) {
+    int dst = -1;
+    for (int q = 0; q < p.nseg; ++q)
+      if (c >= p.seg[q].src && c < p.seg[q].src + p.seg[q].len) dst = p.seg[q].dst + (c - p.seg[q].src);
+    cref[cnt] = c;
+    dref[cnt] = dst >= 0 ? dwi[dst] : 0.0f;
+  }
+  if (p.g != nullptr) {
+    double dotd = 0.0, ssd = 0.0;
+    for (int q = 0; q < 2; ++q)
+      if (cref[q] >= 0) { double vv = p.v[(long)n * p.k_ref + cref[q]]; dotd += (double)dref[q] * vv; ssd += vv * vv; }
+    dotd = block_sum_256d(dotd, redd);
+    ssd = block_sum_256d(ssd, redd);
+    const float dot = (float)dotd;
+    const float nrm = (float)sqrt(ssd);
+    const float gg = p.g[n];
+    if (tid == 0) p.dg[n] = dot / nrm;
+    for (int q = 0; q < 2; ++q)
+      if (cref[q] >= 0) {
+        float vv = p.v[(long)n * p.k_ref + cref[q]];
+        p.dv[(long)n * p.k_ref + cref[q]] = (gg / nrm) * (dref[q] - dot / (nrm * nrm) * vv);
+      }
+  } else {
+    for (int q = 0; q < 2; ++q)
+      if (cref[q] >= 0) p.dv[(long)n * p.k_ref + cref[q]] = dref[q];
+  }
+  if (p.db != nullptr && p.colsum != nullptr) {
+    float s = 0.0f;
+    for (int c = tid; c < p.nchunk; c += 256) s += p.colsum[(long)c * p.npad + n];
+    s = block_sum_256(s, red);
+    if (tid == 0) p.db[n] = s;
+  }
+}
+void be_finish_weight(const FinishWeight& p, cnr_stream s) {
+  hipLaunchKernelGGL(finish_weight_kernel, dim3(p.n), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("finish_weight");
+}
+
+__global__ __launch_bounds__(256) void reduce_eik_kernel(const ReduceEik p) {
+  __shared__ float red[4];
+  float a = 0.0f, b = 0.0f;
+  for (long r = threadIdx.x; r < p.R; r += 256) { a += p.partial[r * 2]; b += p.partial[r * 2 + 1]; }
+  a = block_sum_256(a, red);
+  b = block_sum_256(b, red);
+  if (threadIdx.x == 0) {
+    p.sums[0] = a; p.sums[1] = b;
+    *p.gradient_error = a / (b + 1e-5f);
+  }
+}
+void be_reduce_eik(const ReduceEik& p, cnr_stream s) {
+  hipLaunchKernelGGL(reduce_eik_kernel, dim3(1), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("reduce_eik");
+}
+
+__global__ __launch_bounds__(256) void variance_finish_kernel(const VarianceFinish p) {
+  __shared__ float red[4];
+  float a = 0.0f;
+  for (long r = threadIdx.x; r < p.R; r += 256) a += p.partial[r];
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) {
+    float raw = expf(p.variance[0] * 10.0f);
+    *p.d_variance = (raw >= 1e-6f && raw <= 1e6f) ? a * 10.0f * raw : 0.0f;
+  }
+}
+void be_variance_finish(const VarianceFinish& p, cnr_stream s) {
+  hipLaunchKernelGGL(variance_finish_kernel, dim3(1), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("variance_finish");
+}
+
+// ================================================================================================
+// per-ray kernels: one wavefront per ray, 4 rays per workgroup, ray state staged in LDS
+// ================================================================================================
+__device__ __forceinline__ float wave_scan_incl_add(float x, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { float y = __shfl_up(x, d); if (lane >= d) x = y + x; }
+  return x;
+}
+__device__ __forceinline__ float wave_scan_incl_mul(float x, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { float y = __shfl_up(x, d); if (lane >= d) x = y * x; }
+  return x;
+}
+// reverse inclusive scan: result[lane] = sum_{l >= lane} x[l]
+__device__ __forceinline__ float wave_scan_incl_add_rev(float x, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { float y = __shfl_down(x, d); if (lane + d < 64) x = x + y; }
+  return x;
+}
+
+__global__ __launch_bounds__(256) void upsample_kernel(const UpSample p) {
+  __shared__ float sh[4][5][kMaxRaySamples];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long ray = (long)blockIdx.x * 4 + wave;
+  const bool active = ray < p.R;
+  if (!active) ray = p.R - 1;
+  float* zs = sh[wave][0]; float* ss = sh[wave][1]; float* cs = sh[wave][2]; float* rs = sh[wave][3]; float* as = sh[wave][4];
+  const int n = p.n, nsec = p.n - 1;
+  float o[3], d[3];
+  for (int c = 0; c < 3; ++c) { o[c] = p.o[ray * 3 + c]; d[c] = p.d[ray * 3 + c]; }
+  for (int i = lane; i < n; i += 64) {
+    float z = p.z[ray * p.ldz + i];
+    zs[i] = z;
+    ss[i] = p.sdf[ray * p.lds + i];
+    float x = o[0] + d[0] * z, y = o[1] + d[1] * z, w = o[2] + d[2] * z;
+    rs[i] = sqrtf(x * x + y * y + w * w);
+  }
+  __syncthreads();
+  for (int i = lane; i < nsec; i += 64) cs[i] = (ss[i + 1] - ss[i]) / (zs[i + 1] - zs[i] + 1e-5f);
+  __syncthreads();
+  for (int i = lane; i < nsec; i += 64) {
+    float prev = i > 0 ? cs[i - 1] : 0.0f;
+    float c = fminf(prev, cs[i]);
+    c = fminf(fmaxf(c, -1e3f), 0.0f);
+    const bool inside = rs[i] < 1.0f || rs[i + 1] < 1.0f;
+    c = inside ? c : c * 0.0f;
+    as[i] = upsample_alpha(ss[i], ss[i + 1], zs[i], zs[i + 1], c, p.inv_s);
+  }
+  __syncthreads();
+  // weights = alpha * exclusive cumprod(1 - alpha + 1e-7), + 1e-5 (sample_pdf), and their sum
+  float carry = 1.0f, part = 0.0f;
+  for (int base = 0; base < nsec; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < nsec;
+    const float a = ok ? as[i] : 0.0f;
+    const float f = ok ? 1.0f - a + 1e-7f : 1.0f;
+    const float incl = wave_scan_incl_mul(f, lane);
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.0f;
+    const float w = a * (carry * excl) + 1e-5f;
+    if (ok) { as[i] = w; part += w; }
+    carry = carry * __shfl(incl, 63);
+  }
+  const float total = wave_sum(part);
+  __syncthreads();
+  // cdf (n entries, cdf[0] = 0) -> cs
+  float csum = 0.0f;
+  for (int base = 0; base < nsec; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < nsec;
+    const float pdf = ok ? as[i] / total : 0.0f;
+    const float incl = wave_scan_incl_add(pdf, lane);
+    if (ok) cs[i + 1] = csum + incl;
+    csum = csum + __shfl(incl, 63);
+  }
+  if (lane == 0) cs[0] = 0.0f;
+  __syncthreads();
+  if (lane < p.m && active) {
+    const float u = linspace_at(0.5f / (float)p.m, 1.0f - 0.5f / (float)p.m, p.m, lane);
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (cs[mid] > u) hi = mid; else lo = mid + 1; }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < n - 1 ? lo : n - 1;
+    const float c0 = cs[below], c1 = cs[above];
+    const float b0 = zs[below], b1 = zs[above];
+    float den = c1 - c0;
+    if (den < 1e-5f) den = 1.0f;
+    const float t = (u - c0) / den;
+    p.new_z[ray * p.m + lane] = b0 + t * (b1 - b0);
+  }
+}
+void be_upsample(const UpSample& p, cnr_stream s) {
+  hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("upsample");
+}
+
+__global__ __launch_bounds__(256) void merge_kernel(const MergeZ p) {
+  __shared__ float sh[4][2][kMaxRaySamples];
+  __shared__ float shn[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long ray = (long)blockIdx.x * 4 + wave;
+  const bool active = ray < p.R;
+  if (!active) ray = p.R - 1;
+  float* zs = sh[wave][0]; float* ss = sh[wave][1]; float* nz = shn[wave][0]; float* ns = shn[wave][1];
+  const bool with_sdf = p.new_sdf != nullptr;
+  for (int i = lane; i < p.n; i += 64) { zs[i] = p.z[ray * p.ldz + i]; ss[i] = with_sdf ? p.sdf_in[ray * p.lds_in + i] : 0.0f; }
+  for (int j = lane; j < p.m; j += 64) { nz[j] = p.new_z[ray * p.m + j]; ns[j] = with_sdf ? p.new_sdf[ray * p.m + j] : 0.0f; }
+  __syncthreads();
+  if (active) {
+    for (int i = lane; i < p.n; i += 64) {   // old sample i: stable position = i + #(new < z_i)
+      const float z = zs[i];
+      int cnt = 0;
+      for (int j = 0; j < p.m; ++j) cnt += nz[j] < z ? 1 : 0;
+      p.z[ray * p.ldz + i + cnt] = z;
+      if (with_sdf) p.sdf_out[ray * p.lds_out + i + cnt] = ss[i];
+    }
+    for (int j = lane; j < p.m; j += 64) {   // new sample j: position = j + #(old <= new_j), new samples keep their order
+      const float z = nz[j];
+      int lo = 0, hi = p.n;
+      while (lo < hi) { int mid = (lo + hi) >> 1; if (zs[mid] > z) hi = mid; else lo = mid + 1; }
+      int rank = 0;   // rank among the new samples (they are monotone in practice; this keeps the merge a bijection regardless)
+      for (int q2 = 0; q2 < p.m; ++q2) rank += (nz[q2] < z || (nz[q2] == z && q2 < j)) ? 1 : 0;
+      p.z[ray * p.ldz + lo + rank] = z;
+      if (with_sdf) p.sdf_out[ray * p.lds_out + lo + rank] = ns[j];
+    }
+  }
+}
+void be_merge(const MergeZ& p, cnr_stream s) {
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("merge");
+}
+
+constexpr int kRayChunks = kMaxRaySamples / 64;
+
+struct RaySample {   // forward quantities of one sample, recomputed identically in forward and backward
+  bool ok;
+  float z, dist, relax, inside, gn;
+  float g[3];
+  AlphaOut a;
+};
+
+__device__ __forceinline__ RaySample ray_sample(const float* zs, int j, int M, float sample_dist, const float o[3], const float d[3],
+                                                const float* sdf, const float* g, long pt, float inv_s, float r) {
+  RaySample q;
+  q.ok = j < M;
+  const int jj = q.ok ? j : M - 1;
+  q.z = zs[jj];
+  q.dist = jj + 1 < M ? zs[jj + 1] - q.z : sample_dist;
+  const float mid = q.z + q.dist * 0.5f;
+  const float x = o[0] + d[0] * mid, y = o[1] + d[1] * mid, w = o[2] + d[2] * mid;
+  const float pn = sqrtf(x * x + y * y + w * w);
+  q.inside = pn < 1.0f ? 1.0f : 0.0f;
+  q.relax = pn < 1.2f ? 1.0f : 0.0f;
+  const long p2 = q.ok ? pt : pt - (j - jj);
+  q.g[0] = g[p2 * 3]; q.g[1] = g[p2 * 3 + 1]; q.g[2] = g[p2 * 3 + 2];
+  q.gn = sqrtf(q.g[0] * q.g[0] + q.g[1] * q.g[1] + q.g[2] * q.g[2]);
+  q.a = alpha_forward(sdf[p2], q.g, d, q.dist, inv_s, r);
+  return q;
+}
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeFwd p) {
+  __shared__ float shz[4][kMaxRaySamples];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long ray = (long)blockIdx.x * 4 + wave;
+  const bool active = ray < p.R;
+  if (!active) ray = p.R - 1;
+  float* zs = shz[wave];
+  const int M = p.M;
+  for (int i = lane; i < M; i += 64) zs[i] = p.z[ray * M + i];
+  __syncthreads();
+  float o[3], d[3];
+  for (int c = 0; c < 3; ++c) { o[c] = p.o[ray * 3 + c]; d[c] = p.d[ray * 3 + c]; }
+  const float inv_s = fminf(fmaxf(expf(p.variance[0] * 10.0f), 1e-6f), 1e6f);
+
+  float carry = 1.0f;
+  float wsum = 0.f, wmax = -1.f, dep = 0.f, col[3] = {0.f, 0.f, 0.f}, gcl[3] = {0.f, 0.f, 0.f}, e0 = 0.f, e1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < kRayChunks; ++c) {
+    if (c * 64 < M) {
+      const int j = c * 64 + lane;
+      const long pt = ray * M + j;
+      RaySample q = ray_sample(zs, j, M, p.sample_dist, o, d, p.sdf, p.g, pt, inv_s, p.cos_anneal);
+      const float f = q.ok ? 1.0f - q.a.alpha + 1e-7f : 1.0f;
+      const float incl = wave_scan_incl_mul(f, lane);
+      float excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = 1.0f;
+      const float w = q.ok ? q.a.alpha * (carry * excl) : 0.0f;
+      carry = carry * __shfl(incl, 63);
+      if (q.ok) {
+        wsum += w; wmax = fmaxf(wmax, w); dep += w * q.z;
+        for (int k = 0; k < 3; ++k) col[k] += w * p.color[pt * p.ldcolor + k];
+        if (p.gcolor) for (int k = 0; k < 3; ++k) gcl[k] += w * p.gcolor[pt * p.ldg + k];
+        e0 += q.relax * (q.gn - 1.0f) * (q.gn - 1.0f);
+        e1 += q.relax;
+        if (active) {
+          p.weights[pt] = w;
+          p.cdf_fine[pt] = q.a.pc;
+          p.inside_sphere[pt] = q.inside;
+        }
+      }
+    }
+  }
+  wsum = wave_sum(wsum); wmax = wave_max(wmax); dep = wave_sum(dep);
+  for (int k = 0; k < 3; ++k) { col[k] = wave_sum(col[k]); gcl[k] = wave_sum(gcl[k]); }
+  e0 = wave_sum(e0); e1 = wave_sum(e1);
+  if (lane == 0 && active) {
+    for (int k = 0; k < 3; ++k) {
+      float cc = col[k];
+      if (p.background_rgb) cc = cc + p.background_rgb[k] * (1.0f - wsum);
+      p.color_fine[ray * 3 + k] = cc;
+      if (p.global_color) p.global_color[ray * 3 + k] = gcl[k];
+    }
+    p.weight_sum[ray] = wsum; p.weight_max[ray] = wmax; p.depth[ray] = dep;
+    p.s_val[ray] = 1.0f / inv_s;
+    p.eik_partial[ray * 2] = e0; p.eik_partial[ray * 2 + 1] = e1;
+  }
+}
+void be_composite_fwd(const CompositeFwd& p, cnr_stream s) {
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("composite_fwd");
+}
+
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p) {
+  __shared__ float shz[4][kMaxRaySamples];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long ray = (long)blockIdx.x * 4 + wave;
+  const bool active = ray < p.R;
+  if (!active) ray = p.R - 1;
+  float* zs = shz[wave];
+  const int M = p.M;
+  for (int i = lane; i < M; i += 64) zs[i] = p.z[ray * M + i];
+  __syncthreads();
+  float o[3], d[3];
+  for (int c = 0; c < 3; ++c) { o[c] = p.o[ray * 3 + c]; d[c] = p.d[ray * 3 + c]; }
+  const float inv_s = fminf(fmaxf(expf(p.variance[0] * 10.0f), 1e-6f), 1e6f);
+
+  RaySample q[kRayChunks];
+  float T[kRayChunks], w[kRayChunks];
+  float carry = 1.0f, wsum = 0.0f, wmax = -1.0f;
+#pragma unroll
+  for (int c = 0; c < kRayChunks; ++c) {
+    T[c] = 0.f; w[c] = 0.f;
+    if (c * 64 < M) {
+      const int j = c * 64 + lane;
+      q[c] = ray_sample(zs, j, M, p.sample_dist, o, d, p.sdf, p.g, ray * M + j, inv_s, p.cos_anneal);
+      const float f = q[c].ok ? 1.0f - q[c].a.alpha + 1e-7f : 1.0f;
+      const float incl = wave_scan_incl_mul(f, lane);
+      float excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = 1.0f;
+      T[c] = carry * excl;
+      w[c] = q[c].ok ? q[c].a.alpha * T[c] : 0.0f;
+      carry = carry * __shfl(incl, 63);
+      wsum += w[c];
+      if (q[c].ok) wmax = fmaxf(wmax, w[c]);
+    }
+  }
+  wsum = wave_sum(wsum);
+  wmax = wave_max(wmax);
+  int amax = 1 << 30;
+#pragma unroll
+  for (int c = 0; c < kRayChunks; ++c)
+    if (c * 64 < M && q[c].ok && w[c] == wmax && c * 64 + lane < amax) amax = c * 64 + lane;
+  amax = wave_min_int(amax);
+
+  float dcol[3] = {0.f, 0.f, 0.f}, dglob[3] = {0.f, 0.f, 0.f};
+  if (p.d_color_fine) for (int k = 0; k < 3; ++k) dcol[k] = p.d_color_fine[ray * 3 + k];
+  if (p.d_global_color) for (int k = 0; k < 3; ++k) dglob[k] = p.d_global_color[ray * 3 + k];
+  float dws = p.d_weight_sum ? p.d_weight_sum[ray] : 0.0f;
+  if (p.background_rgb) for (int k = 0; k < 3; ++k) dws -= dcol[k] * p.background_rgb[k];
+  const float ddepth = p.d_depth ? p.d_depth[ray] : 0.0f;
+  const float dwmax = p.d_weight_max ? p.d_weight_max[ray] : 0.0f;
+  const float dge = p.d_gradient_error ? p.d_gradient_error[0] : 0.0f;
+  const float eik_den = p.eik_sums[1] + 1e-5f;
+
+  // d loss / d w_j and the suffix sums S_j = sum_{k>j} wbar_k w_k (reverse scan, chunks from the back)
+  float wbar[kRayChunks], S[kRayChunks];
+  float rcarry = 0.0f;
+#pragma unroll
+  for (int c = kRayChunks - 1; c >= 0; --c) {
+    wbar[c] = 0.f; S[c] = 0.f;
+    if (c * 64 < M) {
+      const int j = c * 64 + lane;
+      const long pt = ray * M + j;
+      float wb = 0.0f;
+      if (q[c].ok) {
+        for (int k = 0; k < 3; ++k) wb += dcol[k] * p.color[pt * p.ldcolor + k];
+        if (p.gcolor) for (int k = 0; k < 3; ++k) wb += dglob[k] * p.gcolor[pt * p.ldg + k];
+        wb += dws + ddepth * q[c].z;
+        if (p.d_weights) wb += p.d_weights[pt];
+        if (j == amax) wb += dwmax;
+      }
+      wbar[c] = wb;
+      const float x = wb * w[c];
+      const float incl = wave_scan_incl_add_rev(x, lane);
+      S[c] = rcarry + (incl - x);
+      rcarry = rcarry + __shfl(incl, 0);
+    }
+  }
+
+  float dinvs = 0.0f, drd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < kRayChunks; ++c) {
+    if (c * 64 < M) {
+      const int j = c * 64 + lane;
+      const long pt = ray * M + j;
+      if (q[c].ok) {
+        const float dalpha = wbar[c] * T[c] - S[c] / (1.0f - q[c].a.alpha + 1e-7f);
+        const AlphaGrad ag = alpha_backward(q[c].a, q[c].dist, inv_s, p.cos_anneal, dalpha, p.d_cdf ? p.d_cdf[pt] : 0.0f);
+        dinvs += ag.d_inv_s;
+        float gb[3];
+        const float ecoef = (q[c].relax > 0.0f && q[c].gn > 0.0f) ? dge / eik_den * 2.0f * (q[c].gn - 1.0f) / q[c].gn : 0.0f;
+        for (int k = 0; k < 3; ++k) {
+          gb[k] = ag.d_tc * d[k] + ecoef * q[c].g[k];
+          if (p.d_gradients) gb[k] += p.d_gradients[pt * 3 + k];
+          drd[k] += ag.d_tc * q[c].g[k];
+        }
+        if (active) {
+          p.ztop[pt * p.ldztop] = ag.d_sdf / p.sdf_scale;
+          for (int k = 0; k < 3; ++k) p.gbar[pt * 4 + k] = gb[k];
+          p.gbar[pt * 4 + 3] = 0.0f;
+          for (int k = 0; k < 3; ++k) {
+            const float cbar = dcol[k] * w[c];                 // cotangent of the composited (relit) colour sample
+            if (p.has_relight) {
+              const float relit = p.color[pt * p.ldcolor + k];
+              const float gc = p.gcolor[pt * p.ldg + k];
+              float tbar, gca = dglob[k] * w[c];
+              if (p.inv_sigmoid) {
+                tbar = cbar * relit * (1.0f - relit);
+                gca += tbar * inverse_sigmoid_grad(gc);
+              } else {
+                const float pass = (relit > 0.0f && relit < 1.0f) ? 1.0f : 0.0f;   // clamp(rgb + sigmoid(h) - 0.5, 0, 1)
+                const float sg = relit - gc + 0.5f;                                 // = sigmoid(h) where the clamp is inactive
+                tbar = cbar * pass * sg * (1.0f - sg);
+                gca += cbar * pass;
+              }
+              p.dtop[pt * 4 + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f);
+              p.gc_a[pt * 4 + k] = gca;
+            } else {
+              p.gc_a[pt * 4 + k] = cbar;
+            }
+          }
+          if (p.has_relight) p.dtop[pt * 4 + 3] = 0.0f;
+          p.gc_a[pt * 4 + 3] = 0.0f;
+        }
+      }
+    }
+  }
+  dinvs = wave_sum(dinvs);
+  for (int k = 0; k < 3; ++k) drd[k] = wave_sum(drd[k]);
+  if (lane == 0 && active) {
+    if (p.d_s_val) dinvs += -p.d_s_val[ray] / (inv_s * inv_s);
+    p.dinvs_partial[ray] = dinvs;
+    if (p.d_rays_d) for (int k = 0; k < 3; ++k) p.d_rays_d[ray * 3 + k] = drd[k];
+  }
+}
+void be_composite_bwd(const CompositeBwd& p, cnr_stream s) {
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("composite_bwd");
+}
+
+// d rays: one wavefront per ray
+__global__ __launch_bounds__(256) void rays_grad_finish_kernel(const RaysGradFinish p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= p.R) return;
+  const int M = p.M;
+  float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+  const int npe = p.multires_view > 0 ? 3 + 6 * p.multires_view : 3;
+  float spe[27];
+  for (int q = 0; q < 27; ++q) spe[q] = 0.0f;
+  for (int j = lane; j < M; j += 64) {
+    const long pt = ray * M + j;
+    const float z0 = p.z[pt];
+    const float dist = j + 1 < M ? p.z[pt + 1] - z0 : p.sample_dist;
+    const float mid = z0 + dist * 0.5f;
+    for (int k = 0; k < 3; ++k) { float pb = p.pbar[pt * 4 + k]; so[k] += pb; sd[k] += pb * mid; }
+    for (int q = 0; q < npe; ++q) {
+      float v = 0.0f;
+      if (p.daux_dir_c) v += p.daux_dir_c[pt * p.lddir + 6 + q];
+      if (p.daux_dir_r) v += p.daux_dir_r[pt * p.lddir + 6 + q];
+      spe[q] += v;
+    }
+  }
+  for (int k = 0; k < 3; ++k) { so[k] = wave_sum(so[k]); sd[k] = wave_sum(sd[k]); }
+  for (int q = 0; q < npe; ++q) spe[q] = wave_sum(spe[q]);
+  if (lane == 0) {
+    for (int k = 0; k < 3; ++k) {
+      const float dk = p.d[ray * 3 + k];
+      float acc = sd[k] + p.d_rays_d_alpha[ray * 3 + k] + spe[k];
+      float f = 1.0f;
+      for (int m = 0; m < p.multires_view; ++m) {
+        acc += f * (cosf(dk * f) * spe[3 + 6 * m + k] - sinf(dk * f) * spe[6 + 6 * m + k]);
+        f *= 2.0f;
+      }
+      p.d_d[ray * 3 + k] = acc;
+      p.d_o[ray * 3 + k] = so[k];
+    }
+  }
+}
+void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s) {
+  hipLaunchKernelGGL(rays_grad_finish_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("rays_grad_finish");
+}
+
+void be_grid_points(float*, cnr_stream) {}
+
+}  // namespace cnr

@@ -1,0 +1,375 @@
+// CPU emulation of the kernel layer -- TEST INFRASTRUCTURE ONLY (built with -DCNR_CPU_EMU into
+// libcolorneus_emu.so, loaded only by tests/ to exercise the host orchestration, operand views, epilogues and
+// per-point bodies without a GPU).  The product path never loads this library.
+//
+// GEMMs are plain loops over the same views / epilogues; per-ray kernels are straightforward serial code.
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#include "cnr_backend.h"
+#include "cnr_bodies.h"
+
+namespace cnr {
+
+const char* be_name() { return "cpu-emu"; }
+int be_check_last_error(char*, size_t) { return 0; }
+void be_memset_zero(void* p, size_t bytes, cnr_stream) { memset(p, 0, bytes); }
+void be_grid_points(float*, cnr_stream) {}
+
+void be_layer_gemm(const LayerGemm& g, cnr_stream) {
+  const int kp = round_up(g.K, 4);
+  std::vector<float> arow(kp + 4);
+#pragma omp parallel for firstprivate(arow)
+  for (long row = 0; row < g.P; ++row) {
+    for (int k = 0; k < kp; k += 4) {
+      f4 v = view_eval4(g.A, row, k);
+      arow[k] = v.x; arow[k + 1] = v.y; arow[k + 2] = v.z; arow[k + 3] = v.w;
+    }
+    for (int n = 0; n < round_up(g.N, 32); ++n) {
+      const float* w = g.W + (long)n * g.ldw;
+#ifdef CNR_EMU_DOUBLE_ACC
+      double accd = 0.0;
+      for (int k = 0; k < g.K; ++k) accd += (double)arow[k] * (double)w[k];
+      float acc = (float)accd;
+#else
+      float acc = 0.0f;
+      for (int k = 0; k < g.K; ++k) acc = fmaf(arow[k], w[k], acc);
+#endif
+      epi_apply(g.E, row, n, acc);
+    }
+  }
+}
+
+void be_dw_gemm(const DwGemm& g, cnr_stream) {
+#pragma omp parallel for
+  for (int chunk = 0; chunk < g.nchunk; ++chunk) {
+    float* out = g.partial + (long)chunk * g.Npad * g.ldk;
+    std::fill(out, out + (long)g.Npad * g.ldk, 0.0f);
+    if (g.colsum) std::fill(g.colsum + (long)chunk * g.Npad, g.colsum + (long)(chunk + 1) * g.Npad, 0.0f);
+    long p0 = chunk * g.chunk_pts, p1 = std::min(g.P, p0 + g.chunk_pts);
+    std::vector<float> x(round_up(g.N, 4) + 4), y(round_up(g.K, 4) + 4);
+    for (int pair = 0; pair < g.npairs; ++pair)
+      for (long pt = p0; pt < p1; ++pt) {
+        for (int n = 0; n < g.N; n += 4) { f4 v = view_eval4(g.X[pair], pt, n); x[n] = v.x; x[n + 1] = v.y; x[n + 2] = v.z; x[n + 3] = v.w; }
+        for (int k = 0; k < g.K; k += 4) { f4 v = view_eval4(g.Y[pair], pt, k); y[k] = v.x; y[k + 1] = v.y; y[k + 2] = v.z; y[k + 3] = v.w; }
+        for (int n = 0; n < g.N; ++n) {
+          float xv = x[n];
+          if (pair == 0 && g.colsum) g.colsum[(long)chunk * g.Npad + n] += xv;
+          if (xv == 0.0f) continue;
+          float* o = out + (long)n * g.ldk;
+          for (int k = 0; k < g.K; ++k) o[k] += xv * y[k];
+        }
+      }
+  }
+}
+
+#define CNR_PW(NAME, PARAM, BODY, COUNT)                \
+  void NAME(const PARAM& p, cnr_stream) {               \
+    const long n_ = (COUNT);                            \
+    _Pragma("omp parallel for") for (long i = 0; i < n_; ++i) BODY(p, i); \
+  }
+CNR_PW(be_embed_z, EmbedZ, body_embed_z, p.R* p.m)
+CNR_PW(be_embed_pts, EmbedPts, body_embed_pts, p.n)
+CNR_PW(be_fine_setup, FineSetup, body_fine_setup, p.R* p.M)
+CNR_PW(be_grad_finish, GradFinish, body_grad_finish, p.P)
+CNR_PW(be_coltop_bwd, ColTopBwd, body_coltop_bwd, p.P)
+CNR_PW(be_gbar_finish, GbarFinish, body_gbar_finish, p.P)
+CNR_PW(be_pbar_finish, PbarFinish, body_pbar_finish, p.P)
+
+static int seg_src_of(const Segment* seg, int nseg, int j) {
+  for (int q = 0; q < nseg; ++q)
+    if (j >= seg[q].dst && j < seg[q].dst + seg[q].len) return seg[q].src + (j - seg[q].dst);
+  return -1;
+}
+
+void be_prep_weight(const PrepWeight& p, cnr_stream) {
+  for (int n = 0; n < p.npad; ++n) {
+    const bool real = n < p.n;
+    float scale = 1.0f;
+    if (p.g && real) {
+      double ss = 0.0;   // row norm accumulated in double (weight_norm is the most rounding-sensitive step: x inv_s downstream)
+      for (int c = 0; c < p.k_ref; ++c) { double x = p.v[(long)n * p.k_ref + c]; ss += x * x; }
+      scale = p.g[n] / (float)sqrt(ss);
+    }
+    for (int j = 0; j < p.kpad; ++j) {
+      float val = 0.0f;
+      if (real && j < p.ldw) {
+        int src = seg_src_of(p.seg, p.nseg, j);
+        if (src >= 0) val = p.v[(long)n * p.k_ref + src] * scale;
+      }
+      if (j < p.ldw) p.W[(long)n * p.ldw + j] = val;
+      if (n < p.ldwt) p.Wt[(long)j * p.ldwt + n] = val;
+    }
+    p.bias[n] = real && p.b ? p.b[n] : 0.0f;
+  }
+}
+
+void be_finish_weight(const FinishWeight& p, cnr_stream) {
+  std::vector<float> dwi(p.ldk), dref(p.k_ref);
+  for (int n = 0; n < p.n; ++n) {
+    for (int j = 0; j < p.ldk; ++j) {
+      float s = 0.0f;
+      for (int c = 0; c < p.nchunk; ++c) s += p.partial[((long)c * p.npad + n) * p.ldk + j];
+      dwi[j] = s;
+    }
+    for (int c = 0; c < p.k_ref; ++c) {
+      int dst = -1;
+      for (int q = 0; q < p.nseg; ++q)
+        if (c >= p.seg[q].src && c < p.seg[q].src + p.seg[q].len) dst = p.seg[q].dst + (c - p.seg[q].src);
+      dref[c] = dst >= 0 ? dwi[dst] : 0.0f;
+    }
+    if (p.g) {
+      double dotd = 0.0, ssd = 0.0;
+      for (int c = 0; c < p.k_ref; ++c) { double vv = p.v[(long)n * p.k_ref + c]; dotd += (double)dref[c] * vv; ssd += vv * vv; }
+      float dot = (float)dotd, nrm = (float)sqrt(ssd), gg = p.g[n];
+      p.dg[n] = dot / nrm;
+      for (int c = 0; c < p.k_ref; ++c) {
+        float vv = p.v[(long)n * p.k_ref + c];
+        p.dv[(long)n * p.k_ref + c] = (gg / nrm) * (dref[c] - dot / (nrm * nrm) * vv);
+      }
+    } else {
+      for (int c = 0; c < p.k_ref; ++c) p.dv[(long)n * p.k_ref + c] = dref[c];
+    }
+    if (p.db && p.colsum) {
+      float s = 0.0f;
+      for (int c = 0; c < p.nchunk; ++c) s += p.colsum[(long)c * p.npad + n];
+      p.db[n] = s;
+    }
+  }
+}
+
+void be_reduce_eik(const ReduceEik& p, cnr_stream) {
+  float a = 0.0f, b = 0.0f;
+  for (long r = 0; r < p.R; ++r) { a += p.partial[r * 2]; b += p.partial[r * 2 + 1]; }
+  p.sums[0] = a; p.sums[1] = b;
+  *p.gradient_error = a / (b + 1e-5f);
+}
+
+void be_variance_finish(const VarianceFinish& p, cnr_stream) {
+  float a = 0.0f;
+  for (long r = 0; r < p.R; ++r) a += p.partial[r];
+  float raw = expf(p.variance[0] * 10.0f);
+  *p.d_variance = (raw >= 1e-6f && raw <= 1e6f) ? a * 10.0f * raw : 0.0f;
+}
+
+void be_upsample(const UpSample& p, cnr_stream) {
+#pragma omp parallel for
+  for (long ray = 0; ray < p.R; ++ray) {
+    const int n = p.n, nsec = n - 1;
+    const float* z = p.z + ray * p.ldz;
+    const float* s = p.sdf + ray * p.lds;
+    std::vector<float> rad(n), cs(n), w(n), cdf(n);
+    for (int i = 0; i < n; ++i) {
+      float x = p.o[ray * 3] + p.d[ray * 3] * z[i], y = p.o[ray * 3 + 1] + p.d[ray * 3 + 1] * z[i], q = p.o[ray * 3 + 2] + p.d[ray * 3 + 2] * z[i];
+      rad[i] = sqrtf(x * x + y * y + q * q);
+    }
+    for (int i = 0; i < nsec; ++i) cs[i] = (s[i + 1] - s[i]) / (z[i + 1] - z[i] + 1e-5f);
+    float T = 1.0f, total = 0.0f;
+    for (int i = 0; i < nsec; ++i) {
+      float prev = i > 0 ? cs[i - 1] : 0.0f;
+      float c = std::min(prev, cs[i]);
+      c = std::min(std::max(c, -1e3f), 0.0f);
+      if (!(rad[i] < 1.0f || rad[i + 1] < 1.0f)) c = c * 0.0f;
+      float a = upsample_alpha(s[i], s[i + 1], z[i], z[i + 1], c, p.inv_s);
+      w[i] = a * T + 1e-5f;
+      T = T * (1.0f - a + 1e-7f);
+      total += w[i];
+    }
+    cdf[0] = 0.0f;
+    float run = 0.0f;
+    for (int i = 0; i < nsec; ++i) { run += w[i] / total; cdf[i + 1] = run; }
+    for (int k = 0; k < p.m; ++k) {
+      float u = linspace_at(0.5f / (float)p.m, 1.0f - 0.5f / (float)p.m, p.m, k);
+      int idx = (int)(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+      int below = std::max(idx - 1, 0), above = std::min(idx, n - 1);
+      float den = cdf[above] - cdf[below];
+      if (den < 1e-5f) den = 1.0f;
+      float t = (u - cdf[below]) / den;
+      p.new_z[ray * p.m + k] = z[below] + t * (z[above] - z[below]);
+    }
+  }
+}
+
+void be_merge(const MergeZ& p, cnr_stream) {
+#pragma omp parallel for
+  for (long ray = 0; ray < p.R; ++ray) {
+    std::vector<float> z(p.z + ray * p.ldz, p.z + ray * p.ldz + p.n), s(p.n, 0.0f);
+    if (p.new_sdf) s.assign(p.sdf_in + ray * p.lds_in, p.sdf_in + ray * p.lds_in + p.n);
+    const float* nz = p.new_z + ray * p.m;
+    for (int i = 0; i < p.n; ++i) {
+      int cnt = 0;
+      for (int j = 0; j < p.m; ++j) cnt += nz[j] < z[i] ? 1 : 0;
+      p.z[ray * p.ldz + i + cnt] = z[i];
+      if (p.new_sdf) p.sdf_out[ray * p.lds_out + i + cnt] = s[i];
+    }
+    for (int j = 0; j < p.m; ++j) {
+      int lo = (int)(std::upper_bound(z.begin(), z.end(), nz[j]) - z.begin());
+      int rank = 0;
+      for (int q = 0; q < p.m; ++q) rank += (nz[q] < nz[j] || (nz[q] == nz[j] && q < j)) ? 1 : 0;
+      p.z[ray * p.ldz + lo + rank] = nz[j];
+      if (p.new_sdf) p.sdf_out[ray * p.lds_out + lo + rank] = p.new_sdf[ray * p.m + j];
+    }
+  }
+}
+
+struct SampleF {
+  float z, dist, relax, inside, gn, g[3];
+  AlphaOut a;
+};
+static SampleF sample_fwd(const float* z, int j, int M, float sample_dist, const float* o, const float* d, const float* sdf,
+                          const float* g, long pt, float inv_s, float r) {
+  SampleF q;
+  q.z = z[j];
+  q.dist = j + 1 < M ? z[j + 1] - q.z : sample_dist;
+  float mid = q.z + q.dist * 0.5f;
+  float x = o[0] + d[0] * mid, y = o[1] + d[1] * mid, w = o[2] + d[2] * mid;
+  float pn = sqrtf(x * x + y * y + w * w);
+  q.inside = pn < 1.0f ? 1.0f : 0.0f;
+  q.relax = pn < 1.2f ? 1.0f : 0.0f;
+  for (int k = 0; k < 3; ++k) q.g[k] = g[pt * 3 + k];
+  q.gn = sqrtf(q.g[0] * q.g[0] + q.g[1] * q.g[1] + q.g[2] * q.g[2]);
+  q.a = alpha_forward(sdf[pt], q.g, d, q.dist, inv_s, r);
+  return q;
+}
+
+void be_composite_fwd(const CompositeFwd& p, cnr_stream) {
+  const float inv_s = std::min(std::max(expf(p.variance[0] * 10.0f), 1e-6f), 1e6f);
+#pragma omp parallel for
+  for (long ray = 0; ray < p.R; ++ray) {
+    const int M = p.M;
+    const float* z = p.z + ray * M;
+    float T = 1.0f, wsum = 0.f, wmax = -1.f, dep = 0.f, col[3] = {0, 0, 0}, gcl[3] = {0, 0, 0}, e0 = 0.f, e1 = 0.f;
+    for (int j = 0; j < M; ++j) {
+      long pt = ray * M + j;
+      SampleF q = sample_fwd(z, j, M, p.sample_dist, p.o + ray * 3, p.d + ray * 3, p.sdf, p.g, pt, inv_s, p.cos_anneal);
+      float w = q.a.alpha * T;
+      T = T * (1.0f - q.a.alpha + 1e-7f);
+      wsum += w; wmax = std::max(wmax, w); dep += w * q.z;
+      for (int k = 0; k < 3; ++k) col[k] += w * p.color[pt * p.ldcolor + k];
+      if (p.gcolor) for (int k = 0; k < 3; ++k) gcl[k] += w * p.gcolor[pt * p.ldg + k];
+      e0 += q.relax * (q.gn - 1.0f) * (q.gn - 1.0f); e1 += q.relax;
+      p.weights[pt] = w; p.cdf_fine[pt] = q.a.pc; p.inside_sphere[pt] = q.inside;
+    }
+    for (int k = 0; k < 3; ++k) {
+      float cc = col[k];
+      if (p.background_rgb) cc = cc + p.background_rgb[k] * (1.0f - wsum);
+      p.color_fine[ray * 3 + k] = cc;
+      if (p.global_color) p.global_color[ray * 3 + k] = gcl[k];
+    }
+    p.weight_sum[ray] = wsum; p.weight_max[ray] = wmax; p.depth[ray] = dep; p.s_val[ray] = 1.0f / inv_s;
+    p.eik_partial[ray * 2] = e0; p.eik_partial[ray * 2 + 1] = e1;
+  }
+}
+
+void be_composite_bwd(const CompositeBwd& p, cnr_stream) {
+  const float inv_s = std::min(std::max(expf(p.variance[0] * 10.0f), 1e-6f), 1e6f);
+  const float dge = p.d_gradient_error ? p.d_gradient_error[0] : 0.0f;
+  const float eik_den = p.eik_sums[1] + 1e-5f;
+#pragma omp parallel for
+  for (long ray = 0; ray < p.R; ++ray) {
+    const int M = p.M;
+    const float* z = p.z + ray * M;
+    const float* d = p.d + ray * 3;
+    std::vector<SampleF> q(M);
+    std::vector<float> T(M), w(M), wbar(M), S(M);
+    float t = 1.0f, wmax = -1.0f;
+    int amax = 0;
+    for (int j = 0; j < M; ++j) {
+      q[j] = sample_fwd(z, j, M, p.sample_dist, p.o + ray * 3, d, p.sdf, p.g, ray * M + j, inv_s, p.cos_anneal);
+      T[j] = t; w[j] = q[j].a.alpha * t; t = t * (1.0f - q[j].a.alpha + 1e-7f);
+      if (w[j] > wmax) { wmax = w[j]; amax = j; }
+    }
+    float dcol[3] = {0, 0, 0}, dglob[3] = {0, 0, 0};
+    if (p.d_color_fine) for (int k = 0; k < 3; ++k) dcol[k] = p.d_color_fine[ray * 3 + k];
+    if (p.d_global_color) for (int k = 0; k < 3; ++k) dglob[k] = p.d_global_color[ray * 3 + k];
+    float dws = p.d_weight_sum ? p.d_weight_sum[ray] : 0.0f;
+    if (p.background_rgb) for (int k = 0; k < 3; ++k) dws -= dcol[k] * p.background_rgb[k];
+    const float ddepth = p.d_depth ? p.d_depth[ray] : 0.0f, dwmax = p.d_weight_max ? p.d_weight_max[ray] : 0.0f;
+    for (int j = 0; j < M; ++j) {
+      long pt = ray * M + j;
+      float wb = 0.0f;
+      for (int k = 0; k < 3; ++k) wb += dcol[k] * p.color[pt * p.ldcolor + k];
+      if (p.gcolor) for (int k = 0; k < 3; ++k) wb += dglob[k] * p.gcolor[pt * p.ldg + k];
+      wb += dws + ddepth * q[j].z;
+      if (p.d_weights) wb += p.d_weights[pt];
+      if (j == amax) wb += dwmax;
+      wbar[j] = wb;
+    }
+    float run = 0.0f;
+    for (int j = M - 1; j >= 0; --j) { S[j] = run; run += wbar[j] * w[j]; }
+    float dinvs = 0.0f, drd[3] = {0, 0, 0};
+    for (int j = 0; j < M; ++j) {
+      long pt = ray * M + j;
+      float dalpha = wbar[j] * T[j] - S[j] / (1.0f - q[j].a.alpha + 1e-7f);
+      AlphaGrad ag = alpha_backward(q[j].a, q[j].dist, inv_s, p.cos_anneal, dalpha, p.d_cdf ? p.d_cdf[pt] : 0.0f);
+      dinvs += ag.d_inv_s;
+      float ecoef = (q[j].relax > 0.0f && q[j].gn > 0.0f) ? dge / eik_den * 2.0f * (q[j].gn - 1.0f) / q[j].gn : 0.0f;
+      for (int k = 0; k < 3; ++k) {
+        float gb = ag.d_tc * d[k] + ecoef * q[j].g[k];
+        if (p.d_gradients) gb += p.d_gradients[pt * 3 + k];
+        p.gbar[pt * 4 + k] = gb;
+        drd[k] += ag.d_tc * q[j].g[k];
+      }
+      p.gbar[pt * 4 + 3] = 0.0f;
+      p.ztop[pt * p.ldztop] = ag.d_sdf / p.sdf_scale;
+      for (int k = 0; k < 3; ++k) {
+        float cbar = dcol[k] * w[j];
+        if (p.has_relight) {
+          float relit = p.color[pt * p.ldcolor + k], gc = p.gcolor[pt * p.ldg + k];
+          float tbar, gca = dglob[k] * w[j];
+          if (p.inv_sigmoid) {
+            tbar = cbar * relit * (1.0f - relit);
+            gca += tbar * inverse_sigmoid_grad(gc);
+          } else {
+            float pass = (relit > 0.0f && relit < 1.0f) ? 1.0f : 0.0f;
+            float sg = relit - gc + 0.5f;
+            tbar = cbar * pass * sg * (1.0f - sg);
+            gca += cbar * pass;
+          }
+          p.dtop[pt * 4 + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f);
+          p.gc_a[pt * 4 + k] = gca;
+        } else {
+          p.gc_a[pt * 4 + k] = cbar;
+        }
+      }
+      if (p.has_relight) p.dtop[pt * 4 + 3] = 0.0f;
+      p.gc_a[pt * 4 + 3] = 0.0f;
+    }
+    if (p.d_s_val) dinvs += -p.d_s_val[ray] / (inv_s * inv_s);
+    p.dinvs_partial[ray] = dinvs;
+    if (p.d_rays_d) for (int k = 0; k < 3; ++k) p.d_rays_d[ray * 3 + k] = drd[k];
+  }
+}
+
+void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream) {
+  const int npe = p.multires_view > 0 ? 3 + 6 * p.multires_view : 3;
+  for (long ray = 0; ray < p.R; ++ray) {
+    float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, spe[27];
+    for (int q = 0; q < 27; ++q) spe[q] = 0.0f;
+    for (int j = 0; j < p.M; ++j) {
+      long pt = ray * p.M + j;
+      float z0 = p.z[pt];
+      float dist = j + 1 < p.M ? p.z[pt + 1] - z0 : p.sample_dist;
+      float mid = z0 + dist * 0.5f;
+      for (int k = 0; k < 3; ++k) { float pb = p.pbar[pt * 4 + k]; so[k] += pb; sd[k] += pb * mid; }
+      for (int q = 0; q < npe; ++q) {
+        if (p.daux_dir_c) spe[q] += p.daux_dir_c[pt * p.lddir + 6 + q];
+        if (p.daux_dir_r) spe[q] += p.daux_dir_r[pt * p.lddir + 6 + q];
+      }
+    }
+    for (int k = 0; k < 3; ++k) {
+      float dk = p.d[ray * 3 + k];
+      float acc = sd[k] + p.d_rays_d_alpha[ray * 3 + k] + spe[k];
+      float f = 1.0f;
+      for (int m = 0; m < p.multires_view; ++m) {
+        acc += f * (cosf(dk * f) * spe[3 + 6 * m + k] - sinf(dk * f) * spe[6 + 6 * m + k]);
+        f *= 2.0f;
+      }
+      p.d_d[ray * 3 + k] = acc;
+      p.d_o[ray * 3 + k] = so[k];
+    }
+  }
+}
+
+}  // namespace cnr

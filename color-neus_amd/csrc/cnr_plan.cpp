@@ -1,0 +1,949 @@
+// Host orchestration of the Color-NeuS render path + the C ABI (include/colorneus_render.h).
+//
+// Forward  (reference NeuS.forward, NeuS.py:294-408):
+//   weight preparation -> coarse z -> [SDF value chain -> up_sample -> merge] x K -> fine set-up ->
+//   SDF chain (stores pre-activations) -> analytic gradient chain (reverse sweep, replaces the reference's second
+//   SDF forward + autograd.grad, fields.py:105-115) -> colour chain -> relight chain -> alpha + compositing.
+// Backward (autograd of the above incl. double backward through grad_x SDF):
+//   compositor backward -> relight / colour chains backward -> second-order forward sweep through the SDF net ->
+//   SDF value backward -> weight-gradient GEMMs (two operand pairs for the SDF net) -> weight-norm backward.
+//
+// This file contains no arithmetic on tensor data: it only sizes buffers, builds kernel descriptors and enqueues
+// kernels through cnr_backend.h.  It is shared verbatim by the HIP build and the CPU-emulation build (tests only).
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/colorneus_render.h"
+#include "cnr_backend.h"
+
+namespace cnr {
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return -1;
+}
+
+struct Lin {
+  int n = 0, k_ref = 0, k_int = 0;
+  int nseg = 0;
+  Segment seg[4];
+  int ldw = 0, npad = 0, ldwt = 0, kpad = 0;
+  bool wn = false;
+  int p_b = -1, p_g = -1, p_v = -1;
+  float *W = nullptr, *Wt = nullptr, *bias = nullptr;
+  std::string name;
+  void finish_dims() {
+    ldw = round_up(k_int, 16);
+    npad = round_up(n, 32);
+    ldwt = round_up(n, 16);
+    kpad = round_up(k_int, 32);
+  }
+  size_t bytes() const { return ((size_t)npad * ldw + (size_t)kpad * ldwt + npad) * sizeof(float); }
+};
+
+struct ParamInfo { std::string name; int rows, cols; };
+
+struct Model {
+  cnr_config c;
+  int S, I, M, K;
+  int emb;            // 3 + 6*multires
+  int Hs, L;          // SDF hidden width, number of hidden layers (top linear layer has index L)
+  int F;              // feature width = sdf_d_out - 1
+  int Hc, NC;         // colour hidden width, number of linear layers
+  int Hr, NR;         // relight hidden width, number of rl_mlp layers (+1 in_layer)
+  int nv;             // width of PE(view dir) in AUX (0 if unused)
+  int mv;             // multires_view used for AUX
+  int naux;           // 6 + nv
+  bool has_relight;
+  std::vector<Lin> sdf, col, rel;   // rel[0] = in_layer, rel[1+i] = rl_mlp[i]
+  std::vector<ParamInfo> params;
+  int p_variance = -1;
+  bool skip(int l) const { return (c.sdf_skip_mask >> l) & 1; }
+};
+
+static void identity_seg(Lin& l) {
+  l.k_int = l.k_ref;
+  l.nseg = 1;
+  l.seg[0] = {0, 0, l.k_ref};
+}
+
+static int add_linear_params(Model& m, Lin& l, const std::string& prefix, bool wn) {
+  l.name = prefix;
+  l.wn = wn;
+  l.p_b = (int)m.params.size();
+  m.params.push_back({prefix + ".bias", l.n, 1});
+  if (wn) {
+    l.p_g = (int)m.params.size();
+    m.params.push_back({prefix + ".weight_g", l.n, 1});
+    l.p_v = (int)m.params.size();
+    m.params.push_back({prefix + ".weight_v", l.n, l.k_ref});
+  } else {
+    l.p_v = (int)m.params.size();
+    m.params.push_back({prefix + ".weight", l.n, l.k_ref});
+  }
+  return 0;
+}
+
+static int build_model(const cnr_config* cfg, Model& m) {
+  if (!cfg) return fail("null config");
+  m.c = *cfg;
+  const cnr_config& c = m.c;
+  m.S = c.n_samples; m.I = c.n_importance; m.M = m.S + m.I; m.K = c.up_sample_steps;
+  if (m.S < 2 || m.M > kMaxRaySamples) return fail("n_samples + n_importance must be in [2, %d]", kMaxRaySamples);
+  if (m.I > 0 && (m.K < 1 || m.I % m.K != 0 || m.I / m.K > 64)) return fail("n_importance must be a multiple of up_sample_steps (<= 64 new samples per step)");
+  if (c.sdf_multires < 1 || c.sdf_multires > 6) return fail("sdf multires must be in [1,6]");
+  m.emb = 3 + 6 * c.sdf_multires;
+  m.Hs = c.sdf_d_hidden; m.L = c.sdf_n_layers; m.F = c.sdf_d_out - 1;
+  if (m.Hs < 40 || m.Hs > 256 || m.Hs % 4) return fail("sdf d_hidden must be a multiple of 4 in [40,256]");
+  if (m.L < 1 || m.L > kMaxLayers) return fail("sdf n_layers out of range");
+  if (m.F < 1 || m.F > 256 || m.F != c.col_d_feature) return fail("sdf d_out - 1 must equal colour d_feature (<= 256)");
+  if (c.sdf_skip_mask & 1) return fail("skip connection at layer 0 is not supported");
+  if ((c.sdf_skip_mask >> m.L) & 1) return fail("skip connection at the top layer is not supported");
+  m.has_relight = c.type == 1;
+  m.Hc = c.col_d_hidden; m.NC = c.col_n_layers + 1;
+  if (m.Hc < 4 || m.Hc > 256 || m.Hc % 4 || c.col_n_layers < 1 || c.col_n_layers >= kMaxLayers) return fail("colour net dims out of range");
+  const bool col_view = c.col_mode != 1;
+  if (col_view && c.col_multires_view > 4) return fail("colour multires_view must be <= 4");
+  int mv_c = col_view ? c.col_multires_view : -1, mv_r = m.has_relight ? c.rel_multires_view : -1;
+  if (mv_c >= 0 && mv_r >= 0 && mv_c != mv_r) return fail("colour and relight multires_view must match when both use view directions");
+  m.mv = mv_c >= 0 ? mv_c : (mv_r >= 0 ? mv_r : 0);
+  if (m.mv > 4) return fail("multires_view must be <= 4");
+  m.nv = (mv_c >= 0 || mv_r >= 0) ? (m.mv > 0 ? 3 + 6 * m.mv : 3) : 0;
+  m.naux = 6 + m.nv;
+  if (m.naux > kAux) return fail("aux input too wide");
+
+  // ---- SDF layers (fields.py:31-75)
+  m.sdf.resize(m.L + 1);
+  int prev = m.emb;
+  for (int l = 0; l <= m.L; ++l) {
+    Lin& q = m.sdf[l];
+    q.k_ref = (l == 0) ? m.emb : m.Hs;
+    int out = (l == m.L) ? c.sdf_d_out : m.Hs;
+    if (l < m.L && m.skip(l + 1)) out = m.Hs - m.emb;
+    q.n = out;
+    if (l > 0 && !m.skip(l) && prev != q.k_ref) return fail("inconsistent SDF dims");
+    if (l > 0 && m.skip(l) && prev + m.emb != q.k_ref) return fail("inconsistent SDF skip dims");
+    identity_seg(q);
+    q.finish_dims();
+    add_linear_params(m, q, "sdf_network.lin" + std::to_string(l), c.sdf_weight_norm != 0);
+    prev = out;
+  }
+  m.p_variance = (int)m.params.size();
+  m.params.push_back({"deviation_network.variance", 1, 1});
+  // ---- colour layers (fields.py:138-153); layer 0 input is permuted to [feat | p g PE(view)]
+  m.col.resize(m.NC);
+  for (int l = 0; l < m.NC; ++l) {
+    Lin& q = m.col[l];
+    q.n = (l == m.NC - 1) ? 3 : m.Hc;
+    if (l == 0) {
+      const int F = m.F, nvc = col_view ? m.nv : 0;
+      if (c.col_mode == 1) {         // [p, g, feat]
+        q.k_ref = 6 + F; q.k_int = F + 6; q.nseg = 3;
+        q.seg[0] = {0, 6, F}; q.seg[1] = {F, 0, 3}; q.seg[2] = {F + 3, 3, 3};
+      } else if (c.col_mode == 0) {  // [p, PE(v), g, feat]
+        q.k_ref = 6 + nvc + F; q.k_int = F + 6 + nvc; q.nseg = 4;
+        q.seg[0] = {0, 6 + nvc, F}; q.seg[1] = {F, 0, 3}; q.seg[2] = {F + 3, 3 + nvc, 3}; q.seg[3] = {F + 6, 3, nvc};
+      } else {                       // [p, PE(v), feat]
+        q.k_ref = 3 + nvc + F; q.k_int = F + 6 + nvc; q.nseg = 3;
+        q.seg[0] = {0, 3 + nvc, F}; q.seg[1] = {F, 0, 3}; q.seg[2] = {F + 6, 3, nvc};
+      }
+    } else {
+      q.k_ref = m.Hc;
+      identity_seg(q);
+    }
+    q.finish_dims();
+    add_linear_params(m, q, "color_network.lin" + std::to_string(l), c.col_weight_norm != 0);
+  }
+  // ---- relight layers (fields.py:305-325)
+  if (m.has_relight) {
+    m.Hr = c.rel_d_hidden; m.NR = c.rel_n_layers;
+    if (m.Hr < 4 || m.Hr > 256 || m.Hr % 4 || m.NR < 1 || m.NR >= kMaxLayers) return fail("relight net dims out of range");
+    if (c.rel_y_in_layer < 1 || c.rel_y_in_layer > m.NR) return fail("relight y_in_layer out of range");
+    m.rel.resize(m.NR + 1);
+    {
+      Lin& q = m.rel[0];
+      q.n = m.Hr;
+      const int ig = c.rel_include_grad ? 3 : 0;
+      q.k_ref = 3 + m.nv + ig; q.k_int = 6 + m.nv; q.nseg = 0;
+      q.seg[q.nseg++] = {0, 0, 3};
+      if (ig) q.seg[q.nseg++] = {3, 3 + m.nv, 3};
+      q.seg[q.nseg++] = {6, 3, m.nv};
+      q.finish_dims();
+      q.name = "relight_network.in_layer"; q.wn = false;
+      q.p_v = (int)m.params.size(); m.params.push_back({q.name + ".weight", q.n, q.k_ref});
+      q.p_b = (int)m.params.size(); m.params.push_back({q.name + ".bias", q.n, 1});
+    }
+    for (int i = 0; i < m.NR; ++i) {
+      Lin& q = m.rel[1 + i];
+      const bool y = i == c.rel_y_in_layer - 1;
+      q.n = (i == m.NR - 1) ? 3 : m.Hr;
+      if (y) {
+        q.k_ref = 3 + m.Hr; q.k_int = m.Hr + 3; q.nseg = 2;
+        q.seg[0] = {0, 3, m.Hr}; q.seg[1] = {m.Hr, 0, 3};
+      } else {
+        q.k_ref = m.Hr; identity_seg(q);
+      }
+      q.finish_dims();
+      q.name = "relight_network.rl_mlp." + std::to_string(i); q.wn = false;
+      q.p_v = (int)m.params.size(); m.params.push_back({q.name + ".weight", q.n, q.k_ref});
+      q.p_b = (int)m.params.size(); m.params.push_back({q.name + ".bias", q.n, 1});
+    }
+  } else {
+    m.Hr = 0; m.NR = 0;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bump allocator over a caller-provided buffer (dry-run when base == nullptr)
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+  char* base; size_t off = 0;
+  explicit Arena(void* b) : base((char*)b) {}
+  float* f(size_t count) {
+    size_t bytes = round_up_sz(count * sizeof(float), 256);
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+struct Ctx {   // forward-saved state
+  // effective weights live in the Lin structs
+  float *E, *AUX, *sdf, *feat, *CE0, *CES, *gcol, *relit, *eik_partial, *eik_sums, *drgb_dummy;
+  std::vector<float*> Z, V, HC, HR;
+  // sampler scratch (forward only)
+  float *sE, *sZa, *sZb, *s_sdf0, *s_sdf, *s_newz, *s_newsdf;
+  int ldztop;
+};
+
+static void layout_weights(Model& m, Arena& a) {
+  auto place = [&](Lin& q) {
+    q.W = a.f((size_t)q.npad * q.ldw);
+    q.Wt = a.f((size_t)q.kpad * q.ldwt);
+    q.bias = a.f(q.npad);
+  };
+  for (auto& q : m.sdf) place(q);
+  for (auto& q : m.col) place(q);
+  for (auto& q : m.rel) place(q);
+}
+
+static void layout_ctx(Model& m, long R, Arena& a, Ctx& x) {
+  const long P = R * m.M;
+  layout_weights(m, a);
+  x.E = a.f((size_t)P * kEmb);
+  x.AUX = a.f((size_t)P * kAux);
+  x.sdf = a.f(P);
+  x.feat = a.f((size_t)P * m.F);
+  x.CE0 = a.f((size_t)P * kEmb);
+  x.CES = a.f((size_t)P * kEmb);
+  x.gcol = a.f((size_t)P * 4);
+  x.relit = a.f((size_t)P * 4);
+  x.eik_partial = a.f((size_t)R * 2);
+  x.eik_sums = a.f(64);
+  x.Z.resize(m.L); x.V.resize(m.L);
+  for (int l = 0; l < m.L; ++l) x.Z[l] = a.f((size_t)P * m.Hs);
+  for (int l = 0; l + 1 < m.L; ++l) x.V[l] = a.f((size_t)P * m.Hs);
+  if (m.L >= 1) x.V[m.L - 1] = nullptr;   // broadcast row W_top[0,:]/scale
+  x.HC.resize(m.NC - 1);
+  for (int l = 0; l + 1 < m.NC; ++l) x.HC[l] = a.f((size_t)P * m.Hc);
+  x.HR.resize(m.NR);
+  for (int i = 0; i < m.NR; ++i) x.HR[i] = a.f((size_t)P * m.Hr);
+  // sampler
+  const long Ps = R * m.S;
+  x.sE = a.f((size_t)Ps * kEmb);
+  x.sZa = a.f((size_t)Ps * m.Hs);
+  x.sZb = a.f((size_t)Ps * m.Hs);
+  x.s_sdf0 = a.f(Ps);
+  x.s_sdf = a.f((size_t)R * m.M);
+  x.s_newz = a.f((size_t)R * 64);
+  x.s_newsdf = a.f((size_t)R * 64);
+  x.ldztop = round_up(m.F + 1, 4);
+}
+
+struct Bwd {   // backward scratch
+  float *ZTOP, *gbar_a, *dtop, *gc_a, *gc_b, *dctop, *dinvs, *drd_alpha, *dAUXc, *dAUXr, *gbar_t, *cbar, *ebar0, *ebars, *pbar;
+  std::vector<float*> D, DC, VB, Z2;
+  float *partial, *colsum;
+  int nchunk; long chunk_pts;
+  size_t partial_floats;
+};
+
+static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
+  const long P = R * m.M;
+  b.ZTOP = a.f((size_t)P * x.ldztop);
+  b.gbar_a = a.f((size_t)P * 4);
+  b.dtop = a.f((size_t)P * 4);
+  b.gc_a = a.f((size_t)P * 4);
+  b.gc_b = a.f((size_t)P * 4);
+  b.dctop = a.f((size_t)P * 4);
+  b.dinvs = a.f(R);
+  b.drd_alpha = a.f((size_t)R * 3);
+  b.dAUXc = a.f((size_t)P * kAux);
+  b.dAUXr = a.f((size_t)P * kAux);
+  b.gbar_t = a.f((size_t)P * 4);
+  b.cbar = a.f((size_t)P * kEmb);
+  b.ebar0 = a.f((size_t)P * kEmb);
+  b.ebars = a.f((size_t)P * kEmb);
+  b.pbar = a.f((size_t)P * 4);
+  b.D.resize(m.NR);
+  for (int i = 0; i < m.NR; ++i) b.D[i] = a.f((size_t)P * m.Hr);
+  b.DC.resize(m.NC - 1);
+  for (int l = 0; l + 1 < m.NC; ++l) b.DC[l] = a.f((size_t)P * m.Hc);
+  b.VB.resize(m.L); b.Z2.resize(m.L);
+  for (int l = 0; l < m.L; ++l) { b.VB[l] = a.f((size_t)P * m.Hs); b.Z2[l] = a.f((size_t)P * m.Hs); }
+  long nch = P / 512;
+  if (nch < 1) nch = 1;
+  if (nch > 256) nch = 256;
+  b.nchunk = (int)nch;
+  b.chunk_pts = round_up((int)((P + nch - 1) / nch), 16);
+  size_t mx = 0;
+  auto upd = [&](const Lin& q) { size_t s = (size_t)q.npad * q.ldw; if (s > mx) mx = s; };
+  for (auto& q : m.sdf) upd(q);
+  for (auto& q : m.col) upd(q);
+  for (auto& q : m.rel) upd(q);
+  b.partial_floats = mx;
+  b.partial = a.f((size_t)b.nchunk * mx);
+  b.colsum = a.f((size_t)b.nchunk * 320);
+}
+
+// ------------------------------------------------------------------------------------------------
+static void prep_all(Model& m, const float* const* params, cnr_stream s) {
+  auto prep = [&](Lin& q) {
+    PrepWeight p;
+    p.g = q.p_g >= 0 ? params[q.p_g] : nullptr;
+    p.v = params[q.p_v];
+    p.b = params[q.p_b];
+    p.n = q.n; p.k_ref = q.k_ref;
+    p.nseg = q.nseg;
+    for (int i = 0; i < q.nseg; ++i) p.seg[i] = q.seg[i];
+    p.W = q.W; p.ldw = q.ldw; p.npad = q.npad;
+    p.Wt = q.Wt; p.ldwt = q.ldwt; p.kpad = q.kpad;
+    p.bias = q.bias;
+    be_prep_weight(p, s);
+  };
+  for (auto& q : m.sdf) prep(q);
+  for (auto& q : m.col) prep(q);
+  for (auto& q : m.rel) prep(q);
+}
+
+// forward-input view of SDF layer l (value path): e, softplus(z_{l-1}) or the skip concat / sqrt(2)
+static View sdf_input_view(const Model& m, int l, const float* E, const float* const* Z) {
+  View v;
+  if (l == 0) {
+    v.kind = VK_DIRECT; v.a = E; v.lda = kEmb; v.ncols = m.emb;
+  } else if (m.skip(l)) {
+    v.kind = VK_SOFTPLUS; v.a = Z[l - 1]; v.lda = m.Hs;
+    v.split = m.sdf[l - 1].n; v.c = E; v.ldc = kEmb; v.ncols = m.sdf[l - 1].n + m.emb; v.scale = kInvSqrt2;
+  } else {
+    v.kind = VK_SOFTPLUS; v.a = Z[l - 1]; v.lda = m.Hs; v.ncols = m.sdf[l - 1].n;
+  }
+  return v;
+}
+
+// SDF value chain on n points; Z[l] receive the pre-activations of the hidden layers.  If value_only the top
+// layer only evaluates row 0 (the sdf) and writes sign*sdf/scale... (sign folded by the caller through `top_scale`).
+static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, float* sdf_out, float* feat_out, float top_scale,
+                      cnr_stream s) {
+  for (int l = 0; l <= m.L; ++l) {
+    const Lin& q = m.sdf[l];
+    LayerGemm g;
+    g.A = sdf_input_view(m, l, E, Z);
+    g.W = q.W; g.ldw = q.ldw; g.K = q.k_int; g.P = n;
+    if (l < m.L) {
+      g.N = q.n;
+      g.E.kind = EK_STORE; g.E.n_out = q.n; g.E.bias = q.bias; g.E.o1 = Z[l]; g.E.ld1 = m.Hs;
+    } else {
+      g.N = feat_out ? q.n : 1;
+      g.E.kind = EK_SDF_TOP; g.E.n_out = g.N; g.E.bias = q.bias; g.E.scale = top_scale;
+      g.E.o1 = feat_out; g.E.ld1 = m.F; g.E.o2 = sdf_out;
+    }
+    be_layer_gemm(g, s);
+  }
+}
+
+static void run_sampler(const Model& m, const cnr_render_inputs* in, float* z, Ctx& x, cnr_stream s) {
+  const long R = in->n_rays;
+  const float scale = m.c.sdf_scale;
+  EmbedZ e;
+  e.o = in->rays_o; e.d = in->rays_d; e.R = R; e.m = m.S; e.z = z; e.ldz = m.M; e.make_z = 1;
+  e.near_ = in->near_; e.far_ = in->far_; e.t_rand = in->t_rand; e.scale = scale; e.multires = m.c.sdf_multires; e.E = x.sE;
+  be_embed_z(e, s);
+  if (m.I <= 0) return;
+  float* Zp[kMaxLayers];
+  for (int l = 0; l < m.L; ++l) Zp[l] = (l & 1) ? x.sZb : x.sZa;
+  sdf_chain(m, R * m.S, x.sE, Zp, x.s_sdf0, nullptr, 1.0f / scale, s);
+  const int mnew = m.I / m.K;
+  int n = m.S;
+  for (int i = 0; i < m.K; ++i) {
+    const bool last = i + 1 == m.K;
+    UpSample u;
+    u.o = in->rays_o; u.d = in->rays_d; u.R = R; u.z = z; u.ldz = m.M;
+    u.sdf = i == 0 ? x.s_sdf0 : x.s_sdf; u.lds = i == 0 ? m.S : m.M; u.n = n; u.m = mnew;
+    u.inv_s = 64.0f * (float)(1 << i); u.new_z = x.s_newz;
+    be_upsample(u, s);
+    if (!last) {
+      EmbedZ e2 = e;
+      e2.m = mnew; e2.z = x.s_newz; e2.ldz = mnew; e2.make_z = 0;
+      be_embed_z(e2, s);
+      sdf_chain(m, R * mnew, x.sE, Zp, x.s_newsdf, nullptr, 1.0f / scale, s);
+    }
+    MergeZ g;
+    g.R = R; g.z = z; g.ldz = m.M; g.sdf_in = i == 0 ? x.s_sdf0 : x.s_sdf; g.lds_in = i == 0 ? m.S : m.M;
+    g.sdf_out = x.s_sdf; g.lds_out = m.M; g.n = n; g.new_z = x.s_newz; g.new_sdf = last ? nullptr : x.s_newsdf; g.m = mnew;
+    be_merge(g, s);
+    n += mnew;
+  }
+}
+
+// analytic gradient chain: cotangent of `sdf` pushed down through the layers
+static void sdf_grad_chain(const Model& m, long P, const float* E, const float* const* Z, float* const* V, float* CE0, float* CES,
+                           cnr_stream s) {
+  const float inv_scale = 1.0f / m.c.sdf_scale;
+  for (int l = m.L - 1; l >= 0; --l) {
+    const Lin& q = m.sdf[l];
+    LayerGemm g;
+    g.A.a = Z[l]; g.A.lda = m.Hs; g.A.ncols = q.n;
+    if (l == m.L - 1) { g.A.kind = VK_SIGMUL_ROW; g.A.b = m.sdf[m.L].W; g.A.scale = inv_scale; }   // v_{L-1} = W_top[0,:]/scale
+    else { g.A.kind = VK_SIGMUL; g.A.b = V[l]; g.A.ldb = m.Hs; }
+    g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+    if (l == 0) {
+      g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = CE0; g.E.ld1 = kEmb;
+    } else if (m.skip(l)) {
+      g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n;
+      g.E.o1 = V[l - 1]; g.E.ld1 = m.Hs; g.E.o2 = CES; g.E.ld2 = kEmb;
+    } else {
+      g.E.kind = EK_STORE; g.E.n_out = q.k_int; g.E.o1 = V[l - 1]; g.E.ld1 = m.Hs;
+    }
+    be_layer_gemm(g, s);
+  }
+}
+
+static bool has_skip(const Model& m) {
+  for (int l = 1; l < m.L; ++l) if (m.skip(l)) return true;
+  return false;
+}
+
+static View color_input_view(const Model& m, int l, const Ctx& x) {
+  View v;
+  if (l == 0) {
+    v.kind = VK_DIRECT; v.a = x.feat; v.lda = m.F; v.split = m.F; v.c = x.AUX; v.ldc = kAux; v.ncols = m.col[0].k_int;
+  } else {
+    v.kind = VK_DIRECT; v.a = x.HC[l - 1]; v.lda = m.Hc; v.ncols = m.Hc;
+  }
+  return v;
+}
+
+static void color_chain(const Model& m, long P, const Ctx& x, cnr_stream s) {
+  for (int l = 0; l < m.NC; ++l) {
+    const Lin& q = m.col[l];
+    LayerGemm g;
+    g.A = color_input_view(m, l, x);
+    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
+    g.E.bias = q.bias; g.E.n_out = q.n;
+    if (l + 1 < m.NC) { g.E.kind = EK_RELU; g.E.o1 = x.HC[l]; g.E.ld1 = m.Hc; }
+    else { g.E.kind = m.c.col_squeeze_out ? EK_SIGMOID : EK_LINEAR_SIG; g.E.o1 = x.gcol; g.E.ld1 = 4; }
+    be_layer_gemm(g, s);
+  }
+}
+
+static View relight_input_view(const Model& m, int i /* rl_mlp index, -1 = in_layer */, const Ctx& x) {
+  View v;
+  if (i < 0) {
+    v.kind = VK_DIRECT; v.a = x.AUX; v.lda = kAux; v.ncols = m.rel[0].k_int;
+  } else {
+    v.kind = VK_DIRECT; v.a = x.HR[i]; v.lda = m.Hr; v.ncols = m.Hr;
+    if (i == m.c.rel_y_in_layer - 1) { v.split = m.Hr; v.c = x.gcol; v.ldc = 4; v.ncols = m.Hr + 3; }
+  }
+  return v;
+}
+
+static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out, cnr_stream s) {
+  {
+    const Lin& q = m.rel[0];
+    LayerGemm g;
+    g.A = relight_input_view(m, -1, x);
+    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
+    g.E.kind = EK_RELU; g.E.bias = q.bias; g.E.n_out = q.n; g.E.o1 = x.HR[0]; g.E.ld1 = m.Hr;
+    be_layer_gemm(g, s);
+  }
+  for (int i = 0; i < m.NR; ++i) {
+    const Lin& q = m.rel[1 + i];
+    LayerGemm g;
+    g.A = relight_input_view(m, i, x);
+    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
+    g.E.bias = q.bias; g.E.n_out = q.n;
+    if (i + 1 < m.NR) { g.E.kind = EK_RELU; g.E.o1 = x.HR[i + 1]; g.E.ld1 = m.Hr; }
+    else {
+      g.E.kind = EK_RELIGHT_TOP; g.E.o1 = delta_out; g.E.ld1 = 3; g.E.o2 = x.relit; g.E.ld2 = 4;
+      g.E.aux = x.gcol; g.E.ldaux = 4; g.E.inv_sigmoid = m.c.rel_inv_sigmoid;
+    }
+    be_layer_gemm(g, s);
+  }
+}
+
+static int check_backend(const char* what) {
+  char msg[256];
+  if (be_check_last_error(msg, sizeof msg) != 0) return fail("%s: %s", what, msg);
+  return 0;
+}
+
+static int render_forward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
+                          const cnr_render_outputs* out, void* ctx, size_t ctx_bytes, cnr_stream s) {
+  Model m;
+  if (build_model(cfg, m)) return -1;
+  if (!params || !in || !out || !ctx) return fail("null argument");
+  const long R = in->n_rays;
+  if (R <= 0) return fail("n_rays must be positive");
+  Arena a(ctx);
+  Ctx x;
+  layout_ctx(m, R, a, x);
+  if (a.off > ctx_bytes) return fail("context buffer too small: need %zu bytes, got %zu", a.off, ctx_bytes);
+  if (!out->z_vals || !out->gradients || !out->weights || !out->color_fine || !out->cdf_fine || !out->inside_sphere ||
+      !out->weight_sum || !out->weight_max || !out->depth || !out->s_val || !out->gradient_error)
+    return fail("missing output buffer");
+  if (m.has_relight && (!out->delta_relight || !out->global_color)) return fail("Color_NeuS needs delta_relight and global_color buffers");
+  const long P = R * m.M;
+  const float scale = m.c.sdf_scale;
+
+  prep_all(m, params, s);
+  if (in->z_vals_override) {
+    if (in->z_vals_override != out->z_vals) return fail("z_vals_override must alias outputs.z_vals (copy it there first)");
+  } else {
+    run_sampler(m, in, out->z_vals, x, s);
+  }
+  FineSetup fs;
+  fs.o = in->rays_o; fs.d = in->rays_d; fs.z = out->z_vals; fs.R = R; fs.M = m.M; fs.sample_dist = 2.0f / (float)m.S;
+  fs.scale = scale; fs.multires = m.c.sdf_multires; fs.multires_view = m.mv; fs.E = x.E; fs.AUX = x.AUX;
+  be_fine_setup(fs, s);
+  sdf_chain(m, P, x.E, x.Z.data(), x.sdf, x.feat, 1.0f / scale, s);
+  sdf_grad_chain(m, P, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s);
+  GradFinish gf;
+  gf.P = P; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
+  gf.grad_out = out->gradients; gf.AUX = x.AUX; gf.neg_g_as_view = 0; gf.multires_view = m.mv;
+  be_grad_finish(gf, s);
+  color_chain(m, P, x, s);
+  if (m.has_relight) relight_chain(m, P, x, out->delta_relight, s);
+
+  CompositeFwd cf;
+  cf.o = in->rays_o; cf.d = in->rays_d; cf.z = out->z_vals; cf.R = R; cf.M = m.M; cf.sample_dist = 2.0f / (float)m.S;
+  cf.sdf = x.sdf; cf.g = out->gradients;
+  cf.color = m.has_relight ? x.relit : x.gcol; cf.ldcolor = 4;
+  cf.gcolor = m.has_relight ? x.gcol : nullptr; cf.ldg = 4;
+  cf.variance = params[m.p_variance]; cf.cos_anneal = in->cos_anneal_ratio; cf.background_rgb = in->background_rgb;
+  cf.color_fine = out->color_fine; cf.s_val = out->s_val; cf.cdf_fine = out->cdf_fine; cf.weight_sum = out->weight_sum;
+  cf.weight_max = out->weight_max; cf.weights = out->weights; cf.inside_sphere = out->inside_sphere; cf.depth = out->depth;
+  cf.global_color = m.has_relight ? out->global_color : nullptr; cf.eik_partial = x.eik_partial;
+  be_composite_fwd(cf, s);
+  ReduceEik re;
+  re.partial = x.eik_partial; re.R = R; re.sums = x.eik_sums; re.gradient_error = out->gradient_error;
+  be_reduce_eik(re, s);
+  return check_backend("render_forward");
+}
+
+// ------------------------------------------------------------------------------------------------
+static void run_dw(const Model& m, const Lin& q, DwGemm& g, const Bwd& b, const float* const* params, float* const* dparams,
+                   bool with_bias, cnr_stream s) {
+  g.N = q.n; g.K = q.k_int; g.nchunk = b.nchunk; g.chunk_pts = b.chunk_pts;
+  g.partial = b.partial; g.Npad = q.npad; g.ldk = q.ldw; g.colsum = with_bias ? b.colsum : nullptr;
+  be_dw_gemm(g, s);
+  FinishWeight f;
+  f.partial = b.partial; f.nchunk = b.nchunk; f.npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? b.colsum : nullptr;
+  f.g = q.p_g >= 0 ? params[q.p_g] : nullptr; f.v = params[q.p_v];
+  f.n = q.n; f.k_ref = q.k_ref; f.nseg = q.nseg;
+  for (int i = 0; i < q.nseg; ++i) f.seg[i] = q.seg[i];
+  f.dg = q.p_g >= 0 ? dparams[q.p_g] : nullptr; f.dv = dparams[q.p_v]; f.db = dparams[q.p_b];
+  be_finish_weight(f, s);
+  (void)m;
+}
+
+static int render_backward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
+                           const cnr_render_outputs* out, const void* ctx, size_t ctx_bytes, const cnr_render_out_grads* go,
+                           const cnr_render_in_grads* gi, void* scratch, size_t scratch_bytes, cnr_stream s) {
+  Model m;
+  if (build_model(cfg, m)) return -1;
+  if (!params || !in || !out || !ctx || !go || !gi || !gi->d_params || !scratch) return fail("null argument");
+  const long R = in->n_rays;
+  const long P = R * m.M;
+  Arena a(const_cast<void*>(ctx));
+  Ctx x;
+  layout_ctx(m, R, a, x);
+  if (a.off > ctx_bytes) return fail("context buffer too small");
+  Arena sa(scratch);
+  Bwd b;
+  layout_bwd(m, R, x, sa, b);
+  if (sa.off > scratch_bytes) return fail("backward scratch too small: need %zu bytes, got %zu", sa.off, scratch_bytes);
+  const float scale = m.c.sdf_scale;
+  const bool rays_grad = gi->d_rays_o != nullptr || gi->d_rays_d != nullptr;
+  if (rays_grad && (!gi->d_rays_o || !gi->d_rays_d)) return fail("d_rays_o and d_rays_d must be given together");
+  float* const* dP = gi->d_params;
+  const bool skipnet = has_skip(m);
+
+  // ---- 1. compositor backward
+  be_memset_zero(b.ZTOP, (size_t)P * x.ldztop * sizeof(float), s);
+  CompositeBwd cb;
+  cb.o = in->rays_o; cb.d = in->rays_d; cb.z = out->z_vals; cb.R = R; cb.M = m.M; cb.sample_dist = 2.0f / (float)m.S;
+  cb.sdf = x.sdf; cb.g = out->gradients; cb.color = m.has_relight ? x.relit : x.gcol; cb.ldcolor = 4;
+  cb.gcolor = m.has_relight ? x.gcol : nullptr; cb.ldg = 4;
+  cb.variance = params[m.p_variance]; cb.cos_anneal = in->cos_anneal_ratio; cb.background_rgb = in->background_rgb;
+  cb.eik_sums = x.eik_sums; cb.sdf_scale = scale; cb.inv_sigmoid = m.c.rel_inv_sigmoid; cb.has_relight = m.has_relight ? 1 : 0;
+  cb.d_color_fine = go->color_fine; cb.d_s_val = go->s_val; cb.d_cdf = go->cdf_fine; cb.d_weight_sum = go->weight_sum;
+  cb.d_weight_max = go->weight_max; cb.d_gradients = go->gradients; cb.d_weights = go->weights;
+  cb.d_gradient_error = go->gradient_error; cb.d_depth = go->depth; cb.d_global_color = m.has_relight ? go->global_color : nullptr;
+  cb.d_delta_relight = m.has_relight ? go->delta_relight : nullptr;
+  cb.ztop = b.ZTOP; cb.ldztop = x.ldztop; cb.gbar = b.gbar_a; cb.dtop = b.dtop; cb.gc_a = b.gc_a; cb.dinvs_partial = b.dinvs;
+  cb.d_rays_d = rays_grad ? b.drd_alpha : nullptr; cb.d_z = nullptr;
+  be_composite_bwd(cb, s);
+  VarianceFinish vf;
+  vf.partial = b.dinvs; vf.R = R; vf.variance = params[m.p_variance]; vf.d_variance = dP[m.p_variance];
+  be_variance_finish(vf, s);
+
+  // ---- 2. relight chain backward
+  if (m.has_relight) {
+    const int y = m.c.rel_y_in_layer - 1;
+    for (int i = m.NR - 1; i >= 0; --i) {
+      const Lin& q = m.rel[1 + i];
+      const float* dout = (i == m.NR - 1) ? b.dtop : b.D[i + 1];
+      const int ldo = (i == m.NR - 1) ? 4 : m.Hr;
+      LayerGemm g;
+      g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo; g.A.ncols = q.n;
+      g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+      g.E.kind = EK_RELU_MASK; g.E.n_out = q.k_int; g.E.split = m.Hr; g.E.o1 = b.D[i]; g.E.ld1 = m.Hr;
+      g.E.aux = x.HR[i]; g.E.ldaux = m.Hr; g.E.o2 = (i == y) ? b.gc_b : nullptr; g.E.ld2 = 4;
+      be_layer_gemm(g, s);
+      DwGemm d;
+      d.npairs = 1; d.P = P;
+      d.X[0] = g.A;
+      d.Y[0] = relight_input_view(m, i, x);
+      run_dw(m, q, d, b, params, dP, true, s);
+    }
+    {
+      const Lin& q = m.rel[0];
+      LayerGemm g;
+      g.A.kind = VK_DIRECT; g.A.a = b.D[0]; g.A.lda = m.Hr; g.A.ncols = q.n;
+      g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+      g.E.kind = EK_STORE; g.E.n_out = q.k_int; g.E.o1 = b.dAUXr; g.E.ld1 = kAux;
+      be_layer_gemm(g, s);
+      DwGemm d;
+      d.npairs = 1; d.P = P;
+      d.X[0] = g.A;
+      d.Y[0] = relight_input_view(m, -1, x);
+      run_dw(m, q, d, b, params, dP, true, s);
+    }
+  }
+  // ---- 3. colour chain backward
+  ColTopBwd ct;
+  ct.P = P; ct.gc_a = b.gc_a; ct.gc_b = m.has_relight ? b.gc_b : nullptr; ct.gcolor = x.gcol; ct.squeeze = m.c.col_squeeze_out;
+  ct.out = b.dctop;
+  be_coltop_bwd(ct, s);
+  for (int l = m.NC - 1; l >= 0; --l) {
+    const Lin& q = m.col[l];
+    const float* dout = (l == m.NC - 1) ? b.dctop : b.DC[l];
+    const int ldo = (l == m.NC - 1) ? 4 : m.Hc;
+    LayerGemm g;
+    g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo; g.A.ncols = q.n;
+    g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+    if (l > 0) {
+      g.E.kind = EK_RELU_MASK; g.E.n_out = q.k_int; g.E.o1 = b.DC[l - 1]; g.E.ld1 = m.Hc; g.E.aux = x.HC[l - 1]; g.E.ldaux = m.Hc;
+    } else {   // cotangent of [feat | aux]: feat part lands in ZTOP[., 1:], aux part in dAUXc
+      g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.split = m.F; g.E.o1 = b.ZTOP; g.E.ld1 = x.ldztop; g.E.o1_off = 1;
+      g.E.o2 = b.dAUXc; g.E.ld2 = kAux;
+    }
+    be_layer_gemm(g, s);
+    DwGemm d;
+    d.npairs = 1; d.P = P;
+    d.X[0] = g.A;
+    d.Y[0] = color_input_view(m, l, x);
+    run_dw(m, q, d, b, params, dP, true, s);
+  }
+  // ---- 4. total d g and the tangent of the embedding
+  GbarFinish gb;
+  gb.P = P; gb.gbar_alpha = b.gbar_a; gb.daux_c = b.dAUXc; gb.daux_r = m.has_relight ? b.dAUXr : nullptr; gb.E = x.E; gb.scale = scale;
+  gb.multires = m.c.sdf_multires; gb.gbar_total = b.gbar_t; gb.cbar = b.cbar;
+  be_gbar_finish(gb, s);
+  // ---- 5. second-order forward sweep (tangent of h_l in the direction induced by gbar)
+  const float inv_scale = 1.0f / scale;
+  auto qbar_view = [&](int l) {
+    View v;
+    if (l == 0) { v.kind = VK_DIRECT; v.a = b.cbar; v.lda = kEmb; v.ncols = m.emb; }
+    else if (m.skip(l)) {
+      v.kind = VK_DIRECT; v.a = b.VB[l - 1]; v.lda = m.Hs; v.split = m.sdf[l - 1].n; v.c = b.cbar; v.ldc = kEmb;
+      v.ncols = m.sdf[l - 1].n + m.emb; v.scale = kInvSqrt2;
+    } else { v.kind = VK_DIRECT; v.a = b.VB[l - 1]; v.lda = m.Hs; v.ncols = m.sdf[l - 1].n; }
+    return v;
+  };
+  for (int l = 0; l < m.L; ++l) {
+    const Lin& q = m.sdf[l];
+    LayerGemm g;
+    g.A = qbar_view(l);
+    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
+    g.E.kind = EK_SWEEP; g.E.n_out = q.n; g.E.z = x.Z[l]; g.E.ldz = m.Hs;
+    if (l == m.L - 1) { g.E.v = m.sdf[m.L].W; g.E.ldv = 0; g.E.vscale = inv_scale; }
+    else { g.E.v = x.V[l]; g.E.ldv = m.Hs; }
+    g.E.o1 = b.Z2[l]; g.E.ld1 = m.Hs; g.E.o2 = b.VB[l]; g.E.ld2 = m.Hs;
+    be_layer_gemm(g, s);
+  }
+  // ---- 6. value-path backward through the SDF net (in place: Z2[l] becomes the total cotangent of z_l)
+  for (int l = m.L; l >= 1; --l) {
+    const Lin& q = m.sdf[l];
+    LayerGemm g;
+    if (l == m.L) { g.A.kind = VK_DIRECT; g.A.a = b.ZTOP; g.A.lda = x.ldztop; g.A.ncols = q.n; }
+    else { g.A.kind = VK_DIRECT; g.A.a = b.Z2[l]; g.A.lda = m.Hs; g.A.ncols = q.n; }
+    g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+    g.E.kind = EK_VBACK; g.E.n_out = q.k_int; g.E.z = x.Z[l - 1]; g.E.ldz = m.Hs; g.E.o1 = b.Z2[l - 1]; g.E.ld1 = m.Hs;
+    if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; }
+    be_layer_gemm(g, s);
+  }
+  if (rays_grad) {
+    const Lin& q = m.sdf[0];
+    LayerGemm g;
+    g.A.kind = VK_DIRECT; g.A.a = b.Z2[0]; g.A.lda = m.Hs; g.A.ncols = q.n;
+    g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+    g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = b.ebar0; g.E.ld1 = kEmb;
+    be_layer_gemm(g, s);
+  }
+  // ---- 7. SDF weight gradients: value pair (zbar_l, input_l) + gradient-chain pair (u_l, qbar_l)
+  for (int l = 0; l <= m.L; ++l) {
+    const Lin& q = m.sdf[l];
+    DwGemm d;
+    d.npairs = 2; d.P = P;
+    if (l == m.L) { d.X[0].kind = VK_DIRECT; d.X[0].a = b.ZTOP; d.X[0].lda = x.ldztop; d.X[0].ncols = q.n; }
+    else { d.X[0].kind = VK_DIRECT; d.X[0].a = b.Z2[l]; d.X[0].lda = m.Hs; d.X[0].ncols = q.n; }
+    d.Y[0] = sdf_input_view(m, l, x.E, x.Z.data());
+    if (l == m.L) {
+      d.X[1].kind = VK_CONST_COL0; d.X[1].ncols = q.n; d.X[1].scale = inv_scale;
+      d.Y[1].kind = VK_DIRECT; d.Y[1].a = b.VB[m.L - 1]; d.Y[1].lda = m.Hs; d.Y[1].ncols = m.sdf[m.L - 1].n;
+    } else {
+      d.X[1].a = x.Z[l]; d.X[1].lda = m.Hs; d.X[1].ncols = q.n;
+      if (l == m.L - 1) { d.X[1].kind = VK_SIGMUL_ROW; d.X[1].b = m.sdf[m.L].W; d.X[1].scale = inv_scale; }
+      else { d.X[1].kind = VK_SIGMUL; d.X[1].b = x.V[l]; d.X[1].ldb = m.Hs; }
+      d.Y[1] = qbar_view(l);
+    }
+    run_dw(m, q, d, b, params, dP, true, s);
+  }
+  // ---- 8. d rays (camera refinement configs)
+  if (rays_grad) {
+    PbarFinish pf;
+    pf.P = P; pf.daux_c = b.dAUXc; pf.daux_r = m.has_relight ? b.dAUXr : nullptr; pf.ebar0 = b.ebar0; pf.ebars = skipnet ? b.ebars : nullptr;
+    pf.E = x.E; pf.ce0 = x.CE0; pf.ces = skipnet ? x.CES : nullptr; pf.gbar_total = b.gbar_t; pf.scale = scale;
+    pf.multires = m.c.sdf_multires; pf.pbar = b.pbar;
+    be_pbar_finish(pf, s);
+    RaysGradFinish rg;
+    rg.R = R; rg.M = m.M; rg.d = in->rays_d; rg.z = out->z_vals; rg.sample_dist = 2.0f / (float)m.S; rg.pbar = b.pbar;
+    rg.daux_dir_c = (m.c.col_mode != 1 && m.nv > 0) ? b.dAUXc : nullptr;
+    rg.daux_dir_r = (m.has_relight && m.nv > 0) ? b.dAUXr : nullptr;
+    rg.lddir = kAux; rg.multires_view = m.mv; rg.d_rays_d_alpha = b.drd_alpha; rg.d_o = gi->d_rays_o; rg.d_d = gi->d_rays_d;
+    be_rays_grad_finish(rg, s);
+  }
+  return check_backend("render_backward");
+}
+
+// ------------------------------------------------------------------------------------------------
+// evaluation paths: dense SDF queries and vertex colours
+// ------------------------------------------------------------------------------------------------
+constexpr long kEvalChunk = 1 << 18;   // points per pass (activations ping-pong: 2 x chunk x H floats)
+
+struct EvalBuf { float *E, *Za, *Zb; };
+static void layout_eval(Model& m, long chunk, Arena& a, EvalBuf& e) {
+  layout_weights(m, a);
+  e.E = a.f((size_t)chunk * kEmb);
+  e.Za = a.f((size_t)chunk * m.Hs);
+  e.Zb = a.f((size_t)chunk * m.Hs);
+}
+
+static int sdf_eval_impl(const cnr_config* cfg, const float* const* params, const float* pts, const float* bmin, const float* bmax,
+                         int res, long n, float sign, float* out, void* scratch, size_t scratch_bytes, cnr_stream s) {
+  Model m;
+  if (build_model(cfg, m)) return -1;
+  if (!params || !out || !scratch) return fail("null argument");
+  const long chunk = n < kEvalChunk ? n : kEvalChunk;
+  Arena a(scratch);
+  EvalBuf e;
+  layout_eval(m, chunk, a, e);
+  if (a.off > scratch_bytes) return fail("scratch too small: need %zu bytes, got %zu", a.off, scratch_bytes);
+  prep_all(m, params, s);
+  float* Zp[kMaxLayers];
+  for (int l = 0; l < m.L; ++l) Zp[l] = (l & 1) ? e.Zb : e.Za;
+  for (long start = 0; start < n; start += chunk) {
+    const long cnt = (n - start) < chunk ? (n - start) : chunk;
+    EmbedPts ep;
+    ep.pts = pts ? pts + start * 3 : nullptr; ep.n = cnt; ep.res = res; ep.start = start;
+    for (int c = 0; c < 3; ++c) { ep.bmin[c] = bmin ? bmin[c] : 0.f; ep.bmax[c] = bmax ? bmax[c] : 0.f; }
+    ep.scale = m.c.sdf_scale; ep.multires = m.c.sdf_multires; ep.E = e.E; ep.AUX = nullptr;
+    be_embed_pts(ep, s);
+    sdf_chain(m, cnt, e.E, Zp, out + start, nullptr, sign / m.c.sdf_scale, s);
+  }
+  return check_backend("sdf_eval");
+}
+
+static size_t eval_scratch_bytes(const cnr_config* cfg, long n) {
+  Model m;
+  if (build_model(cfg, m)) return 0;
+  Arena a(nullptr);
+  EvalBuf e;
+  layout_eval(m, n < kEvalChunk ? n : kEvalChunk, a, e);
+  return a.off;
+}
+
+// vertex colour: reuse the training context layout with R = chunk rays of M = 1... simpler: dedicated small layout
+struct VcBuf { Ctx x; };
+static void layout_vc(Model& m, long n, Arena& a, Ctx& x) {
+  layout_weights(m, a);
+  x.E = a.f((size_t)n * kEmb);
+  x.AUX = a.f((size_t)n * kAux);
+  x.sdf = a.f(n);
+  x.feat = a.f((size_t)n * m.F);
+  x.CE0 = a.f((size_t)n * kEmb);
+  x.CES = a.f((size_t)n * kEmb);
+  x.gcol = a.f((size_t)n * 4);
+  x.relit = a.f((size_t)n * 4);   // reused as the [n][3] gradient buffer
+  x.Z.resize(m.L); x.V.resize(m.L);
+  for (int l = 0; l < m.L; ++l) x.Z[l] = a.f((size_t)n * m.Hs);
+  for (int l = 0; l + 1 < m.L; ++l) x.V[l] = a.f((size_t)n * m.Hs);
+  if (m.L >= 1) x.V[m.L - 1] = nullptr;
+  x.HC.resize(m.NC - 1);
+  for (int l = 0; l + 1 < m.NC; ++l) x.HC[l] = a.f((size_t)n * m.Hc);
+}
+constexpr long kVcChunk = 1 << 16;
+
+__attribute__((unused)) static void copy_rgb_stub() {}
+
+}  // namespace cnr
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace cnr;
+
+extern "C" {
+
+int cnr_abi_version(void) { return CNR_ABI_VERSION; }
+const char* cnr_backend_name(void) { return be_name(); }
+const char* cnr_last_error(void) { return g_err.c_str(); }
+
+int cnr_param_count(const cnr_config* cfg) {
+  Model m;
+  if (build_model(cfg, m)) return -1;
+  return (int)m.params.size();
+}
+
+int cnr_param_info(const cnr_config* cfg, int index, char* name, int name_len, int* rows, int* cols) {
+  Model m;
+  if (build_model(cfg, m)) return -1;
+  if (index < 0 || index >= (int)m.params.size()) return fail("parameter index out of range");
+  if (name && name_len > 0) snprintf(name, name_len, "%s", m.params[index].name.c_str());
+  if (rows) *rows = m.params[index].rows;
+  if (cols) *cols = m.params[index].cols;
+  return 0;
+}
+
+size_t cnr_ctx_bytes(const cnr_config* cfg, int64_t n_rays) {
+  Model m;
+  if (build_model(cfg, m) || n_rays <= 0) return 0;
+  Arena a(nullptr);
+  Ctx x;
+  layout_ctx(m, n_rays, a, x);
+  return a.off;
+}
+
+size_t cnr_bwd_scratch_bytes(const cnr_config* cfg, int64_t n_rays) {
+  Model m;
+  if (build_model(cfg, m) || n_rays <= 0) return 0;
+  Arena a(nullptr);
+  Ctx x;
+  layout_ctx(m, n_rays, a, x);
+  Arena sa(nullptr);
+  Bwd b;
+  layout_bwd(m, n_rays, x, sa, b);
+  return sa.off;
+}
+
+int cnr_render_forward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
+                       const cnr_render_outputs* out, void* ctx, size_t ctx_bytes, void* stream) {
+  return render_forward(cfg, params, in, out, ctx, ctx_bytes, (cnr_stream)stream);
+}
+
+int cnr_render_backward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
+                        const cnr_render_outputs* out, const void* ctx, size_t ctx_bytes, const cnr_render_out_grads* gout,
+                        const cnr_render_in_grads* gin, void* scratch, size_t scratch_bytes, void* stream) {
+  return render_backward(cfg, params, in, out, ctx, ctx_bytes, gout, gin, scratch, scratch_bytes, (cnr_stream)stream);
+}
+
+size_t cnr_sdf_eval_scratch_bytes(const cnr_config* cfg, int64_t n_points) { return eval_scratch_bytes(cfg, n_points); }
+
+int cnr_sdf_eval(const cnr_config* cfg, const float* const* params, const float* pts, int64_t n_points, float sign, float* out,
+                 void* scratch, size_t scratch_bytes, void* stream) {
+  if (!pts) return fail("null points");
+  return sdf_eval_impl(cfg, params, pts, nullptr, nullptr, 0, n_points, sign, out, scratch, scratch_bytes, (cnr_stream)stream);
+}
+
+size_t cnr_sdf_grid_scratch_bytes(const cnr_config* cfg, int32_t resolution) {
+  return eval_scratch_bytes(cfg, (long)resolution * resolution * resolution);
+}
+
+int cnr_sdf_grid(const cnr_config* cfg, const float* const* params, const float* bound_min, const float* bound_max,
+                 int32_t resolution, float* u, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!bound_min || !bound_max || resolution < 2) return fail("bad lattice");
+  const long n = (long)resolution * resolution * resolution;
+  return sdf_eval_impl(cfg, params, nullptr, bound_min, bound_max, resolution, n, -1.0f, u, scratch, scratch_bytes, (cnr_stream)stream);
+}
+
+size_t cnr_vertex_color_scratch_bytes(const cnr_config* cfg, int64_t n_points) {
+  Model m;
+  if (build_model(cfg, m) || n_points <= 0) return 0;
+  Arena a(nullptr);
+  Ctx x;
+  layout_vc(m, n_points < kVcChunk ? n_points : kVcChunk, a, x);
+  return a.off;
+}
+
+int cnr_vertex_color(const cnr_config* cfg, const float* const* params, const float* verts, int64_t n_points, float* rgb,
+                     void* scratch, size_t scratch_bytes, void* stream) {
+  Model m;
+  if (build_model(cfg, m)) return -1;
+  if (!params || !verts || !rgb || !scratch) return fail("null argument");
+  cnr_stream s = (cnr_stream)stream;
+  const long chunk = n_points < kVcChunk ? n_points : kVcChunk;
+  Arena a(scratch);
+  Ctx x;
+  layout_vc(m, chunk, a, x);
+  if (a.off > scratch_bytes) return fail("scratch too small: need %zu bytes, got %zu", a.off, scratch_bytes);
+  prep_all(m, params, s);
+  const float scale = m.c.sdf_scale;
+  for (long start = 0; start < n_points; start += chunk) {
+    const long cnt = (n_points - start) < chunk ? (n_points - start) : chunk;
+    EmbedPts ep;
+    ep.pts = verts + start * 3; ep.n = cnt; ep.res = 0; ep.start = 0;
+    for (int c = 0; c < 3; ++c) { ep.bmin[c] = 0.f; ep.bmax[c] = 0.f; }
+    ep.scale = scale; ep.multires = m.c.sdf_multires; ep.E = x.E; ep.AUX = x.AUX;
+    be_embed_pts(ep, s);
+    sdf_chain(m, cnt, x.E, x.Z.data(), x.sdf, x.feat, 1.0f / scale, s);
+    sdf_grad_chain(m, cnt, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s);
+    GradFinish gf;
+    gf.P = cnt; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
+    gf.grad_out = x.relit; gf.AUX = x.AUX; gf.neg_g_as_view = (m.c.col_mode != 1) ? 1 : 0; gf.multires_view = m.mv;
+    be_grad_finish(gf, s);
+    // colour chain with the final layer written straight into the caller's [n][3] buffer
+    for (int l = 0; l < m.NC; ++l) {
+      const Lin& q = m.col[l];
+      LayerGemm g;
+      g.A = color_input_view(m, l, x);
+      g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = cnt;
+      g.E.bias = q.bias; g.E.n_out = q.n;
+      if (l + 1 < m.NC) { g.E.kind = EK_RELU; g.E.o1 = x.HC[l]; g.E.ld1 = m.Hc; }
+      else { g.E.kind = m.c.col_squeeze_out ? EK_SIGMOID : EK_LINEAR_SIG; g.E.o1 = rgb + start * 3; g.E.ld1 = 3; }
+      be_layer_gemm(g, s);
+    }
+  }
+  return check_backend("vertex_color");
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+/* colorneus_render.h -- C ABI of the MI355X-native Color-NeuS volume renderer (libcolorneus_hip.so).
+ *
+ * The reference (Colmar-zlicheng/Color-NeuS) is pure Python and has no FFI boundary of its own; its plug-in
+ * interface for this path is the RENDERER registry class whose forward() is
+ *     NeuS.forward(rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0)
+ *                                                              (lib/models/renderers/NeuS.py:294-408)
+ * with Color_NeuS.render_core (lib/models/renderers/Color_NeuS.py:24-138) underneath, plus
+ *     NeuS.extract_geometry / extract_fields   (NeuS.py:14-40, 410-417)   -> cnr_sdf_grid / cnr_sdf_eval
+ *     NeuS.extract_color                       (NeuS.py:44-64, 419-420)   -> cnr_vertex_color
+ * The entry points below are what a ctypes / cffi binding of that class calls.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise; the caller owns all memory
+ *     (outputs, context, scratch); the library allocates nothing and keeps no state between calls
+ *   - all work is enqueued on the given hipStream_t (passed as void*); no internal synchronisation
+ *   - return value: 0 on success, negative on error; cnr_last_error() returns a message for the calling thread
+ *   - parameters are passed as an array of device pointers in the canonical order reported by cnr_param_info()
+ *     (names are the reference's state_dict names, e.g. "sdf_network.lin0.weight_v")
+ */
+#ifndef COLORNEUS_RENDER_H_
+#define COLORNEUS_RENDER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNR_ABI_VERSION 1
+
+typedef struct cnr_config {
+  int32_t type;              /* 0 = NeuS (NeuS.py:68), 1 = Color_NeuS (Color_NeuS.py:10) */
+  int32_t n_samples;         /* N_SAMPLES      (NeuS.py:80) */
+  int32_t n_importance;      /* N_IMPORTANCE   (NeuS.py:81) */
+  int32_t up_sample_steps;   /* UP_SAMPLE_STEPS(NeuS.py:83) */
+  /* SDFNetwork (fields.py:19-29) */
+  int32_t sdf_d_hidden, sdf_n_layers, sdf_d_out, sdf_multires, sdf_skip_mask /* bit l set <=> l in SKIP_IN */, sdf_weight_norm;
+  float sdf_scale;
+  /* RenderingNetwork (fields.py:126-134): mode 0 = idr, 1 = no_view_dir, 2 = no_normal */
+  int32_t col_mode, col_d_feature, col_d_hidden, col_n_layers, col_multires_view, col_weight_norm, col_squeeze_out;
+  /* RelightNetwork (fields.py:296-303), ignored when type == 0 */
+  int32_t rel_d_hidden, rel_n_layers, rel_y_in_layer, rel_multires_view, rel_include_grad, rel_inv_sigmoid;
+} cnr_config;
+
+typedef struct cnr_render_inputs {
+  const float* rays_o;          /* [R][3] */
+  const float* rays_d;          /* [R][3] */
+  const float* near_;           /* [R]    */
+  const float* far_;            /* [R]    */
+  const float* t_rand;          /* [R] uniform [0,1) jitter draw (the reference's torch.rand([R,1]), NeuS.py:325) or NULL = no perturb */
+  const float* z_vals_override; /* [R][M] or NULL: skip the sampler and render at these z (parity gate G2) */
+  const float* background_rgb;  /* [3] or NULL */
+  int64_t n_rays;
+  float cos_anneal_ratio;
+} cnr_render_inputs;
+
+/* the reference's return dict (NeuS.py:387-408) plus the final z_vals; M = n_samples + n_importance */
+typedef struct cnr_render_outputs {
+  float* color_fine;     /* [R][3]    */
+  float* s_val;          /* [R]       */
+  float* cdf_fine;       /* [R][M]    */
+  float* weight_sum;     /* [R]       */
+  float* weight_max;     /* [R]       */
+  float* gradients;      /* [R][M][3] */
+  float* weights;        /* [R][M]    */
+  float* gradient_error; /* [1]       */
+  float* inside_sphere;  /* [R][M]    */
+  float* depth;          /* [R]       */
+  float* global_color;   /* [R][3]    (Color_NeuS only, else NULL) */
+  float* delta_relight;  /* [R][M][3] (Color_NeuS only, else NULL) */
+  float* z_vals;         /* [R][M]    */
+} cnr_render_outputs;
+
+/* upstream gradients of the outputs; any member may be NULL (= zero) */
+typedef struct cnr_render_out_grads {
+  const float* color_fine; const float* s_val; const float* cdf_fine; const float* weight_sum; const float* weight_max;
+  const float* gradients; const float* weights; const float* gradient_error; const float* depth;
+  const float* global_color; const float* delta_relight;
+} cnr_render_out_grads;
+
+typedef struct cnr_render_in_grads {
+  float* const* d_params;   /* host array of device pointers, same order/shapes as the parameters; overwritten (not accumulated) */
+  float* d_rays_o;          /* [R][3] or NULL */
+  float* d_rays_d;          /* [R][3] or NULL */
+} cnr_render_in_grads;
+
+int cnr_abi_version(void);
+const char* cnr_backend_name(void);
+const char* cnr_last_error(void);
+
+/* parameter inventory in canonical order */
+int cnr_param_count(const cnr_config* cfg);
+int cnr_param_info(const cnr_config* cfg, int index, char* name, int name_len, int* rows, int* cols);
+
+/* bytes of the context buffer (saved activations, written by forward, read by backward) and of the backward scratch */
+size_t cnr_ctx_bytes(const cnr_config* cfg, int64_t n_rays);
+size_t cnr_bwd_scratch_bytes(const cnr_config* cfg, int64_t n_rays);
+
+/* renderer(rays_o, rays_d, near, far) -- NeuS.forward / Color_NeuS.render_core */
+int cnr_render_forward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
+                       const cnr_render_outputs* out, void* ctx, size_t ctx_bytes, void* stream);
+
+/* autograd backward of cnr_render_forward (loss.backward(), train.py:70): parameter gradients incl. the
+ * second-order terms through grad_x SDF, and optionally d rays_o / d rays_d */
+int cnr_render_backward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
+                        const cnr_render_outputs* out, const void* ctx, size_t ctx_bytes,
+                        const cnr_render_out_grads* gout, const cnr_render_in_grads* gin,
+                        void* scratch, size_t scratch_bytes, void* stream);
+
+/* sdf_network.sdf(pts): out[i] = sign * sdf(pts[i]); extract_fields uses sign = -1 (NeuS.py:416) */
+size_t cnr_sdf_eval_scratch_bytes(const cnr_config* cfg, int64_t n_points);
+int cnr_sdf_eval(const cnr_config* cfg, const float* const* params, const float* pts, int64_t n_points, float sign,
+                 float* out, void* scratch, size_t scratch_bytes, void* stream);
+
+/* extract_fields: u[x][y][z] = -sdf on linspace(bmin,bmax,res)^3 (NeuS.py:14-28); bmin/bmax are HOST floats */
+size_t cnr_sdf_grid_scratch_bytes(const cnr_config* cfg, int32_t resolution);
+int cnr_sdf_grid(const cnr_config* cfg, const float* const* params, const float* bound_min, const float* bound_max,
+                 int32_t resolution, float* u, void* scratch, size_t scratch_bytes, void* stream);
+
+/* extract_color: rgb = color_network(pts, g, -g, feat) per vertex (NeuS.py:44-64) */
+size_t cnr_vertex_color_scratch_bytes(const cnr_config* cfg, int64_t n_points);
+int cnr_vertex_color(const cnr_config* cfg, const float* const* params, const float* verts, int64_t n_points,
+                     float* rgb, void* scratch, size_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLORNEUS_RENDER_H_ */
