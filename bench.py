@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the Color-NeuS render hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = forward + loss + backward (+ RCCL gradient all-reduce for N>1, + per-parameter clip + Adam) of the Color_NeuS DTU
+renderer block (config/Color_NeuS_dtu.yml: 8x256 SDF net, 4x256 colour net, 4x256 relight net, 64 coarse + 64 importance
+samples in 4 up-sampling steps) over one batch of synthetic rays of an 800x800 view; inputs resident in HBM.  Rays shard
+across ranks (weak scaling: --rays is per GPU).  Rank 0 prints ONE JSON line.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel (FP32-MFMA layer GEMM, 256-wide): algorithmic FLOP / per-launch HIP-event time, vs the FP32
+               matrix peak of MI355X (157.3 TFLOP/s).  Measured in a second, event-instrumented pass over the same steps.
+  cpu_baseline the CPU oracle (a port of the reference algorithm in plain PyTorch ops) timed on the host cores on a bounded
+               sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per step per GPU")
+    ap.add_argument("--no-optim", action="store_true", help="time fwd+loss+bwd only (skip clip + Adam)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=128)
+    ap.add_argument("--torch-gpu-baseline", action="store_true", help="also time the plain-PyTorch restatement on the GPU")
+    return ap.parse_args()
+
+
+def clip_per_parameter_(params, max_norm=1.0):
+    """clip_gradient (lib/utils/net_utils.py:174-184): each parameter tensor's L2 norm clipped separately."""
+    grads = [p.grad for p in params if p.grad is not None]
+    norms = torch._foreach_norm(grads)
+    coefs = [torch.clamp(max_norm / (n + 1e-6), max=1.0) for n in norms]
+    torch._foreach_mul_(grads, coefs)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the render path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import color_neus_amd as cn
+    from color_neus_amd import synthetic, parallel
+
+    cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)   # Color_NeuS_dtu.yml
+    torch.manual_seed(0)
+    renderer = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(dev)
+    params = list(renderer.parameters())
+    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.99), fused=True)
+    lib = cn.load_library()
+    assert lib.backend == "hip-gfx950"
+
+    R = args.rays
+    M = cfg.n_total
+    o_all, d_all, near_all, far_all, rgb_all, mask_all = synthetic.synthetic_view(seed=1 + rank, device=dev)
+    n_all = o_all.shape[0]
+    perm = torch.randperm(n_all, generator=torch.Generator().manual_seed(7)).to(dev)
+    Rg = R * world
+
+    def batch(i):
+        idx = perm[(i * R) % (n_all - R):(i * R) % (n_all - R) + R]
+        return o_all[idx], d_all[idx], near_all[idx], far_all[idx], rgb_all[idx], mask_all[idx]
+
+    torch.manual_seed(2)   # jitter stream (CPU generator, like the reference)
+
+    def step(i):
+        o, d, near, far, gt, mask = batch(i)
+        out = renderer(o, d, near, far)
+        if world == 1:
+            loss, _ = cn.compute_loss(out, gt, mask)
+        else:
+            loss, _ = parallel.sharded_loss(out, gt, mask, n_rays_global=Rg, n_samples=M)
+        for p in params:
+            p.grad = None
+        loss.backward()
+        if world > 1:
+            parallel.allreduce_gradients(params)
+        if not args.no_optim:
+            clip_per_parameter_(params)
+            opt.step()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = Rg * args.steps / dt
+
+    result = {
+        "metric": "rays/sec (fwd+bwd) at 128 samples/ray", "value": round(value, 1), "unit": "rays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Color_NeuS_dtu.yml renderer block (SDF 8x256 + colour 4x256 + relight 4x256), synthetic 800x800 "
+                               "view, %d rays/step/GPU x (64+64) samples, trained-like weights" % R,
+                   "rays_per_step_per_gpu": R, "samples_per_ray": M, "parallelism": "ray-sharded dp%d" % world,
+                   "step": "fwd+loss+bwd" + ("" if args.no_optim else "+clip+adam") + ("+rccl-allreduce" if world > 1 else ""),
+                   "final_loss": float(loss.detach())},
+    }
+
+    # ---- roofline of the dominant kernel: event-instrumented pass over the same steps (rank 0)
+    if not args.no_roofline and rank == 0:
+        lib.timing_enable(True)
+        nrep = min(args.steps, 3)
+        for i in range(nrep):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize(dev)
+        recs = lib.timing_collect()
+        lib.timing_enable(False)
+        agg = {}
+        for name, kind, nt, P, N, K, pairs, ms in recs:
+            key = (name, nt) if kind != 2 else (name, 0)
+            a = agg.setdefault(key, [0.0, 0.0, 0])
+            a[0] += ms
+            a[1] += 2.0 * P * N * K * max(pairs, 1) if kind != 2 else 0.0
+            a[2] += 1
+        tot_ms = sum(a[0] for a in agg.values())
+        dom = agg.get(("layer_gemm", 8))
+        if dom:
+            ach = dom[1] / (dom[0] * 1e-3) / 1e12
+            result["roofline"] = {"kernel": "layer_gemm_kernel<8> (FP32 MFMA 32x32x2, 128-point x 256-wide tile)", "bound": "mfma",
+                                  "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                  "avg_launch_ms": round(dom[0] / dom[2], 4), "launches_per_step": dom[2] // nrep,
+                                  "share_of_kernel_time": round(dom[0] / tot_ms, 3)}
+        top = sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]
+        result["kernel_breakdown"] = [{"kernel": "%s/%d" % k, "ms_per_step": round(v[0] / nrep, 3),
+                                       "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[1] else None, "launches": v[2] // nrep}
+                                      for k, v in top]
+        result["kernel_ms_per_step"] = round(tot_ms / nrep, 3)
+
+    # ---- optional: the plain-PyTorch restatement on the same GPU (the 'reference single-GPU PyTorch' stand-in)
+    if args.torch_gpu_baseline and rank == 0:
+        from oracle import colorneus_oracle as O
+        ocfg = O.dtu_config()
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in renderer.state_dict().items()}
+        Rt = min(R, 1024)
+        o, d, near, far, gt, mask = [x[:Rt] for x in batch(0)]
+
+        def tstep():
+            t_rand = torch.rand(Rt, 1).to(dev)
+            out = O.render(P, ocfg, o, d, near, far, t_rand=t_rand)
+            l, _ = O.compute_loss(out, gt, mask)
+            for p in P.values():
+                p.grad = None
+            l.backward()
+        for _ in range(2):
+            tstep()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        nt_ = 5
+        for _ in range(nt_):
+            tstep()
+        torch.cuda.synchronize(dev)
+        result["torch_gpu_baseline"] = {"value": round(Rt * nt_ / (time.perf_counter() - t1), 1), "unit": "rays/s",
+                                        "sample": "%d rays x 128 samples, plain PyTorch-ROCm ops (oracle restatement), fwd+bwd" % Rt}
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle import colorneus_oracle as O
+        ocfg = O.dtu_config()
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in renderer.state_dict().items()}
+        Rc = args.cpu_rays
+        o, d, near, far, gt, mask = [x[:Rc].cpu() for x in batch(0)]
+
+        def cstep():
+            t_rand = torch.rand(Rc, 1)
+            out = O.render(P, ocfg, o, d, near, far, t_rand=t_rand)
+            l, _ = O.compute_loss(out, gt, mask)
+            for p in P.values():
+                p.grad = None
+            l.backward()
+        cstep()
+        t1 = time.perf_counter()
+        n_it = 0
+        while n_it < 3 or (time.perf_counter() - t1 < 10.0 and n_it < 20):
+            cstep()
+            n_it += 1
+        cdt = time.perf_counter() - t1
+        result["cpu_baseline"] = {"value": round(Rc * n_it / cdt, 2), "unit": "rays/s", "cores": cores, "kind": "port",
+                                  "sample": "%d iterations of %d rays x (64+64) samples, fwd+bwd, same network/weights, "
+                                            "torch CPU ops with %d threads" % (n_it, Rc, cores)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,7 +26,7 @@ class CnrInputs(C.Structure):
 
 
 OUTPUT_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
-                 "inside_sphere", "depth", "global_color", "delta_relight", "z_vals"]
+                 "inside_sphere", "depth", "global_color", "delta_relight", "z_vals", "eik_sums"]
 OUT_GRAD_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
                    "depth", "global_color", "delta_relight"]
 
@@ -37,6 +37,11 @@ class CnrOutputs(C.Structure):
 
 class CnrOutGrads(C.Structure):
     _fields_ = [(n, _FP) for n in OUT_GRAD_FIELDS]
+
+
+class CnrKernelTiming(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("kind", C.c_int32), ("nt", C.c_int32), ("P", C.c_long), ("N", C.c_int32),
+                ("K", C.c_int32), ("pairs", C.c_int32), ("ms", C.c_float)]
 
 
 class CnrInGrads(C.Structure):
@@ -63,7 +68,8 @@ def c_config(cfg) -> CnrConfig:
 
 EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_count", "cnr_param_info", "cnr_ctx_bytes",
            "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
-           "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color"]
+           "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
+           "cnr_timing_enable", "cnr_timing_collect"]
 
 
 class RenderLibrary:
@@ -93,6 +99,9 @@ class RenderLibrary:
         L.cnr_sdf_grid.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32,
                                    _FP, _FP, C.c_size_t, _FP]
         L.cnr_vertex_color.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), _FP, C.c_int64, _FP, _FP, C.c_size_t, _FP]
+        L.cnr_timing_enable.argtypes = [C.c_int]
+        L.cnr_timing_enable.restype = None
+        L.cnr_timing_collect.argtypes = [C.POINTER(CnrKernelTiming), C.c_int]
         if L.cnr_abi_version() != 1:
             raise RuntimeError("colorneus library ABI mismatch")
 
@@ -103,6 +112,16 @@ class RenderLibrary:
     def check(self, rc, what):
         if rc != 0:
             raise RuntimeError(f"{what} failed: {self.lib.cnr_last_error().decode()}")
+
+    def timing_enable(self, on: bool):
+        self.lib.cnr_timing_enable(1 if on else 0)
+
+    def timing_collect(self, max_records=65536):
+        """Per-launch records [(name, kind, nt, P, N, K, pairs, ms)] since the last collect (synchronises the events)."""
+        buf = (CnrKernelTiming * max_records)()
+        n = self.lib.cnr_timing_collect(buf, max_records)
+        return [(buf[i].name.decode(), buf[i].kind, buf[i].nt, buf[i].P, buf[i].N, buf[i].K, buf[i].pairs, buf[i].ms)
+                for i in range(min(n, max_records))]
 
     def param_inventory(self, ccfg):
         n = self.lib.cnr_param_count(C.byref(ccfg))

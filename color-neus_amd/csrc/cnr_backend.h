@@ -84,7 +84,7 @@ struct CompositeFwd {   // Color_NeuS.py:66-123, NeuS.py:382-399
   float* eik_partial;    // [R][2]
 };
 
-struct ReduceEik { const float* partial; long R; float* sums /*[2]*/; float* gradient_error; };
+struct ReduceEik { const float* partial; long R; float* sums /*[2]*/; float* sums_out /*[2] or null*/; float* gradient_error; };
 
 struct CompositeBwd {
   const float* o; const float* d; const float* z; long R; int M; float sample_dist;
@@ -149,6 +149,9 @@ void be_pbar_finish(const PbarFinish& p, cnr_stream s);
 void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s);
 void be_memset_zero(void* p, size_t bytes, cnr_stream s);
 void be_grid_points(float* pts /*unused*/, cnr_stream s);
+struct KernelTiming { char name[32]; int kind; int nt; long P; int N, K, pairs; float ms; };
+void be_timing_enable(int on);
+int be_timing_collect(KernelTiming* out, int max_records);   // synchronises the recorded events, returns #records, resets
 const char* be_name();
 int be_check_last_error(char* msg, size_t n);   // 0 ok
 

@@ -27,7 +27,7 @@ template <int KIND, int NT>
 __device__ __forceinline__ void lg_epilogue(const Epi& e, const f32x16 (&acc)[NT], long row_base, int lane, long P);
 
 template <int NT>
-__global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
+__global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void layer_gemm_kernel(const LayerGemm g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                            // [2][128][LG_LD]
   float* Bs = smem + 2 * LG_BM * LG_LD;        // [2][NT*32][LG_LD]
@@ -142,6 +142,7 @@ static void launch_layer_gemm(const LayerGemm& g, cnr_stream s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  TimingScope ts_("layer_gemm", 0, NT, g.P, g.N, g.K, 1, s);
   hipLaunchKernelGGL(layer_gemm_kernel<NT>, dim3(grid), dim3(256), lds, s, g);
 }
 
@@ -157,8 +158,9 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
     case 7: launch_layer_gemm<7>(g, s); break;
     case 8: launch_layer_gemm<8>(g, s); break;
     case 9: launch_layer_gemm<9>(g, s); break;
+    case 10: launch_layer_gemm<10>(g, s); break;
     default:
-      if (g_first_error == hipSuccess) { g_first_error = hipErrorInvalidValue; g_first_error_where = "layer_gemm: N > 288"; }
+      if (g_first_error == hipSuccess) { g_first_error = hipErrorInvalidValue; g_first_error_where = "layer_gemm: N > 320"; }
       return;
   }
   CNR_LAUNCH_CHECK("layer_gemm");
@@ -293,6 +295,7 @@ static void launch_dw(const DwGemm& g, int n0, int k0, cnr_stream s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_kernel<WR, WC, MT, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  TimingScope ts_("dw_gemm", 1, WR * 1000 + WC * 100 + MT * 10 + KT, g.P, (g.N - n0) < WR * MT * 32 ? (g.N - n0) : WR * MT * 32, (g.K - k0) < WC * KT * 32 ? (g.K - k0) : WC * KT * 32, g.npairs, s);
   hipLaunchKernelGGL((dw_gemm_kernel<WR, WC, MT, KT>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
 }
 

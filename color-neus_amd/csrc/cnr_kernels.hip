@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <vector>
 
 #include "cnr_backend.h"
 #include "cnr_bodies.h"
@@ -25,6 +26,47 @@ hipError_t g_first_error = hipSuccess;
 const char* g_first_error_where = "";
 
 const char* be_name() { return "hip-gfx950"; }
+
+// ---- per-launch timing (HIP events recorded on the launch stream) ---------------------------------------------------
+struct TimingRec { KernelTiming t; hipEvent_t e0, e1; };
+static bool g_timing_on = false;
+static std::vector<TimingRec> g_timing;
+static std::vector<hipEvent_t> g_event_pool;
+static hipEvent_t get_event() {
+  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void timing_begin(const char* name, int kind, int nt, long P, int N, int K, int pairs, hipStream_t s) {
+  if (!g_timing_on) return;
+  TimingRec r;
+  snprintf(r.t.name, sizeof r.t.name, "%s", name);
+  r.t.kind = kind; r.t.nt = nt; r.t.P = P; r.t.N = N; r.t.K = K; r.t.pairs = pairs; r.t.ms = 0.f;
+  r.e0 = get_event(); r.e1 = get_event();
+  (void)hipEventRecord(r.e0, s);
+  g_timing.push_back(r);
+}
+void timing_end(hipStream_t s) {
+  if (!g_timing_on || g_timing.empty()) return;
+  (void)hipEventRecord(g_timing.back().e1, s);
+}
+void be_timing_enable(int on) { g_timing_on = on != 0; }
+int be_timing_collect(KernelTiming* out, int max_records) {
+  int n = 0;
+  for (auto& r : g_timing) {
+    (void)hipEventSynchronize(r.e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    r.t.ms = ms;
+    if (out && n < max_records) out[n] = r.t;
+    ++n;
+    g_event_pool.push_back(r.e0);
+    g_event_pool.push_back(r.e1);
+  }
+  g_timing.clear();
+  return n;
+}
 
 int be_check_last_error(char* msg, size_t n) {
   if (g_first_error == hipSuccess) return 0;
@@ -50,6 +92,7 @@ void be_memset_zero(void* p, size_t bytes, cnr_stream s) {
     if (n <= 0) return;                                                                      \
     long blocks = (n + 255) / 256;                                                           \
     if (blocks > 8192) blocks = 8192;                                                        \
+    TimingScope ts_(#NAME, 2, 0, n, 0, 0, 0, s);                                             \
     hipLaunchKernelGGL(NAME##_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n);        \
     CNR_LAUNCH_CHECK(#NAME);                                                                 \
   }
@@ -133,6 +176,7 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(const PrepWeight p) {
   if (tid == 0) p.bias[n] = real && p.b ? p.b[n] : 0.0f;
 }
 void be_prep_weight(const PrepWeight& p, cnr_stream s) {
+  TimingScope ts_("prep_weight", 2, 0, p.npad, 0, 0, 0, s);
   hipLaunchKernelGGL(prep_weight_kernel, dim3(p.npad), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("prep_weight");
 }
@@ -187,6 +231,7 @@ __global__ __launch_bounds__(256) void finish_weight_kernel(const FinishWeight p
   }
 }
 void be_finish_weight(const FinishWeight& p, cnr_stream s) {
+  TimingScope ts_("finish_weight", 2, 0, p.n, 0, 0, 0, s);
   hipLaunchKernelGGL(finish_weight_kernel, dim3(p.n), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("finish_weight");
 }
@@ -199,10 +244,12 @@ __global__ __launch_bounds__(256) void reduce_eik_kernel(const ReduceEik p) {
   b = block_sum_256(b, red);
   if (threadIdx.x == 0) {
     p.sums[0] = a; p.sums[1] = b;
+    if (p.sums_out) { p.sums_out[0] = a; p.sums_out[1] = b; }
     *p.gradient_error = a / (b + 1e-5f);
   }
 }
 void be_reduce_eik(const ReduceEik& p, cnr_stream s) {
+  TimingScope ts_("reduce_eik", 2, 0, p.R, 0, 0, 0, s);
   hipLaunchKernelGGL(reduce_eik_kernel, dim3(1), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("reduce_eik");
 }
@@ -218,6 +265,7 @@ __global__ __launch_bounds__(256) void variance_finish_kernel(const VarianceFini
   }
 }
 void be_variance_finish(const VarianceFinish& p, cnr_stream s) {
+  TimingScope ts_("variance_finish", 2, 0, p.R, 0, 0, 0, s);
   hipLaunchKernelGGL(variance_finish_kernel, dim3(1), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("variance_finish");
 }
@@ -314,6 +362,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const UpSample p) {
   }
 }
 void be_upsample(const UpSample& p, cnr_stream s) {
+  TimingScope ts_("upsample", 2, 0, p.R, 0, 0, 0, s);
   hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("upsample");
 }
@@ -350,6 +399,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeZ p) {
   }
 }
 void be_merge(const MergeZ& p, cnr_stream s) {
+  TimingScope ts_("merge", 2, 0, p.R, 0, 0, 0, s);
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("merge");
 }
@@ -440,6 +490,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeFwd p
   }
 }
 void be_composite_fwd(const CompositeFwd& p, cnr_stream s) {
+  TimingScope ts_("composite_fwd", 2, 0, p.R, 0, 0, 0, s);
   hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("composite_fwd");
 }
@@ -578,6 +629,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
   }
 }
 void be_composite_bwd(const CompositeBwd& p, cnr_stream s) {
+  TimingScope ts_("composite_bwd", 2, 0, p.R, 0, 0, 0, s);
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("composite_bwd");
 }
@@ -622,6 +674,7 @@ __global__ __launch_bounds__(256) void rays_grad_finish_kernel(const RaysGradFin
   }
 }
 void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s) {
+  TimingScope ts_("rays_grad_finish", 2, 0, p.R, 0, 0, 0, s);
   hipLaunchKernelGGL(rays_grad_finish_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("rays_grad_finish");
 }

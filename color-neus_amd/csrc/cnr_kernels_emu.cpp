@@ -13,6 +13,8 @@
 namespace cnr {
 
 const char* be_name() { return "cpu-emu"; }
+void be_timing_enable(int) {}
+int be_timing_collect(KernelTiming*, int) { return 0; }
 int be_check_last_error(char*, size_t) { return 0; }
 void be_memset_zero(void* p, size_t bytes, cnr_stream) { memset(p, 0, bytes); }
 void be_grid_points(float*, cnr_stream) {}
@@ -143,6 +145,7 @@ void be_reduce_eik(const ReduceEik& p, cnr_stream) {
   float a = 0.0f, b = 0.0f;
   for (long r = 0; r < p.R; ++r) { a += p.partial[r * 2]; b += p.partial[r * 2 + 1]; }
   p.sums[0] = a; p.sums[1] = b;
+  if (p.sums_out) { p.sums_out[0] = a; p.sums_out[1] = b; }
   *p.gradient_error = a / (b + 1e-5f);
 }
 

@@ -544,7 +544,7 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   cf.global_color = m.has_relight ? out->global_color : nullptr; cf.eik_partial = x.eik_partial;
   be_composite_fwd(cf, s);
   ReduceEik re;
-  re.partial = x.eik_partial; re.R = R; re.sums = x.eik_sums; re.gradient_error = out->gradient_error;
+  re.partial = x.eik_partial; re.R = R; re.sums = x.eik_sums; re.sums_out = out->eik_sums; re.gradient_error = out->gradient_error;
   be_reduce_eik(re, s);
   return check_backend("render_forward");
 }
@@ -875,6 +875,13 @@ int cnr_render_backward(const cnr_config* cfg, const float* const* params, const
                         const cnr_render_outputs* out, const void* ctx, size_t ctx_bytes, const cnr_render_out_grads* gout,
                         const cnr_render_in_grads* gin, void* scratch, size_t scratch_bytes, void* stream) {
   return render_backward(cfg, params, in, out, ctx, ctx_bytes, gout, gin, scratch, scratch_bytes, (cnr_stream)stream);
+}
+
+void cnr_timing_enable(int on) { be_timing_enable(on); }
+
+int cnr_timing_collect(cnr_kernel_timing* out, int max_records) {
+  static_assert(sizeof(cnr_kernel_timing) == sizeof(KernelTiming), "timing record layout");
+  return be_timing_collect(reinterpret_cast<KernelTiming*>(out), max_records);
 }
 
 size_t cnr_sdf_eval_scratch_bytes(const cnr_config* cfg, int64_t n_points) { return eval_scratch_bytes(cfg, n_points); }

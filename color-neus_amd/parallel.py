@@ -3,7 +3,7 @@
 The reference is single-GPU only (train.py:111).  Rays are independent, so the path shards without any data-path
 collective; exact equality with the single-GPU objective needs two exchanges per step:
 
-  1. before backward, one all-reduce(sum) of 4 floats {sum relax*(|g|-1)^2, sum relax, sum delta_relight(*mask), count}
+  1. before backward, one all-reduce(sum) of 3 floats {sum relax*(|g|-1)^2, sum relax, sum delta_relight(*mask)}
      because the eikonal term is a ratio of global sums (Color_NeuS.py:122-123) and the relight term the square of a
      global mean (NeuS_Trainer.py:153);
   2. after backward, ONE flat-bucket all-reduce(sum) of all parameter gradients (3.83 MiB for Color_NeuS) -- RCCL over
@@ -29,58 +29,45 @@ def draw_jitter(n_rays_global: int, rank: int, world: int, device):
 
 
 def sharded_loss(out, rgb_gt, mask, n_rays_global, n_samples, group=None, lambda_fine=1.0, lambda_eikonal=0.1, lambda_mask=0.1,
-                 lambda_relight=1.0, include_mask=True, eik_sums=None):
-    """Loss of this rank's shard such that the SUM over ranks equals compute_loss on the whole batch, with the
-    non-separable terms built from all-reduced statistics.  Returns (local_loss_for_backward, global_loss_value).
+                 lambda_relight=1.0, include_mask=True):
+    """Loss of this rank's ray shard, built so that the SUM over ranks of its gradients equals the gradient of
+    compute_loss (loss.py) on the whole batch.  Returns (local_loss_for_backward, global_loss_value_detached).
 
-    ``eik_sums`` = (sum relax*err, sum relax) of the local shard; recovered from gradient_error when not given."""
+    Needs out["eik_sums"] = {sum relax*(|g|-1)^2, sum relax} of the shard (extra output of the native renderer)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    R_loc = out["color_fine"].shape[0]
-    # ---- separable terms, normalised by the GLOBAL counts
-    rgb = ((out["color_fine"] - rgb_gt) ** 2).sum() / (n_rays_global * 3)
-    loss = lambda_fine * rgb
+    dev = out["color_fine"].device
+    # ---- separable terms, normalised by GLOBAL counts
+    local = lambda_fine * ((out["color_fine"] - rgb_gt) ** 2).sum() / (n_rays_global * 3)
     if lambda_mask != 0 and mask is not None:
         ws = out["weight_sum"].squeeze(-1).clip(1e-3, 1.0 - 1e-3)
-        bce = -(mask * torch.log(ws) + (1 - mask) * torch.log(1 - ws)).sum() / n_rays_global
-        loss = loss + lambda_mask * bce
-    # ---- non-separable terms
-    stats = torch.zeros(4, dtype=torch.float32, device=out["color_fine"].device)
-    gerr = out["gradient_error"]
-    if eik_sums is None:
-        relax_cnt = out.get("relax_count")
-        if relax_cnt is None:
-            raise ValueError("sharded_loss needs out['relax_count'] (sum of the relaxed inside-sphere mask of the shard)")
-        num_loc = gerr * (relax_cnt + 1e-5)
-        den_loc = relax_cnt
-    else:
-        num_loc, den_loc = eik_sums
-    stats[0], stats[1] = num_loc.detach(), den_loc.detach() if torch.is_tensor(den_loc) else den_loc
+        local = local + lambda_mask * (-(mask * torch.log(ws) + (1 - mask) * torch.log(1 - ws)).sum() / n_rays_global)
+    # ---- statistics of the non-separable terms: one 3-float all-reduce before backward
     has_rel = lambda_relight != 0 and "delta_relight" in out
+    dr_sum = None
+    stats = torch.zeros(3, dtype=torch.float32, device=dev)
+    stats[0:2] = out["eik_sums"].detach()
     if has_rel:
         dr = out["delta_relight"]
         if include_mask and mask is not None:
             dr = dr * mask[:, None, None]
         dr_sum = dr.sum()
         stats[2] = dr_sum.detach()
-    stats[3] = float(R_loc)
+    den_loc = stats[1].clone()
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-    den_g = stats[1] + 1e-5
-    # d/d(local) of [sum_all num / (sum_all den + 1e-5)]: only the local numerator carries gradient (the mask is detached)
-    eik_local = num_loc / den_g
-    loss = loss + lambda_eikonal * eik_local
-    glob = lambda_eikonal * stats[0] / den_g
+    # eikonal: global ratio sum_r num_r / (sum_r den_r + 1e-5); the local output is num_r / (den_r + 1e-5)
+    eik_local = out["gradient_error"] * ((den_loc + 1e-5) / (stats[1] + 1e-5))
+    local = local + lambda_eikonal * eik_local
+    value = local.detach().clone()
+    if world > 1:
+        dist.all_reduce(value, op=dist.ReduceOp.SUM, group=group)
     if has_rel:
         n_el = float(n_rays_global * n_samples * 3)
         mean_g = stats[2] / n_el
-        # (mean_g)^2 with gradient only through the local part of the mean: 2*mean_g * dr_sum/n_el, written as a surrogate
-        loss = loss + lambda_relight * (2.0 * mean_g * dr_sum / n_el - (2.0 * mean_g * dr_sum.detach() / n_el) + (mean_g ** 2) / world)
-        glob = glob + lambda_relight * mean_g ** 2
-    sep = loss.detach() - lambda_eikonal * eik_local.detach() - (lambda_relight * (mean_g ** 2) / world if has_rel else 0.0)
-    sep_t = sep.clone()
-    if world > 1:
-        dist.all_reduce(sep_t, op=dist.ReduceOp.SUM, group=group)
-    return loss, (sep_t + glob)
+        # d/d(shard) of mean_g^2 = 2 * mean_g * d(dr_sum_local)/n_el : linear surrogate with the right gradient
+        local = local + lambda_relight * 2.0 * mean_g * (dr_sum - dr_sum.detach()) / n_el
+        value = value + lambda_relight * mean_g ** 2
+    return local, value
 
 
 def allreduce_gradients(params, group=None):

@@ -46,7 +46,7 @@ class _RenderFunction(torch.autograd.Function):
                    gradient_error=torch.empty((), **f32), inside_sphere=torch.empty(R, M, **f32), depth=torch.empty(R, **f32),
                    global_color=torch.empty(R, 3, **f32) if color else None,
                    delta_relight=torch.empty(R, M, 3, **f32) if color else None,
-                   z_vals=torch.empty(R, M, **f32))
+                   z_vals=torch.empty(R, M, **f32), eik_sums=torch.empty(2, **f32))
         if z_override is not None:
             out["z_vals"].copy_(z_override.detach().reshape(R, M))
         plist = [p.detach().contiguous() for p in params]
@@ -63,8 +63,8 @@ class _RenderFunction(torch.autograd.Function):
         ctx.aux = (rays_o_c, rays_d_c, near_c, far_c, t_rand, background_rgb, float(cos_anneal_ratio), out, ctx_buf, plist,
                    z_override is not None)
         ctx.rays_need_grad = rays_o.requires_grad or rays_d.requires_grad
-        ctx.mark_non_differentiable(out["inside_sphere"], out["z_vals"])
-        res = [out[k] for k in _OUT_DIFF if out[k] is not None] + [out["inside_sphere"], out["z_vals"]]
+        ctx.mark_non_differentiable(out["inside_sphere"], out["z_vals"], out["eik_sums"])
+        res = [out[k] for k in _OUT_DIFF if out[k] is not None] + [out["inside_sphere"], out["z_vals"], out["eik_sums"]]
         return tuple(res)
 
     @staticmethod
@@ -266,13 +266,14 @@ class NeuSRenderer(nn.Module):
         params = self._ordered_params()
         res = _RenderFunction.apply(self, rays_o, rays_d, near, far, t_rand, z_vals, bg, cos_anneal_ratio, *params)
         names = [k for k in _OUT_DIFF if not (k in ("global_color", "delta_relight") and self.rcfg.type != "Color_NeuS")]
-        out = dict(zip(names + ["inside_sphere", "z_vals"], res))
+        out = dict(zip(names + ["inside_sphere", "z_vals", "eik_sums"], res))
         ret = {k: out[k] for k in ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",
                                    "gradient_error", "inside_sphere", "depth"]}
         if self.rcfg.type == "Color_NeuS":
             ret["global_color"] = out["global_color"]
             ret["delta_relight"] = out["delta_relight"]
-        ret["z_vals"] = out["z_vals"]   # extra key (not in the reference dict)
+        ret["z_vals"] = out["z_vals"]       # extra keys (not in the reference dict)
+        ret["eik_sums"] = out["eik_sums"]   # {sum relax*(|g|-1)^2, sum relax}: needed by ray-sharded training
         return ret
 
     # -- evaluation paths (NeuS.py:14-64, 410-420) ---------------------------------------------------------------------

@@ -70,6 +70,7 @@ typedef struct cnr_render_outputs {
   float* global_color;   /* [R][3]    (Color_NeuS only, else NULL) */
   float* delta_relight;  /* [R][M][3] (Color_NeuS only, else NULL) */
   float* z_vals;         /* [R][M]    */
+  float* eik_sums;       /* [2] or NULL: {sum relax*(|g|-1)^2, sum relax} of this call's rays -- lets a ray-sharded run rebuild the global eikonal ratio */
 } cnr_render_outputs;
 
 /* upstream gradients of the outputs; any member may be NULL (= zero) */
@@ -84,6 +85,18 @@ typedef struct cnr_render_in_grads {
   float* d_rays_o;          /* [R][3] or NULL */
   float* d_rays_d;          /* [R][3] or NULL */
 } cnr_render_in_grads;
+
+/* optional per-launch timing (HIP events on the launch stream); used by bench.py for the roofline figures */
+typedef struct cnr_kernel_timing {
+  char name[32];
+  int32_t kind;     /* 0 = layer GEMM, 1 = weight-gradient GEMM, 2 = other */
+  int32_t nt;       /* tile variant */
+  long P;           /* points (rows) or rays */
+  int32_t N, K, pairs;
+  float ms;
+} cnr_kernel_timing;
+void cnr_timing_enable(int on);
+int cnr_timing_collect(cnr_kernel_timing* out, int max_records);
 
 int cnr_abi_version(void);
 const char* cnr_backend_name(void);

@@ -1,0 +1,82 @@
+"""CPU, world_size 2, gloo: the ray-sharded data-parallel path (color-neus_amd/parallel.py) reproduces the single-process
+loss and gradients on the same batch.  The render kernels run on the CPU-emulation build (tests only)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import multiprocessing as mp
+
+import _golden as G
+import _native as N
+
+pytestmark = pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import color_neus_amd as cn
+    from color_neus_amd import parallel
+    fx = G.load("tiny_sharp")
+    ocfg, P = G.weights_of("tiny_sharp", fx)
+    r = N.make_renderer(ocfg, P, N.EMU_LIB, "cpu")
+    R = fx["rays_o"].shape[0]
+    sl = parallel.shard_slice(R, rank, world)
+    t = lambda k: torch.from_numpy(fx[k])[sl]
+    torch.manual_seed(2)
+    t_rand = parallel.draw_jitter(R, rank, world, "cpu")
+    orig = torch.rand
+    try:
+        torch.rand = lambda *a, **k: t_rand.clone()
+        out = r(t("rays_o"), t("rays_d"), t("jit:near"), t("jit:far"))
+    finally:
+        torch.rand = orig
+    loss, value = parallel.sharded_loss(out, t("rgb_gt"), t("mask"), n_rays_global=R, n_samples=ocfg.n_samples + ocfg.n_importance)
+    loss.backward()
+    params = list(r.parameters())
+    parallel.allreduce_gradients(params)
+    if rank == 0:
+        q.put((float(value), {k: p.grad.numpy().copy() for k, p in r.named_parameters()}, out["z_vals"].numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    value, grads, z0 = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, whole batch, same jitter stream
+    import color_neus_amd as cn
+    fx = G.load("tiny_sharp")
+    ocfg, P = G.weights_of("tiny_sharp", fx)
+    r = N.make_renderer(ocfg, P, N.EMU_LIB, "cpu")
+    torch.manual_seed(2)
+    out = r(torch.from_numpy(fx["rays_o"]), torch.from_numpy(fx["rays_d"]), torch.from_numpy(fx["jit:near"]),
+            torch.from_numpy(fx["jit:far"]))
+    loss, _ = cn.compute_loss(out, torch.from_numpy(fx["rgb_gt"]), torch.from_numpy(fx["mask"]))
+    loss.backward()
+    assert torch.equal(out["z_vals"][:z0.shape[0]], torch.from_numpy(z0)), "rank 0 must see the single-process jitter rows"
+    assert abs(value - float(loss)) < 1e-5 * abs(float(loss))
+    gmax = max(float(p.grad.abs().max()) for p in r.parameters())
+    for k, p in r.named_parameters():
+        err = float((torch.from_numpy(grads[k]) - p.grad).abs().max())
+        assert err <= 2e-5 * max(float(p.grad.abs().max()), 0.1 * gmax) + 1e-9, (k, err)
