@@ -73,6 +73,7 @@ struct GradFinish { // g = scale * J_PE^T (ce0 + ce_skip)
   float* grad_out;   // [P][3] (the 'gradients' output tensor)
   float* AUX;        // g copied to AUX[.,3:6]
   int neg_g_as_view; int multires_view;   // vertex colouring (NeuS.py:60): view_dirs = -g -> AUX[.,6:] = PE(-g)
+  float* featx; int ldfx; int F;          // colour-net input [feat | aux | 0]: the aux row is copied to featx[.,F:ldfx)
 };
 
 struct CompositeFwd {   // Color_NeuS.py:66-123, NeuS.py:382-399
@@ -98,15 +99,15 @@ struct CompositeBwd {
   // per-point cotangents
   float* ztop; int ldztop;     // ztop[pt][0] = d sdf / scale
   float* gbar;                 // [P][4] d loss / d g through alpha, eikonal and the 'gradients' output
-  float* dtop;                 // [P][4] cotangent of the last relight (or colour) layer output, pre-activation
-  float* gc_a;                 // [P][4] cotangent of the global colour (post-sigmoid): direct + inverse-sigmoid path
+  float* dtop;                 // [P][kTop] cotangent of the last relight layer output (pre-activation), zero padded
+  float* gc_a;                 // [P][kTop] cotangent of the global colour (post-sigmoid): direct + inverse-sigmoid path
   float* dinvs_partial;        // [R]
   float* d_rays_d;             // [R][3] (null when rays need no grad): sum_j d tc_j * g_j
   float* d_z;                  // [R][M] cotangent of z through dists/depth (null unless needed)
 };
 
 struct ColTopBwd {  // cotangent of the colour net's last pre-activation
-  long P; const float* gc_a; const float* gc_b /* may be null */; const float* gcolor; int squeeze; float* out; /*[P][4]*/
+  long P; const float* gc_a /*[P][kTop]*/; const float* gc_b /* [P][4], may be null */; const float* gcolor; int squeeze; float* out; /*[P][kTop]*/
 };
 
 struct GbarFinish { // total d g, then tangent of the embedding: cbar = J_PE (scale * gbar)

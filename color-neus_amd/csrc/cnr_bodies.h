@@ -105,15 +105,21 @@ CNR_HD void body_grad_finish(const GradFinish& p, long pt) {
     int npe = p.multires_view > 0 ? 3 + 6 * p.multires_view : 3;
     for (int c = 0; c < npe; ++c) p.AUX[pt * kAux + 6 + c] = row[c];
   }
+  if (p.featx) {
+    float* fx = p.featx + pt * p.ldfx + p.F;
+    const float* a = p.AUX + pt * kAux;
+    const int w = p.ldfx - p.F;
+    for (int c = 0; c < w; ++c) fx[c] = c < kAux ? a[c] : 0.0f;
+  }
 }
 
 CNR_HD void body_coltop_bwd(const ColTopBwd& p, long pt) {
   for (int c = 0; c < 3; ++c) {
-    float gc = p.gc_a[pt * 4 + c] + (p.gc_b ? p.gc_b[pt * 4 + c] : 0.0f);
+    float gc = p.gc_a[pt * kTop + c] + (p.gc_b ? p.gc_b[pt * 4 + c] : 0.0f);
     float y = p.gcolor[pt * 4 + c];
-    p.out[pt * 4 + c] = p.squeeze ? gc * y * (1.0f - y) : gc;
+    p.out[pt * kTop + c] = p.squeeze ? gc * y * (1.0f - y) : gc;
   }
-  p.out[pt * 4 + 3] = 0.0f;
+  for (int c = 3; c < kTop; ++c) p.out[pt * kTop + c] = 0.0f;
 }
 
 CNR_HD void body_gbar_finish(const GbarFinish& p, long pt) {

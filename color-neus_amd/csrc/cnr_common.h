@@ -24,34 +24,53 @@ typedef hipStream_t cnr_stream;
 
 namespace cnr {
 
+#if defined(CNR_CPU_EMU)
 struct alignas(16) f4 {
   float x, y, z, w;
 };
-
-CNR_HD float& f4_at(f4& v, int i) { return (&v.x)[i]; }
+#else
+// native 4-wide vector: arrays of this type stay in VGPRs (arrays of an aligned struct were placed in scratch by hipcc)
+typedef float f4 __attribute__((ext_vector_type(4)));
+#endif
 
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr int kMaxLayers = 12;   // per MLP
-constexpr int kEmb = 40;         // padded width of the SDF positional-encoding buffer (39 -> 40)
-constexpr int kAux = 40;         // padded width of the auxiliary input buffer [p(3) g(3) PE4(dir)(27) pad]
+constexpr int kEmb = 48;         // padded width of the SDF positional-encoding buffer (39 -> 48: GEMM operands are padded to 16)
+constexpr int kAux = 48;         // padded width of the auxiliary input buffer [p(3) g(3) PE4(dir)(27) pad]
+constexpr int kTop = 16;         // padded width of the 3-wide cotangent buffers that feed GEMMs
 
 CNR_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+#if defined(CNR_CPU_EMU)
+CNR_HD float fast_exp_(float x) { return expf(x); }
+CNR_HD float fast_log_(float x) { return logf(x); }
+CNR_HD float fast_rcp_(float x) { return 1.0f / x; }
+#else
+// hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp): used only inside the GEMM prologues /
+// epilogues on softplus(beta=100) terms, where the affected quantity is bounded (log term <= 0.0069, sigmoid in (0,1))
+// so the absolute error stays below 1e-9 / 1e-7 -- far inside the fp32 round-off of the surrounding dot products
+CNR_HD float fast_exp_(float x) { return __expf(x); }
+CNR_HD float fast_log_(float x) { return __logf(x); }
+CNR_HD float fast_rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
 // nn.Softplus(beta=100, threshold=20)                                      (reference fields.py:77)
+// log1p(exp(t))/100 == max(z,0) + log(1 + exp(-|t|))/100 for every t; above the threshold the reference returns z
 CNR_HD float softplus100(float z) {
   float t = 100.0f * z;
-  return t > 20.0f ? z : log1pf(expf(t)) * 0.01f;
+  if (t > 20.0f) return z;
+  return fmaxf(z, 0.0f) + fast_log_(1.0f + fast_exp_(-fabsf(t))) * 0.01f;
 }
 // d softplus / dz = sigmoid(100 z) (1 above the threshold)
 CNR_HD float softplus100_d1(float z) {
   float t = 100.0f * z;
-  return t > 20.0f ? 1.0f : sigmoidf_(t);
+  return t > 20.0f ? 1.0f : fast_rcp_(1.0f + fast_exp_(-t));
 }
 // d2 softplus / dz2 = 100 s (1-s) (0 above the threshold)
 CNR_HD float softplus100_d2(float z) {
   float t = 100.0f * z;
   if (t > 20.0f) return 0.0f;
-  float s = sigmoidf_(t);
+  float s = fast_rcp_(1.0f + fast_exp_(-t));
   return 100.0f * s * (1.0f - s);
 }
 

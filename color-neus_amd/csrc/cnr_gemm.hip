@@ -3,9 +3,12 @@
 //
 //   layer_gemm_kernel<NT>   C[P x N] = epilogue(A[P x K] * W[N x K]^T): 128-point tile x full N per workgroup (4 waves x
 //                           32 rows, v_mfma_f32_32x32x2_f32, NT*16 accumulator registers per lane), K streamed in 16-wide
-//                           slabs through double-buffered LDS (row stride 20 floats -> conflict-free ds_read_b128), operand
-//                           prologue fused into the HBM->LDS staging (cnr_views.h), epilogue fused on the accumulators.
-//   dw_gemm_kernel<...>     dW[N x K] = sum_pts X[pt][n] * Y[pt][k]: 8 waves, 256x256 output tile held in registers,
+//                           slabs through double-buffered LDS (row stride 20 floats -> conflict-free ds_read_b128).
+//                           Staging = unconditional 16-byte loads issued BEFORE the MFMAs of the current slab, prologue
+//                           math (cnr_views.h) applied AFTER them on the way to LDS.  Epilogue: accumulators are transposed
+//                           through a wave-private LDS tile so that every lane handles 4 consecutive columns of one row
+//                           (16-byte loads/stores of the side inputs/outputs, 128-byte contiguous segments per 8 lanes).
+//   dw_gemm_kernel<...>     dW[N x K] = sum_pts X[pt][n] * Y[pt][k]: 8 waves, up to 256x256 output tile held in registers,
 //                           points streamed 16 at a time, per-chunk partial results (deterministic reduction afterwards).
 #include <hip/hip_runtime.h>
 
@@ -22,9 +25,36 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LG_BM = 128;     // points per workgroup (4 waves x 32 rows)
 constexpr int LG_BK = 16;      // K slab
 constexpr int LG_LD = 20;      // LDS row stride in floats: 20 = 4*5 -> ds_read_b128 of 16 rows hits 64 distinct banks
+constexpr int LG_TLD = 33;     // row stride of the epilogue transpose tile
 
-template <int KIND, int NT>
-__device__ __forceinline__ void lg_epilogue(const Epi& e, const f32x16 (&acc)[NT], long row_base, int lane, long P);
+// compile-time recursion over the N tiles: accumulator indices stay static (a runtime-indexed ext-vector array would be
+// placed in scratch memory)
+template <int NT, int I>
+__device__ __forceinline__ void lg_epilogue_tiles(const f32x16 (&acc)[NT], const Epi& e, float* T, long wave_row0, long P, int lane,
+                                                  int ncols_live) {
+  if constexpr (I < NT) {
+    if (I * 32 < ncols_live) {
+      const int hi = lane >> 5, cl = lane & 31;
+      const int er = lane >> 3, ec4 = (lane & 7) * 4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * LG_TLD + cl] = acc[I][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = er + 8 * i;
+        const long row = wave_row0 + rr;
+        f4 v;
+        v.x = T[rr * LG_TLD + ec4 + 0]; v.y = T[rr * LG_TLD + ec4 + 1];
+        v.z = T[rr * LG_TLD + ec4 + 2]; v.w = T[rr * LG_TLD + ec4 + 3];
+        if (row < P) epi_apply4(e, row, I * 32 + ec4, v);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    lg_epilogue_tiles<NT, I + 1>(acc, e, T, wave_row0, P, lane, ncols_live);
+  }
+}
 
 template <int NT>
 __global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void layer_gemm_kernel(const LayerGemm g) {
@@ -35,6 +65,7 @@ __global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void layer_gemm_kernel(cons
   const long row0 = (long)blockIdx.x * LG_BM;
   const int nslab = (g.K + LG_BK - 1) / LG_BK;
   constexpr int NB = (NT * 32 * 4 + 255) / 256;   // float4 of W per thread per slab
+  constexpr bool NB_EXACT = (NT * 32 * 4) % 256 == 0;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -42,48 +73,55 @@ __global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void layer_gemm_kernel(cons
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
 
-  f4 ra[2];
-  f4 rb[NB];
-  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // staging registers (native vectors: stay in VGPRs)
+  f4 ra0, ra1, rb0a, rb1a;   // A: raw a / b operands of the two float4 this thread stages
+  f4 rw[NB];
+  const int ar0 = tid >> 2, ar1 = (tid + 256) >> 2, ac4 = (tid & 3) * 4;
+  long arow0 = row0 + ar0, arow1 = row0 + ar1;
+  if (arow0 >= g.P) arow0 = g.P - 1;           // clamp: rows beyond P are computed on valid data and dropped in the epilogue
+  if (arow1 >= g.P) arow1 = g.P - 1;
+  const View A = g.A;
+  const bool has_b = A.kind == VK_SIGMUL || A.kind == VK_SIGMUL_ROW;
+  const float* a0p = A.a + arow0 * A.lda + ac4;
+  const float* a1p = A.a + arow1 * A.lda + ac4;
+  const float* b0p = A.kind == VK_SIGMUL ? A.b + arow0 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a0p);
+  const float* b1p = A.kind == VK_SIGMUL ? A.b + arow1 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a1p);
+  const float* wp = g.W + (long)(tid >> 2) * g.ldw + ac4;
 
-  auto load_slab = [&](int s) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int idx = tid + i * 256;
-      int r = idx >> 2, c4 = idx & 3;
-      long row = row0 + r;
-      ra[i] = row < g.P ? view_eval4(g.A, row, s * LG_BK + c4 * 4) : zero4;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int idx = tid + i * 256;
-      int r = idx >> 2, c4 = idx & 3;
-      if (NT * 32 * 4 % 256 == 0 || idx < NT * 32 * 4)
-        rb[i] = *reinterpret_cast<const f4*>(g.W + (long)r * g.ldw + s * LG_BK + c4 * 4);
-    }
-  };
-  auto store_slab = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int idx = tid + i * 256;
-      int r = idx >> 2, c4 = idx & 3;
-      *reinterpret_cast<f4*>(As + (buf * LG_BM + r) * LG_LD + c4 * 4) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int idx = tid + i * 256;
-      int r = idx >> 2, c4 = idx & 3;
-      if (NT * 32 * 4 % 256 == 0 || idx < NT * 32 * 4)
-        *reinterpret_cast<f4*>(Bs + (buf * NT * 32 + r) * LG_LD + c4 * 4) = rb[i];
-    }
-  };
+#define LG_LOAD_SLAB(s_)                                                                     \
+  {                                                                                          \
+    const int ko_ = (s_) * LG_BK;                                                            \
+    ra0 = *reinterpret_cast<const f4*>(a0p + ko_);                                           \
+    ra1 = *reinterpret_cast<const f4*>(a1p + ko_);                                           \
+    if (has_b) {                                                                             \
+      rb0a = *reinterpret_cast<const f4*>(b0p + ko_);                                        \
+      rb1a = *reinterpret_cast<const f4*>(b1p + ko_);                                        \
+    }                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                         \
+      if (NB_EXACT || tid + i * 256 < NT * 32 * 4)                                           \
+        rw[i] = *reinterpret_cast<const f4*>(wp + (long)i * 64 * g.ldw + ko_);               \
+    }                                                                                        \
+  }
+#define LG_STORE_SLAB(buf_, s_)                                                              \
+  {                                                                                          \
+    const int kc_ = (s_) * LG_BK + ac4;                                                      \
+    Raw4 q0_, q1_;                                                                           \
+    q0_.a = ra0; q0_.b = has_b ? rb0a : ra0;                                                 \
+    q1_.a = ra1; q1_.b = has_b ? rb1a : ra1;                                                 \
+    *reinterpret_cast<f4*>(As + ((buf_) * LG_BM + ar0) * LG_LD + ac4) = view_finish4(A, q0_, kc_); \
+    *reinterpret_cast<f4*>(As + ((buf_) * LG_BM + ar1) * LG_LD + ac4) = view_finish4(A, q1_, kc_); \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                         \
+      if (NB_EXACT || tid + i * 256 < NT * 32 * 4)                                           \
+        *reinterpret_cast<f4*>(Bs + ((buf_) * NT * 32 + (tid >> 2) + i * 64) * LG_LD + ac4) = rw[i]; \
+    }                                                                                        \
+  }
 
-  load_slab(0);
-  store_slab(0);
+  LG_LOAD_SLAB(0)
+  LG_STORE_SLAB(0, 0)
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nslab) load_slab(s + 1);
+    if (s + 1 < nslab) LG_LOAD_SLAB(s + 1)
     const float* Ab = As + (buf * LG_BM + wave * 32 + (lane & 31)) * LG_LD + (lane >> 5) * 4;
     const float* Bb = Bs + (buf * NT * 32 + (lane & 31)) * LG_LD + (lane >> 5) * 4;
 #pragma unroll
@@ -98,38 +136,17 @@ __global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void layer_gemm_kernel(cons
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
       }
     }
-    if (s + 1 < nslab) store_slab(buf ^ 1);
+    if (s + 1 < nslab) LG_STORE_SLAB(buf ^ 1, s + 1)
     __syncthreads();
   }
+#undef LG_LOAD_SLAB
+#undef LG_STORE_SLAB
 
-  const long row_base = row0 + wave * 32 + 4 * (lane >> 5);
-  switch (g.E.kind) {
-    case EK_STORE: lg_epilogue<EK_STORE, NT>(g.E, acc, row_base, lane, g.P); break;
-    case EK_SPLIT: lg_epilogue<EK_SPLIT, NT>(g.E, acc, row_base, lane, g.P); break;
-    case EK_SDF_TOP: lg_epilogue<EK_SDF_TOP, NT>(g.E, acc, row_base, lane, g.P); break;
-    case EK_RELU: lg_epilogue<EK_RELU, NT>(g.E, acc, row_base, lane, g.P); break;
-    case EK_SIGMOID: lg_epilogue<EK_SIGMOID, NT>(g.E, acc, row_base, lane, g.P); break;
-    case EK_LINEAR_SIG: lg_epilogue<EK_LINEAR_SIG, NT>(g.E, acc, row_base, lane, g.P); break;
-    case EK_RELIGHT_TOP: lg_epilogue<EK_RELIGHT_TOP, NT>(g.E, acc, row_base, lane, g.P); break;
-    case EK_SWEEP: lg_epilogue<EK_SWEEP, NT>(g.E, acc, row_base, lane, g.P); break;
-    case EK_VBACK: lg_epilogue<EK_VBACK, NT>(g.E, acc, row_base, lane, g.P); break;
-    default: lg_epilogue<EK_RELU_MASK, NT>(g.E, acc, row_base, lane, g.P); break;
-  }
-}
-
-template <int KIND, int NT>
-__device__ __forceinline__ void lg_epilogue(const Epi& e0, const f32x16 (&acc)[NT], long row_base, int lane, long P) {
-  Epi e = e0;
-  e.kind = KIND;   // compile-time kind -> the switch in epi_apply folds away
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = nt * 32 + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long row = row_base + (r & 3) + 8 * (r >> 2);
-      if (row < P) epi_apply(e, row, col, acc[nt][r]);
-    }
-  }
+  // ---- epilogue: transpose each 32x32 accumulator tile through a wave-private LDS tile, then 4 columns per lane
+  float* T = smem + wave * (32 * LG_TLD);
+  const Epi e = g.E;
+  const int ncols_live = e.n_out + (e.tail_src ? e.tail_n : 0);
+  lg_epilogue_tiles<NT, 0>(acc, e, T, row0 + wave * 32, g.P, lane, ncols_live);
 }
 
 template <int NT>
@@ -147,7 +164,9 @@ static void launch_layer_gemm(const LayerGemm& g, cnr_stream s) {
 }
 
 void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
-  const int nt = (g.N + 31) / 32;
+  int ncols = g.N;
+  if (g.E.tail_src && g.E.n_out + g.E.tail_n > ncols) ncols = g.E.n_out + g.E.tail_n;   // tail-fill columns need a tile too
+  const int nt = (ncols + 31) / 32;
   switch (nt) {
     case 1: launch_layer_gemm<1>(g, s); break;
     case 2: launch_layer_gemm<2>(g, s); break;
@@ -187,6 +206,7 @@ __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, in
   const int nslab_pair = p_end > p_begin ? (int)((p_end - p_begin + DW_BP - 1) / DW_BP) : 0;
   const int nslab = nslab_pair * g.npairs;
   constexpr int NX = (DW_BP * TN / 4 + 511) / 512, NY = (DW_BP * TK / 4 + 511) / 512;
+  constexpr bool NX_EXACT = (DW_BP * TN / 4) % 512 == 0, NY_EXACT = (DW_BP * TK / 4) % 512 == 0;
 
   f32x16 acc[MT][KT];
 #pragma unroll
@@ -196,58 +216,71 @@ __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f4 rx[NX], ry[NY];
-  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f4 rxa[NX], rxb[NX], rya[NY], ryb[NY];
+  bool okx[NX], oky[NY];
+  int staged_pair = 0;
   float csum = 0.0f;
   const bool want_colsum = g.colsum != nullptr && k0 == 0;
 
-  auto load_slab = [&](int s) {
-    const int pair = s / nslab_pair;
-    const long pbase = p_begin + (long)(s - pair * nslab_pair) * DW_BP;
-    const View& X = g.X[pair];
-    const View& Y = g.Y[pair];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      int idx = tid + i * 512;
-      if (DW_BP * TN / 4 % 512 == 0 || idx < DW_BP * TN / 4) {
-        int pl = idx / (TN / 4), c4 = idx % (TN / 4);
-        long pt = pbase + pl;
-        rx[i] = pt < p_end ? view_eval4(X, pt, n0 + c4 * 4) : zero4;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NY; ++i) {
-      int idx = tid + i * 512;
-      if (DW_BP * TK / 4 % 512 == 0 || idx < DW_BP * TK / 4) {
-        int pl = idx / (TK / 4), c4 = idx % (TK / 4);
-        long pt = pbase + pl;
-        ry[i] = pt < p_end ? view_eval4(Y, pt, k0 + c4 * 4) : zero4;
-      }
-    }
-  };
-  auto store_slab = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      int idx = tid + i * 512;
-      if (DW_BP * TN / 4 % 512 == 0 || idx < DW_BP * TN / 4)
-        *reinterpret_cast<f4*>(Xs + buf * DW_BP * TN + idx * 4) = rx[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NY; ++i) {
-      int idx = tid + i * 512;
-      if (DW_BP * TK / 4 % 512 == 0 || idx < DW_BP * TK / 4)
-        *reinterpret_cast<f4*>(Ys + buf * DW_BP * TK + idx * 4) = ry[i];
-    }
-  };
+#define DW_LOAD_SLAB(s_)                                                                                  \
+  {                                                                                                       \
+    const int pair_ = (s_) / nslab_pair;                                                                  \
+    staged_pair = pair_;                                                                                  \
+    const long pbase_ = p_begin + (long)((s_) - pair_ * nslab_pair) * DW_BP;                              \
+    const View& X_ = g.X[pair_];                                                                          \
+    const View& Y_ = g.Y[pair_];                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
+      const int idx = tid + i * 512;                                                                      \
+      if (NX_EXACT || idx < DW_BP * TN / 4) {                                                             \
+        const int pl = idx / (TN / 4), c4 = idx % (TN / 4);                                               \
+        long pt = pbase_ + pl;                                                                            \
+        okx[i] = pt < p_end;                                                                              \
+        if (!okx[i]) pt = p_end - 1;                                                                      \
+        const Raw4 q_ = view_fetch4(X_, pt, n0 + c4 * 4);                                                 \
+        rxa[i] = q_.a; rxb[i] = q_.b;                                                                     \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NY; ++i) {                                                      \
+      const int idx = tid + i * 512;                                                                      \
+      if (NY_EXACT || idx < DW_BP * TK / 4) {                                                             \
+        const int pl = idx / (TK / 4), c4 = idx % (TK / 4);                                               \
+        long pt = pbase_ + pl;                                                                            \
+        oky[i] = pt < p_end;                                                                              \
+        if (!oky[i]) pt = p_end - 1;                                                                      \
+        const Raw4 q_ = view_fetch4(Y_, pt, k0 + c4 * 4);                                                 \
+        rya[i] = q_.a; ryb[i] = q_.b;                                                                     \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+#define DW_STORE_SLAB(buf_)                                                                               \
+  {                                                                                                       \
+    const f4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
+      const int idx = tid + i * 512;                                                                      \
+      if (NX_EXACT || idx < DW_BP * TN / 4) {                                                             \
+        Raw4 q_; q_.a = rxa[i]; q_.b = rxb[i];                                                            \
+        const f4 v_ = view_finish4(g.X[staged_pair], q_, n0 + (idx % (TN / 4)) * 4);                      \
+        *reinterpret_cast<f4*>(Xs + (buf_) * DW_BP * TN + idx * 4) = okx[i] ? v_ : z4_;                   \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NY; ++i) {                                                      \
+      const int idx = tid + i * 512;                                                                      \
+      if (NY_EXACT || idx < DW_BP * TK / 4) {                                                             \
+        Raw4 q_; q_.a = rya[i]; q_.b = ryb[i];                                                            \
+        const f4 v_ = view_finish4(g.Y[staged_pair], q_, k0 + (idx % (TK / 4)) * 4);                      \
+        *reinterpret_cast<f4*>(Ys + (buf_) * DW_BP * TK + idx * 4) = oky[i] ? v_ : z4_;                   \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
 
   if (nslab > 0) {
-    load_slab(0);
-    store_slab(0);
+    DW_LOAD_SLAB(0)
+    DW_STORE_SLAB(0)
   }
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nslab) load_slab(s + 1);
+    if (s + 1 < nslab) DW_LOAD_SLAB(s + 1)
     const float* Xb = Xs + buf * DW_BP * TN + (lane >> 5) * TN + wr * MT * 32 + (lane & 31);
     const float* Yb = Ys + buf * DW_BP * TK + (lane >> 5) * TK + wc * KT * 32 + (lane & 31);
 #pragma unroll
@@ -267,9 +300,11 @@ __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, in
 #pragma unroll
       for (int pl = 0; pl < DW_BP; ++pl) csum += xc[pl * TN];
     }
-    if (s + 1 < nslab) store_slab(buf ^ 1);
+    if (s + 1 < nslab) DW_STORE_SLAB(buf ^ 1)
     __syncthreads();
   }
+#undef DW_LOAD_SLAB
+#undef DW_STORE_SLAB
 
   float* out = g.partial + chunk * (long)g.Npad * g.ldk;
 #pragma unroll
@@ -295,7 +330,8 @@ static void launch_dw(const DwGemm& g, int n0, int k0, cnr_stream s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_kernel<WR, WC, MT, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  TimingScope ts_("dw_gemm", 1, WR * 1000 + WC * 100 + MT * 10 + KT, g.P, (g.N - n0) < WR * MT * 32 ? (g.N - n0) : WR * MT * 32, (g.K - k0) < WC * KT * 32 ? (g.K - k0) : WC * KT * 32, g.npairs, s);
+  TimingScope ts_("dw_gemm", 1, WR * 1000 + WC * 100 + MT * 10 + KT, g.P, (g.N - n0) < TN ? (g.N - n0) : TN,
+                  (g.K - k0) < TK ? (g.K - k0) : TK, g.npairs, s);
   hipLaunchKernelGGL((dw_gemm_kernel<WR, WC, MT, KT>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
 }
 
@@ -315,6 +351,5 @@ void be_dw_gemm(const DwGemm& g, cnr_stream s) {
   }
   CNR_LAUNCH_CHECK("dw_gemm");
 }
-
 
 }  // namespace cnr

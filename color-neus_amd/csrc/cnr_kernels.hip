@@ -608,14 +608,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
                 tbar = cbar * pass * sg * (1.0f - sg);
                 gca += cbar * pass;
               }
-              p.dtop[pt * 4 + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f);
-              p.gc_a[pt * 4 + k] = gca;
+              p.dtop[pt * kTop + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f);
+              p.gc_a[pt * kTop + k] = gca;
             } else {
-              p.gc_a[pt * 4 + k] = cbar;
+              p.gc_a[pt * kTop + k] = cbar;
             }
           }
-          if (p.has_relight) p.dtop[pt * 4 + 3] = 0.0f;
-          p.gc_a[pt * 4 + 3] = 0.0f;
+          if (p.has_relight) for (int k = 3; k < kTop; ++k) p.dtop[pt * kTop + k] = 0.0f;
+          for (int k = 3; k < kTop; ++k) p.gc_a[pt * kTop + k] = 0.0f;
         }
       }
     }

@@ -28,15 +28,17 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream) {
       f4 v = view_eval4(g.A, row, k);
       arow[k] = v.x; arow[k + 1] = v.y; arow[k + 2] = v.z; arow[k + 3] = v.w;
     }
-    for (int n = 0; n < round_up(g.N, 32); ++n) {
-      const float* w = g.W + (long)n * g.ldw;
+    int ncols = g.N;
+    if (g.E.tail_src && g.E.n_out + g.E.tail_n > ncols) ncols = g.E.n_out + g.E.tail_n;
+    for (int n = 0; n < round_up(ncols, 32); ++n) {
+      const float* w = g.W + (long)(n < round_up(g.N, 32) ? n : 0) * g.ldw;
 #ifdef CNR_EMU_DOUBLE_ACC
       double accd = 0.0;
-      for (int k = 0; k < g.K; ++k) accd += (double)arow[k] * (double)w[k];
+      if (n < round_up(g.N, 32)) for (int k = 0; k < g.K; ++k) accd += (double)arow[k] * (double)w[k];
       float acc = (float)accd;
 #else
       float acc = 0.0f;
-      for (int k = 0; k < g.K; ++k) acc = fmaf(arow[k], w[k], acc);
+      if (n < round_up(g.N, 32)) for (int k = 0; k < g.K; ++k) acc = fmaf(arow[k], w[k], acc);
 #endif
       epi_apply(g.E, row, n, acc);
     }
@@ -330,14 +332,14 @@ void be_composite_bwd(const CompositeBwd& p, cnr_stream) {
             tbar = cbar * pass * sg * (1.0f - sg);
             gca += cbar * pass;
           }
-          p.dtop[pt * 4 + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f);
-          p.gc_a[pt * 4 + k] = gca;
+          p.dtop[pt * kTop + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f);
+          p.gc_a[pt * kTop + k] = gca;
         } else {
-          p.gc_a[pt * 4 + k] = cbar;
+          p.gc_a[pt * kTop + k] = cbar;
         }
       }
-      if (p.has_relight) p.dtop[pt * 4 + 3] = 0.0f;
-      p.gc_a[pt * 4 + 3] = 0.0f;
+      if (p.has_relight) for (int k = 3; k < kTop; ++k) p.dtop[pt * kTop + k] = 0.0f;
+      for (int k = 3; k < kTop; ++k) p.gc_a[pt * kTop + k] = 0.0f;
     }
     if (p.d_s_val) dinvs += -p.d_s_val[ray] / (inv_s * inv_s);
     p.dinvs_partial[ray] = dinvs;

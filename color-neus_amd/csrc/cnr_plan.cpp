@@ -102,14 +102,14 @@ static int build_model(const cnr_config* cfg, Model& m) {
   if (c.sdf_multires < 1 || c.sdf_multires > 6) return fail("sdf multires must be in [1,6]");
   m.emb = 3 + 6 * c.sdf_multires;
   m.Hs = c.sdf_d_hidden; m.L = c.sdf_n_layers; m.F = c.sdf_d_out - 1;
-  if (m.Hs < 40 || m.Hs > 256 || m.Hs % 4) return fail("sdf d_hidden must be a multiple of 4 in [40,256]");
+  if (m.Hs < 48 || m.Hs > 256 || m.Hs % 16) return fail("sdf d_hidden must be a multiple of 16 in [48,256]");
   if (m.L < 1 || m.L > kMaxLayers) return fail("sdf n_layers out of range");
   if (m.F < 1 || m.F > 256 || m.F != c.col_d_feature) return fail("sdf d_out - 1 must equal colour d_feature (<= 256)");
   if (c.sdf_skip_mask & 1) return fail("skip connection at layer 0 is not supported");
   if ((c.sdf_skip_mask >> m.L) & 1) return fail("skip connection at the top layer is not supported");
   m.has_relight = c.type == 1;
   m.Hc = c.col_d_hidden; m.NC = c.col_n_layers + 1;
-  if (m.Hc < 4 || m.Hc > 256 || m.Hc % 4 || c.col_n_layers < 1 || c.col_n_layers >= kMaxLayers) return fail("colour net dims out of range");
+  if (m.Hc < 16 || m.Hc > 256 || m.Hc % 16 || c.col_n_layers < 1 || c.col_n_layers >= kMaxLayers) return fail("colour d_hidden must be a multiple of 16 in [16,256]");
   const bool col_view = c.col_mode != 1;
   if (col_view && c.col_multires_view > 4) return fail("colour multires_view must be <= 4");
   int mv_c = col_view ? c.col_multires_view : -1, mv_r = m.has_relight ? c.rel_multires_view : -1;
@@ -165,7 +165,7 @@ static int build_model(const cnr_config* cfg, Model& m) {
   // ---- relight layers (fields.py:305-325)
   if (m.has_relight) {
     m.Hr = c.rel_d_hidden; m.NR = c.rel_n_layers;
-    if (m.Hr < 4 || m.Hr > 256 || m.Hr % 4 || m.NR < 1 || m.NR >= kMaxLayers) return fail("relight net dims out of range");
+    if (m.Hr < 16 || m.Hr > 256 || m.Hr % 16 || m.NR < 1 || m.NR >= kMaxLayers) return fail("relight d_hidden must be a multiple of 16 in [16,256]");
     if (c.rel_y_in_layer < 1 || c.rel_y_in_layer > m.NR) return fail("relight y_in_layer out of range");
     m.rel.resize(m.NR + 1);
     {
@@ -218,12 +218,15 @@ struct Arena {
 
 struct Ctx {   // forward-saved state
   // effective weights live in the Lin structs
-  float *E, *AUX, *sdf, *feat, *CE0, *CES, *gcol, *relit, *eik_partial, *eik_sums, *drgb_dummy;
+  float *E, *AUX, *sdf, *featx, *hry, *CE0, *CES, *gcol, *relit, *eik_partial, *eik_sums;
+  int ldfx = 0, ldy = 0;   // row strides of featx = [feat | aux | 0] and hry = [relight hidden | global colour | 0]
   std::vector<float*> Z, V, HC, HR;
   // sampler scratch (forward only)
   float *sE, *sZa, *sZb, *s_sdf0, *s_sdf, *s_newz, *s_newsdf;
   int ldztop;
 };
+
+static int hr_ld(const Model& m, const Ctx& x, int i) { return i == m.c.rel_y_in_layer - 1 ? x.ldy : m.Hr; }
 
 static void layout_weights(Model& m, Arena& a) {
   auto place = [&](Lin& q) {
@@ -242,7 +245,10 @@ static void layout_ctx(Model& m, long R, Arena& a, Ctx& x) {
   x.E = a.f((size_t)P * kEmb);
   x.AUX = a.f((size_t)P * kAux);
   x.sdf = a.f(P);
-  x.feat = a.f((size_t)P * m.F);
+  x.ldfx = round_up(m.F + kAux, 16);
+  x.featx = a.f((size_t)P * x.ldfx);
+  x.ldy = m.has_relight ? m.Hr + 16 : 0;
+  x.hry = m.has_relight ? a.f((size_t)P * x.ldy) : nullptr;
   x.CE0 = a.f((size_t)P * kEmb);
   x.CES = a.f((size_t)P * kEmb);
   x.gcol = a.f((size_t)P * 4);
@@ -256,7 +262,7 @@ static void layout_ctx(Model& m, long R, Arena& a, Ctx& x) {
   x.HC.resize(m.NC - 1);
   for (int l = 0; l + 1 < m.NC; ++l) x.HC[l] = a.f((size_t)P * m.Hc);
   x.HR.resize(m.NR);
-  for (int i = 0; i < m.NR; ++i) x.HR[i] = a.f((size_t)P * m.Hr);
+  for (int i = 0; i < m.NR; ++i) x.HR[i] = (i == m.c.rel_y_in_layer - 1) ? x.hry : a.f((size_t)P * m.Hr);
   // sampler
   const long Ps = R * m.S;
   x.sE = a.f((size_t)Ps * kEmb);
@@ -266,7 +272,8 @@ static void layout_ctx(Model& m, long R, Arena& a, Ctx& x) {
   x.s_sdf = a.f((size_t)R * m.M);
   x.s_newz = a.f((size_t)R * 64);
   x.s_newsdf = a.f((size_t)R * 64);
-  x.ldztop = round_up(m.F + 1, 4);
+  x.ldztop = round_up(m.F + 1, 16);
+  a.f(1024);   // slack: GEMM tiles may read (never use) a few columns past the last row of a buffer
 }
 
 struct Bwd {   // backward scratch
@@ -281,10 +288,10 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   const long P = R * m.M;
   b.ZTOP = a.f((size_t)P * x.ldztop);
   b.gbar_a = a.f((size_t)P * 4);
-  b.dtop = a.f((size_t)P * 4);
-  b.gc_a = a.f((size_t)P * 4);
+  b.dtop = a.f((size_t)P * kTop);
+  b.gc_a = a.f((size_t)P * kTop);
   b.gc_b = a.f((size_t)P * 4);
-  b.dctop = a.f((size_t)P * 4);
+  b.dctop = a.f((size_t)P * kTop);
   b.dinvs = a.f(R);
   b.drd_alpha = a.f((size_t)R * 3);
   b.dAUXc = a.f((size_t)P * kAux);
@@ -313,6 +320,7 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   b.partial_floats = mx;
   b.partial = a.f((size_t)b.nchunk * mx);
   b.colsum = a.f((size_t)b.nchunk * 320);
+  a.f(1024);   // slack (see layout_ctx)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,20 +347,18 @@ static void prep_all(Model& m, const float* const* params, cnr_stream s) {
 static View sdf_input_view(const Model& m, int l, const float* E, const float* const* Z) {
   View v;
   if (l == 0) {
-    v.kind = VK_DIRECT; v.a = E; v.lda = kEmb; v.ncols = m.emb;
-  } else if (m.skip(l)) {
-    v.kind = VK_SOFTPLUS; v.a = Z[l - 1]; v.lda = m.Hs;
-    v.split = m.sdf[l - 1].n; v.c = E; v.ldc = kEmb; v.ncols = m.sdf[l - 1].n + m.emb; v.scale = kInvSqrt2;
+    v.kind = VK_DIRECT; v.a = E; v.lda = kEmb;
   } else {
-    v.kind = VK_SOFTPLUS; v.a = Z[l - 1]; v.lda = m.Hs; v.ncols = m.sdf[l - 1].n;
+    v.kind = VK_SOFTPLUS; v.a = Z[l - 1]; v.lda = m.Hs;
+    if (m.skip(l)) { v.math_split = m.sdf[l - 1].n; v.scale = kInvSqrt2; }   // tail columns of Z[l-1] hold e (tail fill)
   }
   return v;
 }
 
 // SDF value chain on n points; Z[l] receive the pre-activations of the hidden layers.  If value_only the top
 // layer only evaluates row 0 (the sdf) and writes sign*sdf/scale... (sign folded by the caller through `top_scale`).
-static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, float* sdf_out, float* feat_out, float top_scale,
-                      cnr_stream s) {
+static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, float* sdf_out, float* feat_out, int ld_feat,
+                      float top_scale, cnr_stream s) {
   for (int l = 0; l <= m.L; ++l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;
@@ -361,10 +367,11 @@ static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, f
     if (l < m.L) {
       g.N = q.n;
       g.E.kind = EK_STORE; g.E.n_out = q.n; g.E.bias = q.bias; g.E.o1 = Z[l]; g.E.ld1 = m.Hs;
+      if (m.skip(l + 1)) { g.E.tail_src = E; g.E.ld_tail = kEmb; g.E.tail_n = m.emb; }   // next layer reads [h | e]
     } else {
       g.N = feat_out ? q.n : 1;
       g.E.kind = EK_SDF_TOP; g.E.n_out = g.N; g.E.bias = q.bias; g.E.scale = top_scale;
-      g.E.o1 = feat_out; g.E.ld1 = m.F; g.E.o2 = sdf_out;
+      g.E.o1 = feat_out; g.E.ld1 = ld_feat; g.E.o2 = sdf_out;
     }
     be_layer_gemm(g, s);
   }
@@ -380,7 +387,7 @@ static void run_sampler(const Model& m, const cnr_render_inputs* in, float* z, C
   if (m.I <= 0) return;
   float* Zp[kMaxLayers];
   for (int l = 0; l < m.L; ++l) Zp[l] = (l & 1) ? x.sZb : x.sZa;
-  sdf_chain(m, R * m.S, x.sE, Zp, x.s_sdf0, nullptr, 1.0f / scale, s);
+  sdf_chain(m, R * m.S, x.sE, Zp, x.s_sdf0, nullptr, 0, 1.0f / scale, s);
   const int mnew = m.I / m.K;
   int n = m.S;
   for (int i = 0; i < m.K; ++i) {
@@ -394,7 +401,7 @@ static void run_sampler(const Model& m, const cnr_render_inputs* in, float* z, C
       EmbedZ e2 = e;
       e2.m = mnew; e2.z = x.s_newz; e2.ldz = mnew; e2.make_z = 0;
       be_embed_z(e2, s);
-      sdf_chain(m, R * mnew, x.sE, Zp, x.s_newsdf, nullptr, 1.0f / scale, s);
+      sdf_chain(m, R * mnew, x.sE, Zp, x.s_newsdf, nullptr, 0, 1.0f / scale, s);
     }
     MergeZ g;
     g.R = R; g.z = z; g.ldz = m.M; g.sdf_in = i == 0 ? x.s_sdf0 : x.s_sdf; g.lds_in = i == 0 ? m.S : m.M;
@@ -411,7 +418,7 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
   for (int l = m.L - 1; l >= 0; --l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;
-    g.A.a = Z[l]; g.A.lda = m.Hs; g.A.ncols = q.n;
+    g.A.a = Z[l]; g.A.lda = m.Hs;
     if (l == m.L - 1) { g.A.kind = VK_SIGMUL_ROW; g.A.b = m.sdf[m.L].W; g.A.scale = inv_scale; }   // v_{L-1} = W_top[0,:]/scale
     else { g.A.kind = VK_SIGMUL; g.A.b = V[l]; g.A.ldb = m.Hs; }
     g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
@@ -434,11 +441,9 @@ static bool has_skip(const Model& m) {
 
 static View color_input_view(const Model& m, int l, const Ctx& x) {
   View v;
-  if (l == 0) {
-    v.kind = VK_DIRECT; v.a = x.feat; v.lda = m.F; v.split = m.F; v.c = x.AUX; v.ldc = kAux; v.ncols = m.col[0].k_int;
-  } else {
-    v.kind = VK_DIRECT; v.a = x.HC[l - 1]; v.lda = m.Hc; v.ncols = m.Hc;
-  }
+  v.kind = VK_DIRECT;
+  if (l == 0) { v.a = x.featx; v.lda = x.ldfx; }     // [feat | p g PE(view) | 0]
+  else { v.a = x.HC[l - 1]; v.lda = m.Hc; }
   return v;
 }
 
@@ -450,19 +455,19 @@ static void color_chain(const Model& m, long P, const Ctx& x, cnr_stream s) {
     g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
     g.E.bias = q.bias; g.E.n_out = q.n;
     if (l + 1 < m.NC) { g.E.kind = EK_RELU; g.E.o1 = x.HC[l]; g.E.ld1 = m.Hc; }
-    else { g.E.kind = m.c.col_squeeze_out ? EK_SIGMOID : EK_LINEAR_SIG; g.E.o1 = x.gcol; g.E.ld1 = 4; }
+    else {
+      g.E.kind = m.c.col_squeeze_out ? EK_SIGMOID : EK_LINEAR_SIG; g.E.o1 = x.gcol; g.E.ld1 = 4;
+      if (m.has_relight) { g.E.o2 = x.hry; g.E.ld2 = x.ldy; g.E.o2_off = m.Hr; }   // relight y-layer input tail [.. | rgb | 0]
+    }
     be_layer_gemm(g, s);
   }
 }
 
 static View relight_input_view(const Model& m, int i /* rl_mlp index, -1 = in_layer */, const Ctx& x) {
   View v;
-  if (i < 0) {
-    v.kind = VK_DIRECT; v.a = x.AUX; v.lda = kAux; v.ncols = m.rel[0].k_int;
-  } else {
-    v.kind = VK_DIRECT; v.a = x.HR[i]; v.lda = m.Hr; v.ncols = m.Hr;
-    if (i == m.c.rel_y_in_layer - 1) { v.split = m.Hr; v.c = x.gcol; v.ldc = 4; v.ncols = m.Hr + 3; }
-  }
+  v.kind = VK_DIRECT;
+  if (i < 0) { v.a = x.AUX; v.lda = kAux; }
+  else { v.a = x.HR[i]; v.lda = hr_ld(m, x, i); }    // i == y: hry = [h | rgb | 0]
   return v;
 }
 
@@ -472,7 +477,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
     LayerGemm g;
     g.A = relight_input_view(m, -1, x);
     g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
-    g.E.kind = EK_RELU; g.E.bias = q.bias; g.E.n_out = q.n; g.E.o1 = x.HR[0]; g.E.ld1 = m.Hr;
+    g.E.kind = EK_RELU; g.E.bias = q.bias; g.E.n_out = q.n; g.E.o1 = x.HR[0]; g.E.ld1 = hr_ld(m, x, 0);
     be_layer_gemm(g, s);
   }
   for (int i = 0; i < m.NR; ++i) {
@@ -481,7 +486,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
     g.A = relight_input_view(m, i, x);
     g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
     g.E.bias = q.bias; g.E.n_out = q.n;
-    if (i + 1 < m.NR) { g.E.kind = EK_RELU; g.E.o1 = x.HR[i + 1]; g.E.ld1 = m.Hr; }
+    if (i + 1 < m.NR) { g.E.kind = EK_RELU; g.E.o1 = x.HR[i + 1]; g.E.ld1 = hr_ld(m, x, i + 1); }
     else {
       g.E.kind = EK_RELIGHT_TOP; g.E.o1 = delta_out; g.E.ld1 = 3; g.E.o2 = x.relit; g.E.ld2 = 4;
       g.E.aux = x.gcol; g.E.ldaux = 4; g.E.inv_sigmoid = m.c.rel_inv_sigmoid;
@@ -524,9 +529,12 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   fs.o = in->rays_o; fs.d = in->rays_d; fs.z = out->z_vals; fs.R = R; fs.M = m.M; fs.sample_dist = 2.0f / (float)m.S;
   fs.scale = scale; fs.multires = m.c.sdf_multires; fs.multires_view = m.mv; fs.E = x.E; fs.AUX = x.AUX;
   be_fine_setup(fs, s);
-  sdf_chain(m, P, x.E, x.Z.data(), x.sdf, x.feat, 1.0f / scale, s);
+  sdf_chain(m, P, x.E, x.Z.data(), x.sdf, x.featx, x.ldfx, 1.0f / scale, s);
+  for (int l = 1; l < m.L; ++l)   // V[l-1] feeds a GEMM over round_up(n,16) columns: its unwritten pad columns must be finite
+    if (m.skip(l) && x.V[l - 1]) be_memset_zero(x.V[l - 1], (size_t)P * m.Hs * sizeof(float), s);
   sdf_grad_chain(m, P, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s);
   GradFinish gf;
+  gf.featx = x.featx; gf.ldfx = x.ldfx; gf.F = m.F;
   gf.P = P; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
   gf.grad_out = out->gradients; gf.AUX = x.AUX; gf.neg_g_as_view = 0; gf.multires_view = m.mv;
   be_grad_finish(gf, s);
@@ -612,12 +620,12 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     for (int i = m.NR - 1; i >= 0; --i) {
       const Lin& q = m.rel[1 + i];
       const float* dout = (i == m.NR - 1) ? b.dtop : b.D[i + 1];
-      const int ldo = (i == m.NR - 1) ? 4 : m.Hr;
+      const int ldo = (i == m.NR - 1) ? kTop : m.Hr;
       LayerGemm g;
-      g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo; g.A.ncols = q.n;
+      g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo;
       g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
       g.E.kind = EK_RELU_MASK; g.E.n_out = q.k_int; g.E.split = m.Hr; g.E.o1 = b.D[i]; g.E.ld1 = m.Hr;
-      g.E.aux = x.HR[i]; g.E.ldaux = m.Hr; g.E.o2 = (i == y) ? b.gc_b : nullptr; g.E.ld2 = 4;
+      g.E.aux = x.HR[i]; g.E.ldaux = hr_ld(m, x, i); g.E.o2 = (i == y) ? b.gc_b : nullptr; g.E.ld2 = 4;
       be_layer_gemm(g, s);
       DwGemm d;
       d.npairs = 1; d.P = P;
@@ -628,7 +636,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     {
       const Lin& q = m.rel[0];
       LayerGemm g;
-      g.A.kind = VK_DIRECT; g.A.a = b.D[0]; g.A.lda = m.Hr; g.A.ncols = q.n;
+      g.A.kind = VK_DIRECT; g.A.a = b.D[0]; g.A.lda = m.Hr;
       g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
       g.E.kind = EK_STORE; g.E.n_out = q.k_int; g.E.o1 = b.dAUXr; g.E.ld1 = kAux;
       be_layer_gemm(g, s);
@@ -647,9 +655,9 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   for (int l = m.NC - 1; l >= 0; --l) {
     const Lin& q = m.col[l];
     const float* dout = (l == m.NC - 1) ? b.dctop : b.DC[l];
-    const int ldo = (l == m.NC - 1) ? 4 : m.Hc;
+    const int ldo = (l == m.NC - 1) ? kTop : m.Hc;
     LayerGemm g;
-    g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo; g.A.ncols = q.n;
+    g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo;
     g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
     if (l > 0) {
       g.E.kind = EK_RELU_MASK; g.E.n_out = q.k_int; g.E.o1 = b.DC[l - 1]; g.E.ld1 = m.Hc; g.E.aux = x.HC[l - 1]; g.E.ldaux = m.Hc;
@@ -673,11 +681,9 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   const float inv_scale = 1.0f / scale;
   auto qbar_view = [&](int l) {
     View v;
-    if (l == 0) { v.kind = VK_DIRECT; v.a = b.cbar; v.lda = kEmb; v.ncols = m.emb; }
-    else if (m.skip(l)) {
-      v.kind = VK_DIRECT; v.a = b.VB[l - 1]; v.lda = m.Hs; v.split = m.sdf[l - 1].n; v.c = b.cbar; v.ldc = kEmb;
-      v.ncols = m.sdf[l - 1].n + m.emb; v.scale = kInvSqrt2;
-    } else { v.kind = VK_DIRECT; v.a = b.VB[l - 1]; v.lda = m.Hs; v.ncols = m.sdf[l - 1].n; }
+    v.kind = VK_DIRECT;
+    if (l == 0) { v.a = b.cbar; v.lda = kEmb; }
+    else { v.a = b.VB[l - 1]; v.lda = m.Hs; if (m.skip(l)) v.scale = kInvSqrt2; }   // skip: tail columns of VB[l-1] hold cbar
     return v;
   };
   for (int l = 0; l < m.L; ++l) {
@@ -689,14 +695,15 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     if (l == m.L - 1) { g.E.v = m.sdf[m.L].W; g.E.ldv = 0; g.E.vscale = inv_scale; }
     else { g.E.v = x.V[l]; g.E.ldv = m.Hs; }
     g.E.o1 = b.Z2[l]; g.E.ld1 = m.Hs; g.E.o2 = b.VB[l]; g.E.ld2 = m.Hs;
+    if (m.skip(l + 1)) { g.E.tail_src = b.cbar; g.E.ld_tail = kEmb; g.E.tail_n = m.emb; }
     be_layer_gemm(g, s);
   }
   // ---- 6. value-path backward through the SDF net (in place: Z2[l] becomes the total cotangent of z_l)
   for (int l = m.L; l >= 1; --l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;
-    if (l == m.L) { g.A.kind = VK_DIRECT; g.A.a = b.ZTOP; g.A.lda = x.ldztop; g.A.ncols = q.n; }
-    else { g.A.kind = VK_DIRECT; g.A.a = b.Z2[l]; g.A.lda = m.Hs; g.A.ncols = q.n; }
+    if (l == m.L) { g.A.kind = VK_DIRECT; g.A.a = b.ZTOP; g.A.lda = x.ldztop; }
+    else { g.A.kind = VK_DIRECT; g.A.a = b.Z2[l]; g.A.lda = m.Hs; }
     g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
     g.E.kind = EK_VBACK; g.E.n_out = q.k_int; g.E.z = x.Z[l - 1]; g.E.ldz = m.Hs; g.E.o1 = b.Z2[l - 1]; g.E.ld1 = m.Hs;
     if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; }
@@ -705,7 +712,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   if (rays_grad) {
     const Lin& q = m.sdf[0];
     LayerGemm g;
-    g.A.kind = VK_DIRECT; g.A.a = b.Z2[0]; g.A.lda = m.Hs; g.A.ncols = q.n;
+    g.A.kind = VK_DIRECT; g.A.a = b.Z2[0]; g.A.lda = m.Hs;
     g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
     g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = b.ebar0; g.E.ld1 = kEmb;
     be_layer_gemm(g, s);
@@ -715,14 +722,14 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     const Lin& q = m.sdf[l];
     DwGemm d;
     d.npairs = 2; d.P = P;
-    if (l == m.L) { d.X[0].kind = VK_DIRECT; d.X[0].a = b.ZTOP; d.X[0].lda = x.ldztop; d.X[0].ncols = q.n; }
-    else { d.X[0].kind = VK_DIRECT; d.X[0].a = b.Z2[l]; d.X[0].lda = m.Hs; d.X[0].ncols = q.n; }
+    if (l == m.L) { d.X[0].kind = VK_DIRECT; d.X[0].a = b.ZTOP; d.X[0].lda = x.ldztop; }
+    else { d.X[0].kind = VK_DIRECT; d.X[0].a = b.Z2[l]; d.X[0].lda = m.Hs; }
     d.Y[0] = sdf_input_view(m, l, x.E, x.Z.data());
     if (l == m.L) {
-      d.X[1].kind = VK_CONST_COL0; d.X[1].ncols = q.n; d.X[1].scale = inv_scale;
-      d.Y[1].kind = VK_DIRECT; d.Y[1].a = b.VB[m.L - 1]; d.Y[1].lda = m.Hs; d.Y[1].ncols = m.sdf[m.L - 1].n;
+      d.X[1].kind = VK_CONST_COL0; d.X[1].a = b.ZTOP; d.X[1].lda = x.ldztop; d.X[1].scale = inv_scale;
+      d.Y[1].kind = VK_DIRECT; d.Y[1].a = b.VB[m.L - 1]; d.Y[1].lda = m.Hs;
     } else {
-      d.X[1].a = x.Z[l]; d.X[1].lda = m.Hs; d.X[1].ncols = q.n;
+      d.X[1].a = x.Z[l]; d.X[1].lda = m.Hs;
       if (l == m.L - 1) { d.X[1].kind = VK_SIGMUL_ROW; d.X[1].b = m.sdf[m.L].W; d.X[1].scale = inv_scale; }
       else { d.X[1].kind = VK_SIGMUL; d.X[1].b = x.V[l]; d.X[1].ldb = m.Hs; }
       d.Y[1] = qbar_view(l);
@@ -757,6 +764,7 @@ static void layout_eval(Model& m, long chunk, Arena& a, EvalBuf& e) {
   e.E = a.f((size_t)chunk * kEmb);
   e.Za = a.f((size_t)chunk * m.Hs);
   e.Zb = a.f((size_t)chunk * m.Hs);
+  a.f(1024);
 }
 
 static int sdf_eval_impl(const cnr_config* cfg, const float* const* params, const float* pts, const float* bmin, const float* bmax,
@@ -779,7 +787,7 @@ static int sdf_eval_impl(const cnr_config* cfg, const float* const* params, cons
     for (int c = 0; c < 3; ++c) { ep.bmin[c] = bmin ? bmin[c] : 0.f; ep.bmax[c] = bmax ? bmax[c] : 0.f; }
     ep.scale = m.c.sdf_scale; ep.multires = m.c.sdf_multires; ep.E = e.E; ep.AUX = nullptr;
     be_embed_pts(ep, s);
-    sdf_chain(m, cnt, e.E, Zp, out + start, nullptr, sign / m.c.sdf_scale, s);
+    sdf_chain(m, cnt, e.E, Zp, out + start, nullptr, 0, sign / m.c.sdf_scale, s);
   }
   return check_backend("sdf_eval");
 }
@@ -800,7 +808,9 @@ static void layout_vc(Model& m, long n, Arena& a, Ctx& x) {
   x.E = a.f((size_t)n * kEmb);
   x.AUX = a.f((size_t)n * kAux);
   x.sdf = a.f(n);
-  x.feat = a.f((size_t)n * m.F);
+  x.ldfx = round_up(m.F + kAux, 16);
+  x.featx = a.f((size_t)n * x.ldfx);
+  x.hry = nullptr; x.ldy = 0;
   x.CE0 = a.f((size_t)n * kEmb);
   x.CES = a.f((size_t)n * kEmb);
   x.gcol = a.f((size_t)n * 4);
@@ -811,6 +821,7 @@ static void layout_vc(Model& m, long n, Arena& a, Ctx& x) {
   if (m.L >= 1) x.V[m.L - 1] = nullptr;
   x.HC.resize(m.NC - 1);
   for (int l = 0; l + 1 < m.NC; ++l) x.HC[l] = a.f((size_t)n * m.Hc);
+  a.f(1024);
 }
 constexpr long kVcChunk = 1 << 16;
 
@@ -932,11 +943,12 @@ int cnr_vertex_color(const cnr_config* cfg, const float* const* params, const fl
     for (int c = 0; c < 3; ++c) { ep.bmin[c] = 0.f; ep.bmax[c] = 0.f; }
     ep.scale = scale; ep.multires = m.c.sdf_multires; ep.E = x.E; ep.AUX = x.AUX;
     be_embed_pts(ep, s);
-    sdf_chain(m, cnt, x.E, x.Z.data(), x.sdf, x.feat, 1.0f / scale, s);
+    sdf_chain(m, cnt, x.E, x.Z.data(), x.sdf, x.featx, x.ldfx, 1.0f / scale, s);
     sdf_grad_chain(m, cnt, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s);
     GradFinish gf;
     gf.P = cnt; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
     gf.grad_out = x.relit; gf.AUX = x.AUX; gf.neg_g_as_view = (m.c.col_mode != 1) ? 1 : 0; gf.multires_view = m.mv;
+    gf.featx = x.featx; gf.ldfx = x.ldfx; gf.F = m.F;
     be_grad_finish(gf, s);
     // colour chain with the final layer written straight into the caller's [n][3] buffer
     for (int l = 0; l < m.NC; ++l) {

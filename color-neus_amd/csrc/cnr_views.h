@@ -1,11 +1,11 @@
 // Operand views and epilogues of the two GEMM kernels (layer GEMM, weight-gradient GEMM).
 //
-// A "view" is a lazily evaluated [P x ncols] fp32 matrix: the GEMM staging code asks it for 4
-// consecutive columns of one row and the view applies the fused prologue (softplus, sigma'(z)*v,
-// concat of two sources, scaling ...) while the tile travels HBM -> LDS.  An "epilogue" consumes one
-// accumulator element (row, col) and applies bias / activation / second-order terms / split stores.
-// Both are interpreted (wave-uniform switch) so that ONE compiled kernel per tile shape serves every
-// layer of the SDF / colour / relight stacks, forward and backward.
+// A "view" is a [P x K] fp32 operand = a plain row-major matrix in HBM (row stride a multiple of 4 floats, padded with
+// finite values up to a multiple of 16 columns) plus a fused element-wise prologue (softplus, sigma'(z)*v, scaling ...)
+// that is applied in registers while the tile travels HBM -> LDS.  The loads are unconditional 16-byte loads (no
+// branches around memory operations in the GEMM main loop); only the math is interpreted (wave-uniform switch).
+// An "epilogue" consumes 4 consecutive accumulator columns of one row and applies bias / activation / second-order
+// terms / split stores with 16-byte accesses where the layout allows.
 //
 // Everything here is host+device so that the CPU emulation build (tests only) executes the same code.
 #pragma once
@@ -14,86 +14,66 @@
 namespace cnr {
 
 enum ViewKind : int {
-  VK_DIRECT = 0,   // a[row*lda + col]
-  VK_SOFTPLUS,     // softplus100(a[row*lda + col])                         h_l = sp(z_l)
-  VK_SIGMUL,       // softplus100'(a[row*lda+col]) * b[row*ldb + col]       u_l = sp'(z_l) * v_l
-  VK_SIGMUL_ROW,   // softplus100'(a[row*lda+col]) * b[col]                 v_l is one broadcast row
-  VK_CONST_COL0,   // col == 0 ? 1 : 0                                      u_top = e_0
+  VK_DIRECT = 0,   // a[row][col]
+  VK_SOFTPLUS,     // softplus100(a[row][col])   for col < math_split, a[row][col] beyond (skip concat tail)
+  VK_SIGMUL,       // softplus100'(a[row][col]) * b[row][col]                u_l = sp'(z_l) * v_l
+  VK_SIGMUL_ROW,   // softplus100'(a[row][col]) * b[col]                     v_l is one broadcast row
+  VK_CONST_COL0,   // col == 0 ? 1 : 0                                       u_top = e_0 (a must still be a valid pointer)
 };
 
 struct View {
   int kind = VK_DIRECT;
   const float* a = nullptr; int lda = 0;
   const float* b = nullptr; int ldb = 0;
-  int split = 1 << 30;                 // columns >= split come from the secondary (direct) source c
-  const float* c = nullptr; int ldc = 0;
-  int ncols = 0;                       // logical width; columns >= ncols evaluate to 0
-  float scale = 1.0f;                  // multiplies primary and secondary
+  int math_split = 1 << 30;            // columns >= math_split bypass the kind's math (identity)
+  float scale = 1.0f;                  // multiplies everything
 };
 
-CNR_HD float view_primary1(const View& v, long row, int col) {
+struct Raw4 { f4 a; f4 b; };
+
+// pure loads: 4 consecutive columns (col % 4 == 0, lda % 4 == 0) of one row
+CNR_HD Raw4 view_fetch4(const View& v, long row, int col) {
+  Raw4 r;
+  r.a = *reinterpret_cast<const f4*>(v.a + row * v.lda + col);
+  if (v.kind == VK_SIGMUL) r.b = *reinterpret_cast<const f4*>(v.b + row * v.ldb + col);
+  else if (v.kind == VK_SIGMUL_ROW) r.b = *reinterpret_cast<const f4*>(v.b + col);
+  else r.b = r.a;
+  return r;
+}
+
+CNR_HD float view_math1(const View& v, float a, float b, int col) {
   switch (v.kind) {
-    case VK_DIRECT: return v.a[row * v.lda + col];
-    case VK_SOFTPLUS: return softplus100(v.a[row * v.lda + col]);
-    case VK_SIGMUL: return softplus100_d1(v.a[row * v.lda + col]) * v.b[row * v.ldb + col];
-    case VK_SIGMUL_ROW: return softplus100_d1(v.a[row * v.lda + col]) * v.b[col];
+    case VK_DIRECT: return a;
+    case VK_SOFTPLUS: return col < v.math_split ? softplus100(a) : a;
+    case VK_SIGMUL:
+    case VK_SIGMUL_ROW: return softplus100_d1(a) * b;
     default: return col == 0 ? 1.0f : 0.0f;
   }
 }
 
-CNR_HD float view_eval1(const View& v, long row, int col) {
-  if (col >= v.ncols) return 0.0f;
-  float x = col < v.split ? view_primary1(v, row, col) : v.c[row * v.ldc + (col - v.split)];
-  return x * v.scale;
-}
-
-// 4 consecutive columns (col % 4 == 0).  row must be < nrows (caller guards).
-CNR_HD f4 view_eval4(const View& v, long row, int col) {
+// pure math
+CNR_HD f4 view_finish4(const View& v, const Raw4& raw, int col) {
   f4 r;
-  int lim = v.split < v.ncols ? v.split : v.ncols;
-  if (col + 4 <= lim && (v.lda & 3) == 0 && v.kind != VK_CONST_COL0) {
-    const f4 za = *reinterpret_cast<const f4*>(v.a + row * v.lda + col);
-    switch (v.kind) {
-      case VK_DIRECT: r = za; break;
-      case VK_SOFTPLUS:
-        r.x = softplus100(za.x); r.y = softplus100(za.y); r.z = softplus100(za.z); r.w = softplus100(za.w);
-        break;
-      case VK_SIGMUL: {
-        f4 vb;
-        if ((v.ldb & 3) == 0) vb = *reinterpret_cast<const f4*>(v.b + row * v.ldb + col);
-        else { vb.x = v.b[row * v.ldb + col]; vb.y = v.b[row * v.ldb + col + 1]; vb.z = v.b[row * v.ldb + col + 2]; vb.w = v.b[row * v.ldb + col + 3]; }
-        r.x = softplus100_d1(za.x) * vb.x; r.y = softplus100_d1(za.y) * vb.y;
-        r.z = softplus100_d1(za.z) * vb.z; r.w = softplus100_d1(za.w) * vb.w;
-      } break;
-      default: {  // VK_SIGMUL_ROW
-        r.x = softplus100_d1(za.x) * v.b[col]; r.y = softplus100_d1(za.y) * v.b[col + 1];
-        r.z = softplus100_d1(za.z) * v.b[col + 2]; r.w = softplus100_d1(za.w) * v.b[col + 3];
-      } break;
-    }
-    if (v.scale != 1.0f) { r.x *= v.scale; r.y *= v.scale; r.z *= v.scale; r.w *= v.scale; }
-    return r;
-  }
-  if (col >= v.ncols) { r.x = r.y = r.z = r.w = 0.0f; return r; }
-  if (col >= v.split && col + 4 <= v.ncols && ((v.ldc | v.split) & 3) == 0) {
-    r = *reinterpret_cast<const f4*>(v.c + row * v.ldc + (col - v.split));
-    if (v.scale != 1.0f) { r.x *= v.scale; r.y *= v.scale; r.z *= v.scale; r.w *= v.scale; }
-    return r;
-  }
-  r.x = view_eval1(v, row, col); r.y = view_eval1(v, row, col + 1);
-  r.z = view_eval1(v, row, col + 2); r.w = view_eval1(v, row, col + 3);
+  r.x = view_math1(v, raw.a.x, raw.b.x, col);
+  r.y = view_math1(v, raw.a.y, raw.b.y, col + 1);
+  r.z = view_math1(v, raw.a.z, raw.b.z, col + 2);
+  r.w = view_math1(v, raw.a.w, raw.b.w, col + 3);
+  if (v.scale != 1.0f) { r.x *= v.scale; r.y *= v.scale; r.z *= v.scale; r.w *= v.scale; }
   return r;
 }
 
+CNR_HD f4 view_eval4(const View& v, long row, int col) { return view_finish4(v, view_fetch4(v, row, col), col); }
+
 // ------------------------------------------------------------------------------------------------
 enum EpiKind : int {
-  EK_STORE = 0,    // o1[row][o1_off+col] = (acc + bias[col]) * scale
+  EK_STORE = 0,    // o1[row][o1_off+col] = (acc + bias[col]) * scale ; optional tail fill (see tail_*)
   EK_SPLIT,        // v = (acc+bias)*scale ; col < split -> o1[row][o1_off+col] ; else o2[row][col-split]   (o2 may be null)
   EK_SDF_TOP,      // col == 0 -> o2[row] = (acc+bias)*scale ; col >= 1 -> o1[row][col-1] = acc+bias
   EK_RELU,         // o1 = relu(acc + bias)
-  EK_SIGMOID,      // o1 = sigmoid(acc + bias)
-  EK_LINEAR_SIG,   // o1 = acc + bias (unsqueezed colour output)
+  EK_SIGMOID,      // y = sigmoid(acc + bias) -> o1[row][col] ; optional copy o2[row][o2_off+col] (zero for col >= n_out, col < 16)
+  EK_LINEAR_SIG,   // as EK_SIGMOID without the sigmoid (unsqueezed colour output)
   EK_RELIGHT_TOP,  // t = acc+bias ; o1[row][col] = t ; o2[row][col] = relight(aux[row][col], t)
-  EK_SWEEP,        // u = acc ; o1 = sp''(z) * v * u  (second-order cotangent on z) ; o2 = sp'(z) * u (tangent of h)
+  EK_SWEEP,        // u = acc ; o1 = sp''(z) * v * u  (second-order cotangent on z) ; o2 = sp'(z) * u (tangent of h) ; tail fill on o2
   EK_VBACK,        // h = acc*scale ; col < split -> o1[row][col] = sp'(z[row][col]) * h + o1[row][col] ; else o2[row][col-split] = h
   EK_RELU_MASK,    // v = acc ; col < split -> o1[row][col] = aux[row][col] > 0 ? v : 0 ; else o2[row][col-split] = v
 };
@@ -104,13 +84,16 @@ struct Epi {
   const float* bias = nullptr;
   float scale = 1.0f;
   float* o1 = nullptr; int ld1 = 0; int o1_off = 0;
-  float* o2 = nullptr; int ld2 = 0;
+  float* o2 = nullptr; int ld2 = 0; int o2_off = 0;
   int split = 1 << 30;
   const float* z = nullptr; int ldz = 0;      // pre-activations (EK_SWEEP / EK_VBACK)
   const float* v = nullptr; int ldv = 0;      // grad-chain cotangent v_l (EK_SWEEP); ldv == 0 -> broadcast row
   float vscale = 1.0f;                        // multiplies v (the broadcast row is W_top[0,:] / scale)
   const float* aux = nullptr; int ldaux = 0;  // relu mask source / global colour
   int inv_sigmoid = 1;                        // EK_RELIGHT_TOP mode
+  // tail fill: columns [n_out, n_out + tail_n) of the main output row (o1 for EK_STORE, o2 for EK_SWEEP) receive
+  // tail_src[row][col - n_out] -- this is how the skip-connection concat [h | e] is materialised without a copy kernel
+  const float* tail_src = nullptr; int ld_tail = 0; int tail_n = 0;
 };
 
 // rgb' = sigmoid(inverse_sigmoid(rgb) + t)   (reference fields.py:354-359, transform.py:304-320)
@@ -123,8 +106,17 @@ CNR_HD float relight_apply(float rgb, float t, int inv_sigmoid) {
   return fminf(fmaxf(rgb + sigmoidf_(t) - 0.5f, 0.0f), 1.0f);
 }
 
+// one accumulator element
 CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
-  if (col >= e.n_out) return;
+  if (col >= e.n_out) {
+    if (e.tail_src && col < e.n_out + e.tail_n) {
+      float t = e.tail_src[row * e.ld_tail + (col - e.n_out)];
+      if (e.kind == EK_STORE) e.o1[row * e.ld1 + e.o1_off + col] = t;
+      else if (e.kind == EK_SWEEP) { if (e.o2) e.o2[row * e.ld2 + col] = t; e.o1[row * e.ld1 + col] = 0.0f; }
+    }
+    if ((e.kind == EK_SIGMOID || e.kind == EK_LINEAR_SIG) && e.o2 && col < 16) e.o2[row * e.ld2 + e.o2_off + col] = 0.0f;
+    return;
+  }
   switch (e.kind) {
     case EK_STORE: {
       float b = e.bias ? e.bias[col] : 0.0f;
@@ -145,8 +137,13 @@ CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
       float v = acc + e.bias[col];
       e.o1[row * e.ld1 + col] = v > 0.0f ? v : 0.0f;
     } break;
-    case EK_SIGMOID: e.o1[row * e.ld1 + col] = sigmoidf_(acc + e.bias[col]); break;
-    case EK_LINEAR_SIG: e.o1[row * e.ld1 + col] = acc + e.bias[col]; break;
+    case EK_SIGMOID:
+    case EK_LINEAR_SIG: {
+      float y = acc + e.bias[col];
+      if (e.kind == EK_SIGMOID) y = sigmoidf_(y);
+      e.o1[row * e.ld1 + col] = y;
+      if (e.o2) e.o2[row * e.ld2 + e.o2_off + col] = y;
+    } break;
     case EK_RELIGHT_TOP: {
       float t = acc + e.bias[col];
       e.o1[row * e.ld1 + col] = t;
@@ -172,6 +169,73 @@ CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
       else if (e.o2) e.o2[row * e.ld2 + (col - e.split)] = acc;
     } break;
   }
+}
+
+// 4 consecutive accumulator columns (col % 4 == 0): 16-byte fast paths for the bandwidth-heavy kinds, element-wise otherwise
+CNR_HD void epi_apply4(const Epi& e, long row, int col, f4 acc) {
+  const bool interior = col + 4 <= e.n_out && col + 4 <= e.split;
+  if (interior) {
+    switch (e.kind) {
+      case EK_STORE:
+        if (((e.ld1 | e.o1_off) & 3) == 0) {
+          f4 b = {0.f, 0.f, 0.f, 0.f};
+          if (e.bias) b = *reinterpret_cast<const f4*>(e.bias + col);
+          f4 o;
+          o.x = (acc.x + b.x) * e.scale; o.y = (acc.y + b.y) * e.scale; o.z = (acc.z + b.z) * e.scale; o.w = (acc.w + b.w) * e.scale;
+          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + e.o1_off + col) = o;
+          return;
+        }
+        break;
+      case EK_RELU:
+        if ((e.ld1 & 3) == 0) {
+          const f4 b = *reinterpret_cast<const f4*>(e.bias + col);
+          f4 o;
+          o.x = fmaxf(acc.x + b.x, 0.f); o.y = fmaxf(acc.y + b.y, 0.f); o.z = fmaxf(acc.z + b.z, 0.f); o.w = fmaxf(acc.w + b.w, 0.f);
+          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+          return;
+        }
+        break;
+      case EK_SWEEP:
+        if (((e.ld1 | e.ld2 | e.ldz | e.ldv) & 3) == 0 && e.o2) {
+          const f4 zz = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
+          f4 vv = e.ldv ? *reinterpret_cast<const f4*>(e.v + row * e.ldv + col) : *reinterpret_cast<const f4*>(e.v + col);
+          f4 o1, o2;
+          o1.x = softplus100_d2(zz.x) * (vv.x * e.vscale) * acc.x; o2.x = softplus100_d1(zz.x) * acc.x;
+          o1.y = softplus100_d2(zz.y) * (vv.y * e.vscale) * acc.y; o2.y = softplus100_d1(zz.y) * acc.y;
+          o1.z = softplus100_d2(zz.z) * (vv.z * e.vscale) * acc.z; o2.z = softplus100_d1(zz.z) * acc.z;
+          o1.w = softplus100_d2(zz.w) * (vv.w * e.vscale) * acc.w; o2.w = softplus100_d1(zz.w) * acc.w;
+          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o1;
+          *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + col) = o2;
+          return;
+        }
+        break;
+      case EK_VBACK:
+        if (((e.ld1 | e.ldz) & 3) == 0) {
+          const f4 zz = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
+          f4* p = reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col);
+          f4 o = *p;
+          o.x = softplus100_d1(zz.x) * (acc.x * e.scale) + o.x; o.y = softplus100_d1(zz.y) * (acc.y * e.scale) + o.y;
+          o.z = softplus100_d1(zz.z) * (acc.z * e.scale) + o.z; o.w = softplus100_d1(zz.w) * (acc.w * e.scale) + o.w;
+          *p = o;
+          return;
+        }
+        break;
+      case EK_RELU_MASK:
+        if (((e.ld1 | e.ldaux) & 3) == 0) {
+          const f4 m = *reinterpret_cast<const f4*>(e.aux + row * e.ldaux + col);
+          f4 o;
+          o.x = m.x > 0.f ? acc.x : 0.f; o.y = m.y > 0.f ? acc.y : 0.f; o.z = m.z > 0.f ? acc.z : 0.f; o.w = m.w > 0.f ? acc.w : 0.f;
+          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+          return;
+        }
+        break;
+      default: break;
+    }
+  }
+  epi_apply(e, row, col, acc.x);
+  epi_apply(e, row, col + 1, acc.y);
+  epi_apply(e, row, col + 2, acc.z);
+  epi_apply(e, row, col + 3, acc.w);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -60,8 +60,15 @@ class _RenderFunction(torch.autograd.Function):
         rc = lib.lib.cnr_render_forward(C.byref(ccfg), parr, C.byref(cin), C.byref(cout), _ptr(ctx_buf), nbytes, _stream_of(rays_o))
         lib.check(rc, "cnr_render_forward")
         ctx.owner = owner
-        ctx.aux = (rays_o_c, rays_d_c, near_c, far_c, t_rand, background_rgb, float(cos_anneal_ratio), out, ctx_buf, plist,
-                   z_override is not None)
+        # tensors go through save_for_backward (outputs held in a plain attribute would form an uncollectable
+        # tensor -> grad_fn -> ctx -> tensor cycle and leak the multi-GB context buffer every step)
+        ctx.cfg_aux = (float(cos_anneal_ratio), z_override is not None, t_rand is not None, background_rgb is not None, len(plist))
+        saved = [rays_o_c, rays_d_c, near_c, far_c, out["z_vals"], out["gradients"], ctx_buf]
+        if t_rand is not None:
+            saved.append(t_rand)
+        if background_rgb is not None:
+            saved.append(background_rgb)
+        ctx.save_for_backward(*saved, *plist)
         ctx.rays_need_grad = rays_o.requires_grad or rays_d.requires_grad
         ctx.mark_non_differentiable(out["inside_sphere"], out["z_vals"], out["eik_sums"])
         res = [out[k] for k in _OUT_DIFF if out[k] is not None] + [out["inside_sphere"], out["z_vals"], out["eik_sums"]]
@@ -71,9 +78,18 @@ class _RenderFunction(torch.autograd.Function):
     def backward(ctx, *gouts):
         owner = ctx.owner
         lib, ccfg, cfg = owner._lib, owner._ccfg, owner.rcfg
-        rays_o, rays_d, near, far, t_rand, background_rgb, car, out, ctx_buf, plist, had_override = ctx.aux
+        car, had_override, has_trand, has_bg, nparams = ctx.cfg_aux
+        sv = list(ctx.saved_tensors)
+        rays_o, rays_d, near, far, z_vals, gradients, ctx_buf = sv[:7]
+        pos = 7
+        t_rand = sv[pos] if has_trand else None
+        pos += 1 if has_trand else 0
+        background_rgb = sv[pos] if has_bg else None
+        pos += 1 if has_bg else 0
+        plist = sv[pos:pos + nparams]
         R = rays_o.shape[0]
-        names = [k for k in _OUT_DIFF if out[k] is not None]
+        color = cfg.type == "Color_NeuS"
+        names = [k for k in _OUT_DIFF if color or k not in ("global_color", "delta_relight")]
         gmap = {}
         for k, g in zip(names, gouts[:len(names)]):
             gmap[k] = g.contiguous().float() if g is not None else None
@@ -85,9 +101,9 @@ class _RenderFunction(torch.autograd.Function):
         gin = _lib.CnrInGrads(d_params=C.cast(darr, C.POINTER(C.c_void_p)), d_rays_o=_ptr(d_o), d_rays_d=_ptr(d_d))
         parr = (C.c_void_p * len(plist))(*[p.data_ptr() for p in plist])
         cin = _lib.CnrInputs(rays_o=_ptr(rays_o), rays_d=_ptr(rays_d), near_=_ptr(near), far_=_ptr(far), t_rand=_ptr(t_rand),
-                             z_vals_override=_ptr(out["z_vals"]) if had_override else None,
+                             z_vals_override=_ptr(z_vals) if had_override else None,
                              background_rgb=_ptr(background_rgb), n_rays=R, cos_anneal_ratio=car)
-        cout = _lib.CnrOutputs(**{k: _ptr(out[k]) for k in _lib.OUTPUT_FIELDS})
+        cout = _lib.CnrOutputs(z_vals=_ptr(z_vals), gradients=_ptr(gradients))   # the only forward outputs backward reads
         nbytes = lib.lib.cnr_bwd_scratch_bytes(C.byref(ccfg), R)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=rays_o.device)
         rc = lib.lib.cnr_render_backward(C.byref(ccfg), parr, C.byref(cin), C.byref(cout), _ptr(ctx_buf), ctx_buf.numel(),

@@ -1,0 +1,209 @@
+// Stand-alone probe: how fast can the 128 x (NT*32) FP32-MFMA layer-GEMM tiling go with a clean inner loop?
+// Variants differ in K-slab width and in how the staging is scheduled.  Build: hipcc --offload-arch=gfx950 -O3 gemm_probe.hip -o gemm_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+#define LOAD_SLAB(s_)                                                                            \
+  {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                               \
+      int idx = tid + i * 256; int r = idx / F4R, c4 = idx % F4R;                                  \
+      long row = row0 + r; if (row >= P) row = P - 1;                                              \
+      ra[i] = *reinterpret_cast<const f4*>(A + row * lda + (s_) * BK + c4 * 4);                    \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                               \
+      int idx = tid + i * 256; int r = idx / F4R, c4 = idx % F4R;                                  \
+      rb[i] = *reinterpret_cast<const f4*>(W + (long)r * ldw + (s_) * BK + c4 * 4);                \
+    }                                                                                              \
+  }
+#define STORE_SLAB(buf_)                                                                           \
+  {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                               \
+      int idx = tid + i * 256; int r = idx / F4R, c4 = idx % F4R;                                  \
+      *reinterpret_cast<f4*>(As + ((buf_) * 128 + r) * LD + c4 * 4) = ra[i];                       \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                               \
+      int idx = tid + i * 256; int r = idx / F4R, c4 = idx % F4R;                                  \
+      *reinterpret_cast<f4*>(Bs + ((buf_) * NT * 32 + r) * LD + c4 * 4) = rb[i];                   \
+    }                                                                                              \
+  }
+
+// C[P][N] = relu(A[P][K] * W[N][K]^T + b)
+template <int NT, int BK, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_v1(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                     float* __restrict__ C, long P, int K, int lda, int ldw, int ldc) {
+  constexpr int LD = BK + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * 128 * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row0 = (long)blockIdx.x * 128;
+  const int nslab = K / BK;
+  constexpr int F4R = BK / 4;                       // float4 per row per slab
+  constexpr int NA = 128 * F4R / 256, NB = NT * 32 * F4R / 256;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  f4 ra[NA], rb[NB];
+  LOAD_SLAB(0) STORE_SLAB(0) __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) LOAD_SLAB(s + 1)
+    const float* Ab = As + (buf * 128 + wave * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+    const float* Bb = Bs + (buf * NT * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      const f4 a = *reinterpret_cast<const f4*>(Ab + kb * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f4 b = *reinterpret_cast<const f4*>(Bb + nt * 32 * LD + kb * 8);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nslab) STORE_SLAB(buf ^ 1)
+    __syncthreads();
+  }
+  const long rb0 = row0 + wave * 32 + 4 * (lane >> 5);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = nt * 32 + (lane & 31);
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long row = rb0 + (r & 3) + 8 * (r >> 2);
+      if (row < P) { float v = acc[nt][r] + bv; C[row * ldc + col] = v > 0.f ? v : 0.f; }
+    }
+  }
+}
+
+// v2: same tiling, epilogue transposed through LDS so that every lane stores 16 B (float4) and a wave writes whole 512 B rows
+template <int NT, int BK, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_v2(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                     float* __restrict__ C, long P, int K, int lda, int ldw, int ldc) {
+  constexpr int LD = BK + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * 128 * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row0 = (long)blockIdx.x * 128;
+  const int nslab = K / BK;
+  constexpr int F4R = BK / 4;
+  constexpr int NA = 128 * F4R / 256, NB = NT * 32 * F4R / 256;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  f4 ra[NA], rb[NB];
+  LOAD_SLAB(0) STORE_SLAB(0) __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) LOAD_SLAB(s + 1)
+    const float* Ab = As + (buf * 128 + wave * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+    const float* Bb = Bs + (buf * NT * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      const f4 a = *reinterpret_cast<const f4*>(Ab + kb * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f4 b = *reinterpret_cast<const f4*>(Bb + nt * 32 * LD + kb * 8);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nslab) STORE_SLAB(buf ^ 1)
+    __syncthreads();
+  }
+  // epilogue through LDS: each wave owns a private 32 x (32+1) staging tile per N tile (reuses the operand buffers)
+  float* T = smem + wave * (32 * 33);
+  const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * 33 + cl] = acc[nt][r];
+    // wave-private region: LDS ops of one wave complete in order; make the compiler keep the order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // 32 rows x 32 cols = 256 float4: lane handles 4 float4: row = (lane>>3) + 8*i, c4 = lane&7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (lane >> 3) + 8 * i, c4 = lane & 7;
+      const long row = row0 + wave * 32 + rr;
+      const int col = nt * 32 + c4 * 4;
+      f4 v;
+      v.x = T[rr * 33 + c4 * 4 + 0] + bias[col + 0]; v.y = T[rr * 33 + c4 * 4 + 1] + bias[col + 1];
+      v.z = T[rr * 33 + c4 * 4 + 2] + bias[col + 2]; v.w = T[rr * 33 + c4 * 4 + 3] + bias[col + 3];
+      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      if (row < P) *reinterpret_cast<f4*>(C + row * ldc + col) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <class KFn>
+static double time_kernel(KFn fn, int iters) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) fn();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) fn();
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters;
+}
+
+int main(int argc, char** argv) {
+  const long P = argc > 1 ? atol(argv[1]) : 524288;
+  const int K = 256, N = 256;
+  std::vector<float> hA((size_t)P * K), hW((size_t)N * K), hb(N);
+  srand(1);
+  for (auto& x : hA) x = (rand() / (float)RAND_MAX) * 2 - 1;
+  for (auto& x : hW) x = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.1f;
+  for (auto& x : hb) x = (rand() / (float)RAND_MAX) * 0.1f;
+  float *A, *W, *b, *C;
+  CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&W, hW.size() * 4)); CK(hipMalloc(&b, N * 4)); CK(hipMalloc(&C, (size_t)P * N * 4));
+  CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b, hb.data(), N * 4, hipMemcpyHostToDevice));
+  const unsigned grid = (unsigned)((P + 127) / 128);
+  const double flop = 2.0 * P * N * K;
+  auto check = [&](const char* name) {
+    std::vector<float> hC(256 * (size_t)N);
+    CK(hipMemcpy(hC.data(), C + (size_t)(P - 256) * N, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int r = 0; r < 256; r += 37) for (int n = 0; n < N; n += 11) {
+      double s = hb[n];
+      for (int k = 0; k < K; ++k) s += (double)hA[(size_t)(P - 256 + r) * K + k] * hW[(size_t)n * K + k];
+      if (s < 0) s = 0;
+      maxerr = fmax(maxerr, fabs(s - hC[(size_t)r * N + n]));
+    }
+    printf("  %-28s check maxerr %.2e\n", name, maxerr);
+  };
+#define RUN(NAME, KERNEL, BKV)                                                                                    \
+  {                                                                                                               \
+    size_t lds = (size_t)(2 * 128 * (BKV + 4) + 2 * 256 * (BKV + 4)) * 4;                                         \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    CK(hipMemset(C, 0, (size_t)P * N * 4));                                                                       \
+    double ms = time_kernel([&] { hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), lds, 0, A, W, b, C, P, K, K, K, N); }, 10); \
+    CK(hipGetLastError());                                                                                        \
+    printf("%-28s %.3f ms  %.1f TF/s  (lds %zu)\n", NAME, ms, flop / (ms * 1e-3) / 1e12, lds);                    \
+    check(NAME);                                                                                                  \
+  }
+  RUN("v1 BK16 2w/simd", (gemm_v1<8, 16, 2>), 16)
+  RUN("v1 BK32 1w/simd", (gemm_v1<8, 32, 1>), 32)
+  RUN("v1 BK16 1w/simd", (gemm_v1<8, 16, 1>), 16)
+  RUN("v2 BK16 2w/simd (LDS epi)", (gemm_v2<8, 16, 2>), 16)
+  RUN("v2 BK32 1w/simd (LDS epi)", (gemm_v2<8, 32, 1>), 32)
+  return 0;
+}
