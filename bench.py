@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--no-optim", action="store_true", help="time fwd+loss+bwd only (skip clip + Adam)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=128)
+    ap.add_argument("--cpu-rays", type=int, default=512)
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="torch threads of the CPU baseline (16 was the fastest of {8,16,32,64,128} on the 2x64-core bench host)")
     ap.add_argument("--torch-gpu-baseline", action="store_true", help="also time the plain-PyTorch restatement on the GPU")
     return ap.parse_args()
 
@@ -198,7 +200,7 @@ def main():
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         from oracle import colorneus_oracle as O
         ocfg = O.dtu_config()
-        cores = os.cpu_count() or 1
+        cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
         torch.set_num_threads(cores)
         P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in renderer.state_dict().items()}
         Rc = args.cpu_rays
@@ -214,13 +216,13 @@ def main():
         cstep()
         t1 = time.perf_counter()
         n_it = 0
-        while n_it < 3 or (time.perf_counter() - t1 < 10.0 and n_it < 20):
+        while n_it < 3 or (time.perf_counter() - t1 < 12.0 and n_it < 40):
             cstep()
             n_it += 1
         cdt = time.perf_counter() - t1
         result["cpu_baseline"] = {"value": round(Rc * n_it / cdt, 2), "unit": "rays/s", "cores": cores, "kind": "port",
                                   "sample": "%d iterations of %d rays x (64+64) samples, fwd+bwd, same network/weights, "
-                                            "torch CPU ops with %d threads" % (n_it, Rc, cores)}
+                                            "torch CPU ops with %d threads (host has %d logical CPUs)" % (n_it, Rc, cores, os.cpu_count() or 0)}
 
     if rank == 0:
         print(json.dumps(result))

@@ -1,0 +1,89 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol that include/colorneus_render.h declares;
+the host-side module mirrors the reference interface; the product path has no fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import color_neus_amd as cn
+from color_neus_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "colorneus_render.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cnr_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    syms = declared_symbols()
+    assert set(syms) == set(_lib.EXPORTS), set(syms) ^ set(_lib.EXPORTS)
+
+
+@pytest.mark.parametrize("path", [cn.library_path(), os.path.join(ROOT, "tests", "_build", "libcolorneus_emu.so")])
+def test_library_exports_every_declared_symbol(path):
+    if not os.path.isfile(path):
+        pytest.skip("library not built: " + path)
+    lib = ctypes.CDLL(path)
+    for s in declared_symbols():
+        assert hasattr(lib, s), s
+
+
+def test_hip_library_identifies_itself():
+    if not os.path.isfile(cn.library_path()):
+        pytest.skip("HIP library not built")
+    lib = cn.load_library()
+    assert lib.backend == "hip-gfx950"
+    inv = lib.param_inventory(_lib.c_config(cn.RenderConfig(col_mode="no_view_dir", col_d_in=6, col_multires_view=0)))
+    assert len(inv) == 53 and sum(r * c for _, r, c in inv) == 1003198
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _lib.RenderLibrary(str(tmp_path / "libcolorneus_hip.so"))
+
+
+def test_module_mirrors_reference_interface():
+    import inspect
+    cfg = {"TYPE": "Color_NeuS", "N_SAMPLES": 16, "N_IMPORTANCE": 16,
+           "SDF": {"D_OUT": 65, "D_HIDDEN": 64, "N_LAYERS": 2, "SKIP_IN": []},
+           "COLOR": {"D_FEATURE": 64, "MODE": "no_view_dir", "D_IN": 6, "D_HIDDEN": 64, "N_LAYERS": 2, "MULTIRES_VIEW": 0},
+           "RELIGHT": {"D_HIDDEN": 64, "N_LAYERS": 2, "Y_IN_LAYER": 1}, "DEVIATION": {"INIT_VAL": 0.3}}
+
+    class Node(dict):
+        __getattr__ = dict.__getitem__
+
+    def wrap(d):
+        return Node({k: wrap(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+    r = cn.build_renderer(wrap(cfg))
+    assert isinstance(r, cn.ColorNeuSRenderer)
+    sig = inspect.signature(r.forward)
+    assert list(sig.parameters)[:7] == ["rays_o", "rays_d", "near", "far", "perturb_overwrite", "background_rgb", "cos_anneal_ratio"]
+    names = set(dict(r.named_parameters()))
+    for k in ["sdf_network.lin0.weight_g", "sdf_network.lin2.weight_v", "deviation_network.variance", "color_network.lin0.bias",
+              "relight_network.in_layer.weight", "relight_network.rl_mlp.1.bias"]:
+        assert k in names, k
+    with pytest.raises(AssertionError):           # Color_NeuS.py:14
+        bad = dict(cfg); bad["COLOR"] = dict(cfg["COLOR"], MODE="idr")
+        cn.ColorNeuSRenderer(wrap(bad))
+    with pytest.raises(NotImplementedError):      # N_OUTSIDE > 0 is outside the accelerated path
+        cn.ColorNeuSRenderer(wrap(dict(cfg, N_OUTSIDE=4)))
+
+
+def test_register_into_reference_style_registry():
+    class Reg:
+        def __init__(self):
+            self.d = {}
+
+        def register_module(self, name=None, force=False, module=None):
+            assert force and module is not None
+            self.d[name] = module
+            return module
+    reg = Reg()
+    cn.register_into(reg)
+    assert reg.d == {"NeuS": cn.NeuSRenderer, "Color_NeuS": cn.ColorNeuSRenderer}
