@@ -140,14 +140,16 @@ def main():
     }
 
     # ---- roofline of the dominant kernel: event-instrumented pass over the same steps (rank 0)
-    if not args.no_roofline and rank == 0:
-        lib.timing_enable(True)
+    if not args.no_roofline:
+        # every rank runs the same extra steps (they contain collectives when N > 1); only rank 0 records events
+        lib.timing_enable(rank == 0)
         nrep = min(args.steps, 3)
         for i in range(nrep):
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize(dev)
-        recs = lib.timing_collect()
+        recs = lib.timing_collect() if rank == 0 else []
         lib.timing_enable(False)
+    if not args.no_roofline and rank == 0:
         agg = {}
         for name, kind, nt, P, N, K, pairs, ms in recs:
             key = (name, nt) if kind != 2 else (name, 0)

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_v1(const float* __restrict__ A
 }
 
 // v2: same tiling, epilogue transposed through LDS so that every lane stores 16 B (float4) and a wave writes whole 512 B rows
-template <int NT, int BK, int MINW>
+template <int NT, int BK, int MINW, int ABL>
 __global__ __launch_bounds__(256, MINW) void gemm_v2(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
                                                      float* __restrict__ C, long P, int K, int lda, int ldw, int ldc) {
   constexpr int LD = BK + 4;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_v2(const float* __restrict__ A
   LOAD_SLAB(0) STORE_SLAB(0) __syncthreads();
   for (int s = 0; s < nslab; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nslab) LOAD_SLAB(s + 1)
+    if (ABL == 0 && s + 1 < nslab) LOAD_SLAB(s + 1)
     const float* Ab = As + (buf * 128 + wave * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
     const float* Bb = Bs + (buf * NT * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
 #pragma unroll
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_v2(const float* __restrict__ A
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
       }
     }
-    if (s + 1 < nslab) STORE_SLAB(buf ^ 1)
+    if (ABL < 2 && s + 1 < nslab) STORE_SLAB(buf ^ 1)
     __syncthreads();
   }
   // epilogue through LDS: each wave owns a private 32 x (32+1) staging tile per N tile (reuses the operand buffers)
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_v2(const float* __restrict__ A
       v.x = T[rr * 33 + c4 * 4 + 0] + bias[col + 0]; v.y = T[rr * 33 + c4 * 4 + 1] + bias[col + 1];
       v.z = T[rr * 33 + c4 * 4 + 2] + bias[col + 2]; v.w = T[rr * 33 + c4 * 4 + 3] + bias[col + 3];
       v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-      if (row < P) *reinterpret_cast<f4*>(C + row * ldc + col) = v;
+      if (row < P && (ABL < 3 || v.x == 123.456f)) *reinterpret_cast<f4*>(C + row * ldc + col) = v;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -203,7 +203,9 @@ int main(int argc, char** argv) {
   RUN("v1 BK16 2w/simd", (gemm_v1<8, 16, 2>), 16)
   RUN("v1 BK32 1w/simd", (gemm_v1<8, 32, 1>), 32)
   RUN("v1 BK16 1w/simd", (gemm_v1<8, 16, 1>), 16)
-  RUN("v2 BK16 2w/simd (LDS epi)", (gemm_v2<8, 16, 2>), 16)
-  RUN("v2 BK32 1w/simd (LDS epi)", (gemm_v2<8, 32, 1>), 32)
+  RUN("v2 BK16 2w/simd (LDS epi)", (gemm_v2<8, 16, 2, 0>), 16)
+  RUN("v2 abl1 no global loads", (gemm_v2<8, 16, 2, 1>), 16)
+  RUN("v2 abl2 no loads/LDS stores", (gemm_v2<8, 16, 2, 2>), 16)
+  RUN("v2 abl3 + no C stores", (gemm_v2<8, 16, 2, 3>), 16)
   return 0;
 }

@@ -7,9 +7,9 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda:0")
 cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)
 torch.manual_seed(0)
-r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(dev)
+r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg, library=os.environ.get('CNR_LIB'))).to(dev)
 o, d, n, f, gt, m = [x[:R] for x in synthetic.synthetic_view(seed=1, device=dev)]
-lib = cn.load_library()
+lib = cn.load_library(os.environ.get('CNR_LIB'))
 def step():
     out = r(o, d, n, f)
     loss, _ = cn.compute_loss(out, gt, m)
@@ -20,6 +20,8 @@ torch.cuda.synchronize()
 lib.timing_enable(True); step(); torch.cuda.synchronize(); recs = lib.timing_collect(); lib.timing_enable(False)
 tot = sum(x[-1] for x in recs)
 print("total kernel ms %.2f over %d launches" % (tot, len(recs)))
+if os.environ.get("CNR_BRIEF"):
+    recs = []
 for i, (name, kind, nt, P, N, K, pairs, ms) in enumerate(recs):
     fl = 2.0 * P * N * K * max(pairs, 1) if kind != 2 else 0
     print("%3d %-16s nt=%-5d P=%-8d N=%-4d K=%-4d pairs=%d  %8.3f ms  %6.1f TF/s" % (i, name, nt, P, N, K, pairs, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
