@@ -188,8 +188,19 @@ __global__ __launch_bounds__(256) void finish_weight_kernel(const FinishWeight p
   __shared__ float dwi[512];
   const int n = blockIdx.x, tid = threadIdx.x;
   for (int j = tid; j < p.ldk; j += 256) {
+    // fixed-order reduction over the chunks, 8 independent loads in flight (same summation order as a plain loop)
+    const float* src = p.partial + (long)n * p.ldk + j;
+    const long cs = (long)p.npad * p.ldk;
     float s = 0.0f;
-    for (int c = 0; c < p.nchunk; ++c) s += p.partial[((long)c * p.npad + n) * p.ldk + j];
+    int c = 0;
+    for (; c + 8 <= p.nchunk; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[(long)(c + q) * cs];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; c < p.nchunk; ++c) s += src[(long)c * cs];
     dwi[j] = s;
   }
   __syncthreads();

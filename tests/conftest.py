@@ -16,3 +16,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+def pytest_sessionstart(session):
+    """Build the CPU-emulation build of the kernel layer (tests only) if it is missing -- a few seconds with g++."""
+    import shutil
+    import subprocess
+    lib = os.path.join(ROOT, "tests", "_build", "libcolorneus_emu.so")
+    if not os.path.isfile(lib) and shutil.which("g++") and shutil.which("make"):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "color-neus_amd", "csrc"), "-j", "4", "emu"],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)

@@ -213,11 +213,40 @@ def function_fixture(CN, mods, Color_NeuS, NeuS):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def rays_fixture(mods):
+    ray_utils = mods["ray_utils"]
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 3, 12, 17
+    c2w = torch.eye(4).repeat(N, 1, 1)
+    q, _ = torch.linalg.qr(torch.randn(N, 3, 3, generator=g))
+    c2w[:, :3, :3] = q
+    c2w[:, :3, 3] = torch.randn(N, 3, generator=g)
+    focal = torch.tensor([23.0, 19.0])
+    image = torch.rand(N, H, W, 3, generator=g)
+    mask = (torch.rand(N, H, W, generator=g) < 0.4).float()
+    fx = dict(c2w=c2w.numpy(), focal=focal.numpy(), image=image.numpy(), mask=mask.numpy())
+    for tag, kw in (("m", dict(mask=mask, mask_rate=0.7, return_mask=True, normalize=True)),
+                    ("nm", dict(mask=None, normalize=False, opengl=True))):
+        torch.manual_seed(5)
+        o, d, rgb, ms = ray_utils.get_rays_multicam(c2w=c2w, focal=focal, image=image, n_rays=40, **kw)
+        fx[tag + ":o"], fx[tag + ":d"], fx[tag + ":rgb"] = o.numpy(), d.numpy(), rgb.numpy()
+        if ms is not None:
+            fx[tag + ":mask"] = ms.numpy()
+    o, d = ray_utils.get_rays_at(c2w[1], focal, H, W, normalize=True)
+    fx["at:o"], fx["at:d"] = o.numpy().copy(), d.numpy()
+    near, far = ray_utils.near_far_from_sphere(torch.from_numpy(fx["m:o"]), torch.from_numpy(fx["m:d"]))
+    fx["nf:near"], fx["nf:far"] = near.numpy(), far.numpy()
+    path = os.path.join(OUT, "rays.npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     Color_NeuS, NeuS, CN, mods = ref_import.import_reference()
     function_fixture(CN, mods, Color_NeuS, NeuS)
+    rays_fixture(mods)
     tiny = O.tiny_config()
     e2e_fixture("tiny_init", tiny, Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=False, store_weights=True, grad_stride=1)
     e2e_fixture("tiny_sharp", tiny, Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=True, store_weights=True, grad_stride=1)
