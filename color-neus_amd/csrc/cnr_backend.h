@@ -20,6 +20,7 @@ struct PrepWeight {
   float* W = nullptr; int ldw = 0; int npad = 0;      // [npad][ldw]
   float* Wt = nullptr; int ldwt = 0; int kpad = 0;    // [kpad][ldwt]
   float* bias = nullptr;                              // [npad]
+  int row_rot = 0;            // internal row i holds reference row (i + row_rot) % n  (SDF top layer: [features | sdf])
 };
 
 // dW partial reduction + weight-norm backward + un-permutation
@@ -30,6 +31,7 @@ struct FinishWeight {
   int n = 0, k_ref = 0;
   int nseg = 0; Segment seg[4];
   float* dg = nullptr; float* dv = nullptr; float* db = nullptr;   // outputs (dg null for plain Linear; dv = d weight)
+  int row_rot = 0;            // see PrepWeight
 };
 
 struct EmbedZ {   // E[r*m + j][0..kEmb) = PE(scale * (o_r + d_r * z[r*ldz + j])), optional coarse-z generation
@@ -97,7 +99,7 @@ struct CompositeBwd {
   const float* d_gradients; const float* d_weights; const float* d_gradient_error; const float* d_depth;
   const float* d_global_color; const float* d_delta_relight;
   // per-point cotangents
-  float* ztop; int ldztop;     // ztop[pt][0] = d sdf / scale
+  float* ztop; int ldztop; int ztop_col;   // ztop[pt][ztop_col] = d sdf / scale (the sdf row is the LAST internal row of the top layer)
   float* gbar;                 // [P][4] d loss / d g through alpha, eikonal and the 'gradients' output
   float* dtop;                 // [P][kTop] cotangent of the last relight layer output (pre-activation), zero padded
   float* gc_a;                 // [P][kTop] cotangent of the global colour (post-sigmoid): direct + inverse-sigmoid path

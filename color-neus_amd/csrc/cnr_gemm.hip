@@ -25,15 +25,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LG_BM = 128;     // points per workgroup (4 waves x 32 rows)
 constexpr int LG_BK = 16;      // K slab
 constexpr int LG_LD = 20;      // LDS row stride in floats: 20 = 4*5 -> ds_read_b128 of 16 rows hits 64 distinct banks
-constexpr int LG_TLD = 33;     // row stride of the epilogue transpose tile
+constexpr int LG_TLD = 36;     // row stride of the epilogue transpose tile (16-byte aligned rows -> ds_read_b128)
 
 // compile-time recursion over the N tiles: accumulator indices stay static (a runtime-indexed ext-vector array would be
 // placed in scratch memory)
 template <int NT, int I>
 __device__ __forceinline__ void lg_epilogue_tiles(const f32x16 (&acc)[NT], const Epi& e, float* T, long wave_row0, long P, int lane,
-                                                  int ncols_live) {
+                                                  int ncols_live, int col0) {
   if constexpr (I < NT) {
-    if (I * 32 < ncols_live) {
+    if (col0 + I * 32 < ncols_live) {
       const int hi = lane >> 5, cl = lane & 31;
       const int er = lane >> 3, ec4 = (lane & 7) * 4;
 #pragma unroll
@@ -44,20 +44,18 @@ __device__ __forceinline__ void lg_epilogue_tiles(const f32x16 (&acc)[NT], const
       for (int i = 0; i < 4; ++i) {
         const int rr = er + 8 * i;
         const long row = wave_row0 + rr;
-        f4 v;
-        v.x = T[rr * LG_TLD + ec4 + 0]; v.y = T[rr * LG_TLD + ec4 + 1];
-        v.z = T[rr * LG_TLD + ec4 + 2]; v.w = T[rr * LG_TLD + ec4 + 3];
-        if (row < P) epi_apply4(e, row, I * 32 + ec4, v);
+        const f4 v = *reinterpret_cast<const f4*>(T + rr * LG_TLD + ec4);
+        if (row < P) epi_apply4(e, row, col0 + I * 32 + ec4, v);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    lg_epilogue_tiles<NT, I + 1>(acc, e, T, wave_row0, P, lane, ncols_live);
+    lg_epilogue_tiles<NT, I + 1>(acc, e, T, wave_row0, P, lane, ncols_live, col0);
   }
 }
 
 template <int NT>
-__global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void layer_gemm_kernel(const LayerGemm g) {
+__global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                            // [2][128][LG_LD]
   float* Bs = smem + 2 * LG_BM * LG_LD;        // [2][NT*32][LG_LD]
@@ -86,7 +84,7 @@ __global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void layer_gemm_kernel(cons
   const float* a1p = A.a + arow1 * A.lda + ac4;
   const float* b0p = A.kind == VK_SIGMUL ? A.b + arow0 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a0p);
   const float* b1p = A.kind == VK_SIGMUL ? A.b + arow1 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a1p);
-  const float* wp = g.W + (long)(tid >> 2) * g.ldw + ac4;
+  const float* wp = g.W + (long)(g.col0 + (tid >> 2)) * g.ldw + ac4;
 
 #define LG_LOAD_SLAB(s_)                                                                     \
   {                                                                                          \
@@ -146,7 +144,7 @@ __global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void layer_gemm_kernel(cons
   float* T = smem + wave * (32 * LG_TLD);
   const Epi e = g.E;
   const int ncols_live = e.n_out + (e.tail_src ? e.tail_n : 0);
-  lg_epilogue_tiles<NT, 0>(acc, e, T, row0 + wave * 32, g.P, lane, ncols_live);
+  lg_epilogue_tiles<NT, 0>(acc, e, T, row0 + wave * 32, g.P, lane, ncols_live, g.col0);
 }
 
 template <int NT>
@@ -163,10 +161,7 @@ static void launch_layer_gemm(const LayerGemm& g, cnr_stream s) {
   hipLaunchKernelGGL(layer_gemm_kernel<NT>, dim3(grid), dim3(256), lds, s, g);
 }
 
-void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
-  int ncols = g.N;
-  if (g.E.tail_src && g.E.n_out + g.E.tail_n > ncols) ncols = g.E.n_out + g.E.tail_n;   // tail-fill columns need a tile too
-  const int nt = (ncols + 31) / 32;
+static void dispatch_layer_gemm(const LayerGemm& g, int nt, cnr_stream s) {
   switch (nt) {
     case 1: launch_layer_gemm<1>(g, s); break;
     case 2: launch_layer_gemm<2>(g, s); break;
@@ -176,11 +171,23 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
     case 6: launch_layer_gemm<6>(g, s); break;
     case 7: launch_layer_gemm<7>(g, s); break;
     case 8: launch_layer_gemm<8>(g, s); break;
-    case 9: launch_layer_gemm<9>(g, s); break;
-    case 10: launch_layer_gemm<10>(g, s); break;
     default:
-      if (g_first_error == hipSuccess) { g_first_error = hipErrorInvalidValue; g_first_error_where = "layer_gemm: N > 320"; }
+      if (g_first_error == hipSuccess) { g_first_error = hipErrorInvalidValue; g_first_error_where = "layer_gemm: tile count"; }
       return;
+  }
+}
+
+void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
+  int ncols = g.N;
+  if (g.E.tail_src && g.E.n_out + g.E.tail_n > ncols) ncols = g.E.n_out + g.E.tail_n;   // tail-fill columns need a tile too
+  // layers wider than 256 columns (257 = sdf + features, 259/262 = cotangents of concatenated inputs) run as a 256-wide launch
+  // at two workgroups per CU plus a narrow launch for the remaining columns (cheaper than one 288-wide tile at one workgroup per CU)
+  for (int c0 = 0; c0 < ncols; c0 += 256) {
+    LayerGemm part = g;
+    part.col0 = c0;
+    const int w = ncols - c0 < 256 ? ncols - c0 : 256;
+    part.N = w;   // (only used for the timing record; the kernel takes its extents from K, P and the epilogue)
+    dispatch_layer_gemm(part, (w + 31) / 32, s);
   }
   CNR_LAUNCH_CHECK("layer_gemm");
 }

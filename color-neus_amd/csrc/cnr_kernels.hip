@@ -100,18 +100,139 @@ void be_memset_zero(void* p, size_t bytes, cnr_stream s) {
 CNR_PW_KERNEL(embed_z, EmbedZ, body_embed_z)
 CNR_PW_KERNEL(embed_pts, EmbedPts, body_embed_pts)
 CNR_PW_KERNEL(fine_setup, FineSetup, body_fine_setup)
-CNR_PW_KERNEL(grad_finish, GradFinish, body_grad_finish)
 CNR_PW_KERNEL(coltop_bwd, ColTopBwd, body_coltop_bwd)
-CNR_PW_KERNEL(gbar_finish, GbarFinish, body_gbar_finish)
 CNR_PW_KERNEL(pbar_finish, PbarFinish, body_pbar_finish)
 
 void be_embed_z(const EmbedZ& p, cnr_stream s) { embed_z_launch(p, p.R * p.m, s); }
 void be_embed_pts(const EmbedPts& p, cnr_stream s) { embed_pts_launch(p, p.n, s); }
 void be_fine_setup(const FineSetup& p, cnr_stream s) { fine_setup_launch(p, p.R * p.M, s); }
-void be_grad_finish(const GradFinish& p, cnr_stream s) { grad_finish_launch(p, p.P, s); }
 void be_coltop_bwd(const ColTopBwd& p, cnr_stream s) { coltop_bwd_launch(p, p.P, s); }
-void be_gbar_finish(const GbarFinish& p, cnr_stream s) { gbar_finish_launch(p, p.P, s); }
 void be_pbar_finish(const PbarFinish& p, cnr_stream s) { pbar_finish_launch(p, p.P, s); }
+
+
+// ------------------------------------------------------------------------------------------------
+// PE-Jacobian kernels: 16 lanes per point, lane j owns the column triple [3j, 3j+3) of the 48-wide rows
+// (triple 0 = x, triple 1+2k = sin(2^k x), triple 2+2k = cos(2^k x)), so every row is read/written as one contiguous
+// 192-byte segment by its 16 lanes; the sin/cos partner values travel by shuffle.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_finish_kernel(const GradFinish p) {
+  const int lane16 = threadIdx.x & 15;
+  const long pt0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const long stride = (long)gridDim.x * 16;
+  for (long pt = pt0; pt < p.P; pt += stride) {   // all 16 lanes of a group share pt -> uniform trip count inside a group
+    const int c0 = lane16 * 3;
+    float e[3], ce[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      e[c] = p.E[pt * kEmb + c0 + c];
+      ce[c] = p.ce0[pt * kEmb + c0 + c] + (p.ces ? p.ces[pt * kEmb + c0 + c] : 0.0f);
+    }
+    const int k = lane16 > 0 ? (lane16 - 1) >> 1 : 0;
+    const bool is_sin = lane16 >= 1 && (lane16 & 1) == 1 && lane16 <= 2 * p.multires;
+    const bool is_cos = lane16 >= 2 && (lane16 & 1) == 0 && lane16 <= 2 * p.multires;
+    const float f = (float)(1 << k);
+    float part[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float e_next = __shfl_down(e[c], 1, 16);   // sin lane reads cos(2^k x) from its right neighbour
+      const float e_prev = __shfl_up(e[c], 1, 16);     // cos lane reads sin(2^k x) from its left neighbour
+      float t = 0.0f;
+      if (lane16 == 0) t = ce[c];
+      else if (is_sin) t = f * (e_next * ce[c]);
+      else if (is_cos) t = -(f * (e_prev * ce[c]));
+      part[c] = t;
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) part[c] += __shfl_xor(part[c], d, 16);
+    float g[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = part[c] * p.scale;
+    if (lane16 == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { p.grad_out[pt * 3 + c] = g[c]; p.AUX[pt * kAux + 3 + c] = g[c]; }
+    }
+    float aux[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) aux[c] = lane16 == 1 ? g[c] : p.AUX[pt * kAux + c0 + c];   // row as it will read after the update
+    if (p.neg_g_as_view) {   // AUX[6:] = PE(-g): triple t >= 2 holds encoding triple (t - 2)
+      const int et = lane16 - 2;
+      if (et >= 0) {
+        float v[3] = {-g[0], -g[1], -g[2]};
+        const int npe_tr = p.multires_view > 0 ? 1 + 2 * p.multires_view : 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float val = 0.0f;
+          if (et == 0) val = v[c];
+          else if (et < npe_tr) { const float ff = (float)(1 << ((et - 1) >> 1)); val = (et & 1) ? sinf(v[c] * ff) : cosf(v[c] * ff); }
+          if (et < npe_tr) { aux[c] = val; p.AUX[pt * kAux + c0 + c] = val; }
+        }
+      }
+    }
+    if (p.featx) {
+      const int w = p.ldfx - p.F;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (c0 + c < w) p.featx[pt * p.ldfx + p.F + c0 + c] = aux[c];
+      for (int c = kAux + lane16; c < w; c += 16) p.featx[pt * p.ldfx + p.F + c] = 0.0f;
+    }
+  }
+}
+void be_grad_finish(const GradFinish& p, cnr_stream s) {
+  if (p.P <= 0) return;
+  long blocks = (p.P * 16 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  TimingScope ts_("grad_finish", 2, 0, p.P, 0, 0, 0, s);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("grad_finish");
+}
+
+__global__ __launch_bounds__(256) void gbar_finish_kernel(const GbarFinish p) {
+  const int lane16 = threadIdx.x & 15;
+  const long pt0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const long stride = (long)gridDim.x * 16;
+  for (long pt = pt0; pt < p.P; pt += stride) {
+    const int c0 = lane16 * 3;
+    float e[3], gb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      e[c] = p.E[pt * kEmb + c0 + c];
+      float v = p.gbar_alpha[pt * 4 + c];
+      if (p.daux_c) v += p.daux_c[pt * kAux + 3 + c];
+      if (p.daux_r) v += p.daux_r[pt * kAux + 3 + c];
+      gb[c] = v;
+    }
+    const int k = lane16 > 0 ? (lane16 - 1) >> 1 : 0;
+    const bool is_sin = lane16 >= 1 && (lane16 & 1) == 1 && lane16 <= 2 * p.multires;
+    const bool is_cos = lane16 >= 2 && (lane16 & 1) == 0 && lane16 <= 2 * p.multires;
+    const float f = (float)(1 << k);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float e_next = __shfl_down(e[c], 1, 16);
+      const float e_prev = __shfl_up(e[c], 1, 16);
+      const float t = gb[c] * p.scale;
+      float out = 0.0f;
+      if (lane16 == 0) out = t;
+      else if (is_sin) out = f * e_next * t;          // d g / d ce_sin = 2^k cos(2^k x0)
+      else if (is_cos) out = -f * e_prev * t;         // d g / d ce_cos = -2^k sin(2^k x0)
+      p.cbar[pt * kEmb + c0 + c] = out;
+    }
+    if (lane16 == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) p.gbar_total[pt * 4 + c] = gb[c];
+      p.gbar_total[pt * 4 + 3] = 0.0f;
+    }
+  }
+}
+void be_gbar_finish(const GbarFinish& p, cnr_stream s) {
+  if (p.P <= 0) return;
+  long blocks = (p.P * 16 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  TimingScope ts_("gbar_finish", 2, 0, p.P, 0, 0, 0, s);
+  hipLaunchKernelGGL(gbar_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("gbar_finish");
+}
 
 // ------------------------------------------------------------------------------------------------
 // block reductions
@@ -152,15 +273,16 @@ __device__ __forceinline__ double block_sum_256d(double x, double* sh4) {
 // effective weights: weight-norm, column permutation, zero padding, transpose copy.  One block per padded row.
 __global__ __launch_bounds__(256) void prep_weight_kernel(const PrepWeight p) {
   __shared__ double redd[4];
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.x, tid = threadIdx.x;     // internal row
   const bool real = n < p.n;
+  const int nr = real ? (n + p.row_rot) % p.n : 0;  // reference row
   float scale = 1.0f;
   if (p.g != nullptr) {
     double ss = 0.0;   // row norm in double: weight_norm is the most rounding-sensitive step (x inv_s downstream)
     if (real)
-      for (int c = tid; c < p.k_ref; c += 256) { double x = p.v[(long)n * p.k_ref + c]; ss += x * x; }
+      for (int c = tid; c < p.k_ref; c += 256) { double x = p.v[(long)nr * p.k_ref + c]; ss += x * x; }
     ss = block_sum_256d(ss, redd);
-    if (real) scale = p.g[n] / (float)sqrt(ss);
+    if (real) scale = p.g[nr] / (float)sqrt(ss);
   }
   for (int j = tid; j < p.kpad; j += 256) {
     float val = 0.0f;
@@ -168,12 +290,12 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(const PrepWeight p) {
       int src = -1;
       for (int q = 0; q < p.nseg; ++q)
         if (j >= p.seg[q].dst && j < p.seg[q].dst + p.seg[q].len) src = p.seg[q].src + (j - p.seg[q].dst);
-      if (src >= 0) val = p.v[(long)n * p.k_ref + src] * scale;
+      if (src >= 0) val = p.v[(long)nr * p.k_ref + src] * scale;
     }
     if (j < p.ldw) p.W[(long)n * p.ldw + j] = val;
     if (n < p.ldwt) p.Wt[(long)j * p.ldwt + n] = val;
   }
-  if (tid == 0) p.bias[n] = real && p.b ? p.b[n] : 0.0f;
+  if (tid == 0) p.bias[n] = real && p.b ? p.b[nr] : 0.0f;
 }
 void be_prep_weight(const PrepWeight& p, cnr_stream s) {
   TimingScope ts_("prep_weight", 2, 0, p.npad, 0, 0, 0, s);
@@ -186,7 +308,8 @@ __global__ __launch_bounds__(256) void finish_weight_kernel(const FinishWeight p
   __shared__ float red[4];
   __shared__ double redd[4];
   __shared__ float dwi[512];
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.x, tid = threadIdx.x;       // internal row
+  const int nr = (n + p.row_rot) % p.n;               // reference row
   for (int j = tid; j < p.ldk; j += 256) {
     // fixed-order reduction over the chunks, 8 independent loads in flight (same summation order as a plain loop)
     const float* src = p.partial + (long)n * p.ldk + j;
@@ -218,27 +341,27 @@ __global__ __launch_bounds__(256) void finish_weight_kernel(const FinishWeight p
   if (p.g != nullptr) {
     double dotd = 0.0, ssd = 0.0;
     for (int q = 0; q < 2; ++q)
-      if (cref[q] >= 0) { double vv = p.v[(long)n * p.k_ref + cref[q]]; dotd += (double)dref[q] * vv; ssd += vv * vv; }
+      if (cref[q] >= 0) { double vv = p.v[(long)nr * p.k_ref + cref[q]]; dotd += (double)dref[q] * vv; ssd += vv * vv; }
     dotd = block_sum_256d(dotd, redd);
     ssd = block_sum_256d(ssd, redd);
     const float dot = (float)dotd;
     const float nrm = (float)sqrt(ssd);
-    const float gg = p.g[n];
-    if (tid == 0) p.dg[n] = dot / nrm;
+    const float gg = p.g[nr];
+    if (tid == 0) p.dg[nr] = dot / nrm;
     for (int q = 0; q < 2; ++q)
       if (cref[q] >= 0) {
-        float vv = p.v[(long)n * p.k_ref + cref[q]];
-        p.dv[(long)n * p.k_ref + cref[q]] = (gg / nrm) * (dref[q] - dot / (nrm * nrm) * vv);
+        float vv = p.v[(long)nr * p.k_ref + cref[q]];
+        p.dv[(long)nr * p.k_ref + cref[q]] = (gg / nrm) * (dref[q] - dot / (nrm * nrm) * vv);
       }
   } else {
     for (int q = 0; q < 2; ++q)
-      if (cref[q] >= 0) p.dv[(long)n * p.k_ref + cref[q]] = dref[q];
+      if (cref[q] >= 0) p.dv[(long)nr * p.k_ref + cref[q]] = dref[q];
   }
   if (p.db != nullptr && p.colsum != nullptr) {
     float s = 0.0f;
     for (int c = tid; c < p.nchunk; c += 256) s += p.colsum[(long)c * p.npad + n];
     s = block_sum_256(s, red);
-    if (tid == 0) p.db[n] = s;
+    if (tid == 0) p.db[nr] = s;
   }
 }
 void be_finish_weight(const FinishWeight& p, cnr_stream s) {
@@ -601,7 +724,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
           drd[k] += ag.d_tc * q[c].g[k];
         }
         if (active) {
-          p.ztop[pt * p.ldztop] = ag.d_sdf / p.sdf_scale;
+          p.ztop[pt * p.ldztop + p.ztop_col] = ag.d_sdf / p.sdf_scale;
           for (int k = 0; k < 3; ++k) p.gbar[pt * 4 + k] = gb[k];
           p.gbar[pt * 4 + 3] = 0.0f;
           for (int k = 0; k < 3; ++k) {

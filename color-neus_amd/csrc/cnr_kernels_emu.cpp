@@ -90,28 +90,30 @@ static int seg_src_of(const Segment* seg, int nseg, int j) {
 void be_prep_weight(const PrepWeight& p, cnr_stream) {
   for (int n = 0; n < p.npad; ++n) {
     const bool real = n < p.n;
+    const int nr = real ? (n + p.row_rot) % p.n : 0;
     float scale = 1.0f;
     if (p.g && real) {
       double ss = 0.0;   // row norm accumulated in double (weight_norm is the most rounding-sensitive step: x inv_s downstream)
-      for (int c = 0; c < p.k_ref; ++c) { double x = p.v[(long)n * p.k_ref + c]; ss += x * x; }
-      scale = p.g[n] / (float)sqrt(ss);
+      for (int c = 0; c < p.k_ref; ++c) { double x = p.v[(long)nr * p.k_ref + c]; ss += x * x; }
+      scale = p.g[nr] / (float)sqrt(ss);
     }
     for (int j = 0; j < p.kpad; ++j) {
       float val = 0.0f;
       if (real && j < p.ldw) {
         int src = seg_src_of(p.seg, p.nseg, j);
-        if (src >= 0) val = p.v[(long)n * p.k_ref + src] * scale;
+        if (src >= 0) val = p.v[(long)nr * p.k_ref + src] * scale;
       }
       if (j < p.ldw) p.W[(long)n * p.ldw + j] = val;
       if (n < p.ldwt) p.Wt[(long)j * p.ldwt + n] = val;
     }
-    p.bias[n] = real && p.b ? p.b[n] : 0.0f;
+    p.bias[n] = real && p.b ? p.b[nr] : 0.0f;
   }
 }
 
 void be_finish_weight(const FinishWeight& p, cnr_stream) {
   std::vector<float> dwi(p.ldk), dref(p.k_ref);
   for (int n = 0; n < p.n; ++n) {
+    const int nr = (n + p.row_rot) % p.n;
     for (int j = 0; j < p.ldk; ++j) {
       float s = 0.0f;
       for (int c = 0; c < p.nchunk; ++c) s += p.partial[((long)c * p.npad + n) * p.ldk + j];
@@ -125,20 +127,20 @@ void be_finish_weight(const FinishWeight& p, cnr_stream) {
     }
     if (p.g) {
       double dotd = 0.0, ssd = 0.0;
-      for (int c = 0; c < p.k_ref; ++c) { double vv = p.v[(long)n * p.k_ref + c]; dotd += (double)dref[c] * vv; ssd += vv * vv; }
-      float dot = (float)dotd, nrm = (float)sqrt(ssd), gg = p.g[n];
-      p.dg[n] = dot / nrm;
+      for (int c = 0; c < p.k_ref; ++c) { double vv = p.v[(long)nr * p.k_ref + c]; dotd += (double)dref[c] * vv; ssd += vv * vv; }
+      float dot = (float)dotd, nrm = (float)sqrt(ssd), gg = p.g[nr];
+      p.dg[nr] = dot / nrm;
       for (int c = 0; c < p.k_ref; ++c) {
-        float vv = p.v[(long)n * p.k_ref + c];
-        p.dv[(long)n * p.k_ref + c] = (gg / nrm) * (dref[c] - dot / (nrm * nrm) * vv);
+        float vv = p.v[(long)nr * p.k_ref + c];
+        p.dv[(long)nr * p.k_ref + c] = (gg / nrm) * (dref[c] - dot / (nrm * nrm) * vv);
       }
     } else {
-      for (int c = 0; c < p.k_ref; ++c) p.dv[(long)n * p.k_ref + c] = dref[c];
+      for (int c = 0; c < p.k_ref; ++c) p.dv[(long)nr * p.k_ref + c] = dref[c];
     }
     if (p.db && p.colsum) {
       float s = 0.0f;
       for (int c = 0; c < p.nchunk; ++c) s += p.colsum[(long)c * p.npad + n];
-      p.db[n] = s;
+      p.db[nr] = s;
     }
   }
 }
@@ -317,7 +319,7 @@ void be_composite_bwd(const CompositeBwd& p, cnr_stream) {
         drd[k] += ag.d_tc * q[j].g[k];
       }
       p.gbar[pt * 4 + 3] = 0.0f;
-      p.ztop[pt * p.ldztop] = ag.d_sdf / p.sdf_scale;
+      p.ztop[pt * p.ldztop + p.ztop_col] = ag.d_sdf / p.sdf_scale;
       for (int k = 0; k < 3; ++k) {
         float cbar = dcol[k] * w[j];
         if (p.has_relight) {

@@ -37,6 +37,7 @@ struct Lin {
   Segment seg[4];
   int ldw = 0, npad = 0, ldwt = 0, kpad = 0;
   bool wn = false;
+  int row_rot = 0;            // internal row i = reference row (i + row_rot) % n
   int p_b = -1, p_g = -1, p_v = -1;
   float *W = nullptr, *Wt = nullptr, *bias = nullptr;
   std::string name;
@@ -132,6 +133,7 @@ static int build_model(const cnr_config* cfg, Model& m) {
     if (l > 0 && !m.skip(l) && prev != q.k_ref) return fail("inconsistent SDF dims");
     if (l > 0 && m.skip(l) && prev + m.emb != q.k_ref) return fail("inconsistent SDF skip dims");
     identity_seg(q);
+    if (l == m.L) q.row_rot = 1;   // internal rows [features (F) | sdf]: the 256 feature columns stay 16-byte aligned
     q.finish_dims();
     add_linear_params(m, q, "sdf_network.lin" + std::to_string(l), c.sdf_weight_norm != 0);
     prev = out;
@@ -335,7 +337,7 @@ static void prep_all(Model& m, const float* const* params, cnr_stream s) {
     for (int i = 0; i < q.nseg; ++i) p.seg[i] = q.seg[i];
     p.W = q.W; p.ldw = q.ldw; p.npad = q.npad;
     p.Wt = q.Wt; p.ldwt = q.ldwt; p.kpad = q.kpad;
-    p.bias = q.bias;
+    p.bias = q.bias; p.row_rot = q.row_rot;
     be_prep_weight(p, s);
   };
   for (auto& q : m.sdf) prep(q);
@@ -368,10 +370,13 @@ static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, f
       g.N = q.n;
       g.E.kind = EK_STORE; g.E.n_out = q.n; g.E.bias = q.bias; g.E.o1 = Z[l]; g.E.ld1 = m.Hs;
       if (m.skip(l + 1)) { g.E.tail_src = E; g.E.ld_tail = kEmb; g.E.tail_n = m.emb; }   // next layer reads [h | e]
-    } else {
-      g.N = feat_out ? q.n : 1;
-      g.E.kind = EK_SDF_TOP; g.E.n_out = g.N; g.E.bias = q.bias; g.E.scale = top_scale;
+    } else if (feat_out) {
+      g.N = q.n;
+      g.E.kind = EK_SDF_TOP; g.E.n_out = q.n; g.E.bias = q.bias; g.E.scale = top_scale; g.E.split = m.F;
       g.E.o1 = feat_out; g.E.ld1 = ld_feat; g.E.o2 = sdf_out;
+    } else {   // value only: just the sdf row (last internal row)
+      g.W = q.W + (long)m.F * q.ldw; g.N = 1;
+      g.E.kind = EK_STORE; g.E.n_out = 1; g.E.bias = q.bias + m.F; g.E.scale = top_scale; g.E.o1 = sdf_out; g.E.ld1 = 1;
     }
     be_layer_gemm(g, s);
   }
@@ -419,7 +424,7 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
     const Lin& q = m.sdf[l];
     LayerGemm g;
     g.A.a = Z[l]; g.A.lda = m.Hs;
-    if (l == m.L - 1) { g.A.kind = VK_SIGMUL_ROW; g.A.b = m.sdf[m.L].W; g.A.scale = inv_scale; }   // v_{L-1} = W_top[0,:]/scale
+    if (l == m.L - 1) { g.A.kind = VK_SIGMUL_ROW; g.A.b = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; g.A.scale = inv_scale; }   // v_{L-1} = W_top[0,:]/scale
     else { g.A.kind = VK_SIGMUL; g.A.b = V[l]; g.A.ldb = m.Hs; }
     g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
     if (l == 0) {
@@ -568,7 +573,7 @@ static void run_dw(const Model& m, const Lin& q, DwGemm& g, const Bwd& b, const 
   f.g = q.p_g >= 0 ? params[q.p_g] : nullptr; f.v = params[q.p_v];
   f.n = q.n; f.k_ref = q.k_ref; f.nseg = q.nseg;
   for (int i = 0; i < q.nseg; ++i) f.seg[i] = q.seg[i];
-  f.dg = q.p_g >= 0 ? dparams[q.p_g] : nullptr; f.dv = dparams[q.p_v]; f.db = dparams[q.p_b];
+  f.dg = q.p_g >= 0 ? dparams[q.p_g] : nullptr; f.dv = dparams[q.p_v]; f.db = dparams[q.p_b]; f.row_rot = q.row_rot;
   be_finish_weight(f, s);
   (void)m;
 }
@@ -607,7 +612,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   cb.d_weight_max = go->weight_max; cb.d_gradients = go->gradients; cb.d_weights = go->weights;
   cb.d_gradient_error = go->gradient_error; cb.d_depth = go->depth; cb.d_global_color = m.has_relight ? go->global_color : nullptr;
   cb.d_delta_relight = m.has_relight ? go->delta_relight : nullptr;
-  cb.ztop = b.ZTOP; cb.ldztop = x.ldztop; cb.gbar = b.gbar_a; cb.dtop = b.dtop; cb.gc_a = b.gc_a; cb.dinvs_partial = b.dinvs;
+  cb.ztop = b.ZTOP; cb.ldztop = x.ldztop; cb.ztop_col = m.F; cb.gbar = b.gbar_a; cb.dtop = b.dtop; cb.gc_a = b.gc_a; cb.dinvs_partial = b.dinvs;
   cb.d_rays_d = rays_grad ? b.drd_alpha : nullptr; cb.d_z = nullptr;
   be_composite_bwd(cb, s);
   VarianceFinish vf;
@@ -661,8 +666,8 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
     if (l > 0) {
       g.E.kind = EK_RELU_MASK; g.E.n_out = q.k_int; g.E.o1 = b.DC[l - 1]; g.E.ld1 = m.Hc; g.E.aux = x.HC[l - 1]; g.E.ldaux = m.Hc;
-    } else {   // cotangent of [feat | aux]: feat part lands in ZTOP[., 1:], aux part in dAUXc
-      g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.split = m.F; g.E.o1 = b.ZTOP; g.E.ld1 = x.ldztop; g.E.o1_off = 1;
+    } else {   // cotangent of [feat | aux]: feat part lands in ZTOP[., 0:F] (the sdf cotangent sits in column F), aux part in dAUXc
+      g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.split = m.F; g.E.o1 = b.ZTOP; g.E.ld1 = x.ldztop; g.E.o1_off = 0;
       g.E.o2 = b.dAUXc; g.E.ld2 = kAux;
     }
     be_layer_gemm(g, s);
@@ -692,7 +697,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     g.A = qbar_view(l);
     g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
     g.E.kind = EK_SWEEP; g.E.n_out = q.n; g.E.z = x.Z[l]; g.E.ldz = m.Hs;
-    if (l == m.L - 1) { g.E.v = m.sdf[m.L].W; g.E.ldv = 0; g.E.vscale = inv_scale; }
+    if (l == m.L - 1) { g.E.v = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; g.E.ldv = 0; g.E.vscale = inv_scale; }
     else { g.E.v = x.V[l]; g.E.ldv = m.Hs; }
     g.E.o1 = b.Z2[l]; g.E.ld1 = m.Hs; g.E.o2 = b.VB[l]; g.E.ld2 = m.Hs;
     if (m.skip(l + 1)) { g.E.tail_src = b.cbar; g.E.ld_tail = kEmb; g.E.tail_n = m.emb; }
@@ -726,11 +731,11 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     else { d.X[0].kind = VK_DIRECT; d.X[0].a = b.Z2[l]; d.X[0].lda = m.Hs; }
     d.Y[0] = sdf_input_view(m, l, x.E, x.Z.data());
     if (l == m.L) {
-      d.X[1].kind = VK_CONST_COL0; d.X[1].a = b.ZTOP; d.X[1].lda = x.ldztop; d.X[1].scale = inv_scale;
+      d.X[1].kind = VK_CONST_COL0; d.X[1].a = b.ZTOP; d.X[1].lda = x.ldztop; d.X[1].scale = inv_scale; d.X[1].math_split = m.F;
       d.Y[1].kind = VK_DIRECT; d.Y[1].a = b.VB[m.L - 1]; d.Y[1].lda = m.Hs;
     } else {
       d.X[1].a = x.Z[l]; d.X[1].lda = m.Hs;
-      if (l == m.L - 1) { d.X[1].kind = VK_SIGMUL_ROW; d.X[1].b = m.sdf[m.L].W; d.X[1].scale = inv_scale; }
+      if (l == m.L - 1) { d.X[1].kind = VK_SIGMUL_ROW; d.X[1].b = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; d.X[1].scale = inv_scale; }
       else { d.X[1].kind = VK_SIGMUL; d.X[1].b = x.V[l]; d.X[1].ldb = m.Hs; }
       d.Y[1] = qbar_view(l);
     }

@@ -18,7 +18,7 @@ enum ViewKind : int {
   VK_SOFTPLUS,     // softplus100(a[row][col])   for col < math_split, a[row][col] beyond (skip concat tail)
   VK_SIGMUL,       // softplus100'(a[row][col]) * b[row][col]                u_l = sp'(z_l) * v_l
   VK_SIGMUL_ROW,   // softplus100'(a[row][col]) * b[col]                     v_l is one broadcast row
-  VK_CONST_COL0,   // col == 0 ? 1 : 0                                       u_top = e_0 (a must still be a valid pointer)
+  VK_CONST_COL0,   // col == hot ? 1 : 0 (hot = math_split, default 0)       u_top = unit vector of the sdf row (a must still be a valid pointer)
 };
 
 struct View {
@@ -47,7 +47,7 @@ CNR_HD float view_math1(const View& v, float a, float b, int col) {
     case VK_SOFTPLUS: return col < v.math_split ? softplus100(a) : a;
     case VK_SIGMUL:
     case VK_SIGMUL_ROW: return softplus100_d1(a) * b;
-    default: return col == 0 ? 1.0f : 0.0f;
+    default: return col == (v.math_split == (1 << 30) ? 0 : v.math_split) ? 1.0f : 0.0f;
   }
 }
 
@@ -68,7 +68,7 @@ CNR_HD f4 view_eval4(const View& v, long row, int col) { return view_finish4(v, 
 enum EpiKind : int {
   EK_STORE = 0,    // o1[row][o1_off+col] = (acc + bias[col]) * scale ; optional tail fill (see tail_*)
   EK_SPLIT,        // v = (acc+bias)*scale ; col < split -> o1[row][o1_off+col] ; else o2[row][col-split]   (o2 may be null)
-  EK_SDF_TOP,      // col == 0 -> o2[row] = (acc+bias)*scale ; col >= 1 -> o1[row][col-1] = acc+bias
+  EK_SDF_TOP,      // internal row order [features | sdf]: col < split -> o1[row][col] = acc+bias ; col == split -> o2[row] = (acc+bias)*scale
   EK_RELU,         // o1 = relu(acc + bias)
   EK_SIGMOID,      // y = sigmoid(acc + bias) -> o1[row][col] ; optional copy o2[row][o2_off+col] (zero for col >= n_out, col < 16)
   EK_LINEAR_SIG,   // as EK_SIGMOID without the sigmoid (unsqueezed colour output)
@@ -130,8 +130,8 @@ CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
     } break;
     case EK_SDF_TOP: {
       float v = acc + e.bias[col];
-      if (col == 0) e.o2[row] = v * e.scale;
-      else e.o1[row * e.ld1 + (col - 1)] = v;
+      if (col < e.split) { if (e.o1) e.o1[row * e.ld1 + col] = v; }
+      else e.o2[row] = v * e.scale;
     } break;
     case EK_RELU: {
       float v = acc + e.bias[col];
@@ -176,6 +176,16 @@ CNR_HD void epi_apply4(const Epi& e, long row, int col, f4 acc) {
   const bool interior = col + 4 <= e.n_out && col + 4 <= e.split;
   if (interior) {
     switch (e.kind) {
+      case EK_SDF_TOP:
+        if ((e.ld1 & 3) == 0 && e.o1) {
+          const f4 b = *reinterpret_cast<const f4*>(e.bias + col);
+          f4 o;
+          o.x = acc.x + b.x; o.y = acc.y + b.y; o.z = acc.z + b.z; o.w = acc.w + b.w;
+          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+          return;
+        }
+        break;
+      case EK_SPLIT:
       case EK_STORE:
         if (((e.ld1 | e.o1_off) & 3) == 0) {
           f4 b = {0.f, 0.f, 0.f, 0.f};
@@ -247,6 +257,7 @@ struct LayerGemm {
   int N = 0, K = 0;
   long P = 0;
   Epi E;
+  int col0 = 0;               // first output column handled by this launch (a wide layer may be split into column ranges)
 };
 
 // dW[N x K] (+)= sum over points of X[pt][n] * Y[pt][k]   (up to two operand pairs share the accumulators)

@@ -152,6 +152,80 @@ __global__ __launch_bounds__(256, MINW) void gemm_v2(const float* __restrict__ A
   }
 }
 
+
+// v3: 256-point tile, 8 waves (one workgroup per CU): W slab staged once per 256 points (half the L2->LDS weight traffic and
+// LDS stores per point), epilogue tile read back with ds_read_b128 (row stride 36 floats)
+template <int NT, int ABL>
+__global__ __launch_bounds__(512, 1) void gemm_v3(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                  float* __restrict__ C, long P, int K, int lda, int ldw, int ldc) {
+  constexpr int BK = 16, LD = 20, BM = 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                      // [2][256][LD]
+  float* Bs = smem + 2 * BM * LD;        // [2][NT*32][LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row0 = (long)blockIdx.x * BM;
+  const int nslab = K / BK;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  f4 ra[2], rb[2];
+  const int r0 = tid >> 2, c4 = (tid & 3) * 4;        // rows r0 and r0 + 128
+  long ar0 = row0 + r0, ar1 = row0 + r0 + 128;
+  if (ar0 >= P) ar0 = P - 1;
+  if (ar1 >= P) ar1 = P - 1;
+  const float* ap0 = A + ar0 * lda + c4; const float* ap1 = A + ar1 * lda + c4;
+  const float* wp0 = W + (long)r0 * ldw + c4; const float* wp1 = W + (long)(r0 + 128) * ldw + c4;
+#define L3(s_) { ra[0] = *reinterpret_cast<const f4*>(ap0 + (s_) * BK); ra[1] = *reinterpret_cast<const f4*>(ap1 + (s_) * BK); \
+                 rb[0] = *reinterpret_cast<const f4*>(wp0 + (s_) * BK); rb[1] = *reinterpret_cast<const f4*>(wp1 + (s_) * BK); }
+#define S3(b_) { *reinterpret_cast<f4*>(As + ((b_) * BM + r0) * LD + c4) = ra[0]; *reinterpret_cast<f4*>(As + ((b_) * BM + r0 + 128) * LD + c4) = ra[1]; \
+                 *reinterpret_cast<f4*>(Bs + ((b_) * NT * 32 + r0) * LD + c4) = rb[0]; *reinterpret_cast<f4*>(Bs + ((b_) * NT * 32 + r0 + 128) * LD + c4) = rb[1]; }
+  L3(0) S3(0) __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (ABL == 0 && s + 1 < nslab) L3(s + 1)
+    const float* Ab = As + (buf * BM + wave * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+    const float* Bb = Bs + (buf * NT * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      const f4 a = *reinterpret_cast<const f4*>(Ab + kb * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f4 b = *reinterpret_cast<const f4*>(Bb + nt * 32 * LD + kb * 8);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
+      }
+    }
+    if (ABL < 2 && s + 1 < nslab) S3(buf ^ 1)
+    __syncthreads();
+  }
+  constexpr int TLD = 36;
+  float* T = smem + wave * (32 * TLD);
+  const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * TLD + cl] = acc[nt][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (lane >> 3) + 8 * i, cc = lane & 7;
+      const long row = row0 + wave * 32 + rr;
+      const int col = nt * 32 + cc * 4;
+      f4 v = *reinterpret_cast<const f4*>(T + rr * TLD + cc * 4);
+      const f4 bb = *reinterpret_cast<const f4*>(bias + col);
+      v.x = fmaxf(v.x + bb.x, 0.f); v.y = fmaxf(v.y + bb.y, 0.f); v.z = fmaxf(v.z + bb.z, 0.f); v.w = fmaxf(v.w + bb.w, 0.f);
+      if (row < P && (ABL < 3 || v.x == 123.456f)) *reinterpret_cast<f4*>(C + row * ldc + col) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <class KFn>
 static double time_kernel(KFn fn, int iters) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -207,5 +281,19 @@ int main(int argc, char** argv) {
   RUN("v2 abl1 no global loads", (gemm_v2<8, 16, 2, 1>), 16)
   RUN("v2 abl2 no loads/LDS stores", (gemm_v2<8, 16, 2, 2>), 16)
   RUN("v2 abl3 + no C stores", (gemm_v2<8, 16, 2, 3>), 16)
+
+#define RUN3(NAME, KERNEL)                                                                                        \
+  {                                                                                                               \
+    size_t lds = (size_t)(2 * 256 * 20 + 2 * 256 * 20) * 4;                                                       \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    CK(hipMemset(C, 0, (size_t)P * N * 4));                                                                       \
+    double ms = time_kernel([&] { hipLaunchKernelGGL(KERNEL, dim3((unsigned)((P + 255) / 256)), dim3(512), lds, 0, A, W, b, C, P, K, K, K, N); }, 10); \
+    CK(hipGetLastError());                                                                                        \
+    printf("%-28s %.3f ms  %.1f TF/s  (lds %zu)\n", NAME, ms, flop / (ms * 1e-3) / 1e12, lds);                    \
+    check(NAME);                                                                                                  \
+  }
+  RUN3("v3 BM256 8 waves", (gemm_v3<8, 0>))
+  RUN3("v3 abl1 no loads", (gemm_v3<8, 1>))
+  RUN3("v3 abl3 no loads/stores", (gemm_v3<8, 3>))
   return 0;
 }
