@@ -22,7 +22,7 @@ _FP = C.c_void_p
 
 class CnrInputs(C.Structure):
     _fields_ = [("rays_o", _FP), ("rays_d", _FP), ("near_", _FP), ("far_", _FP), ("t_rand", _FP), ("z_vals_override", _FP),
-                ("background_rgb", _FP), ("n_rays", C.c_int64), ("cos_anneal_ratio", C.c_float)]
+                ("background_rgb", _FP), ("n_rays", C.c_int64), ("cos_anneal_ratio", C.c_float), ("prune_eps", C.c_float)]
 
 
 OUTPUT_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",

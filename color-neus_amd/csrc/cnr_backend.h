@@ -87,6 +87,22 @@ struct CompositeFwd {   // Color_NeuS.py:66-123, NeuS.py:382-399
   float* eik_partial;    // [R][2]
 };
 
+// inference-only early-termination compaction: samples whose compositing weight is below eps contribute < eps to the pixel,
+// so the colour / relight networks are evaluated only on the kept samples (valid when the caller consumes colour / depth only)
+struct PruneCount { const float* weights; long R; int M; float eps; int* counts; };
+struct PruneScan { const int* counts; long R; int* offsets /*[R+1]*/; };
+struct PruneGather {
+  const float* weights; long R; int M; float eps; const int* offsets;
+  int* idx;                                       // [kept] original point index
+  const float* featx; int ldfx; float* featx_c;   // rows gathered to the compact list
+  const float* aux; float* aux_c;                 // [.][kAux]
+};
+struct PruneScatter {
+  long P; const int* count; const int* idx;
+  const float* gcol_c; const float* relit_c; const float* delta_c;   // compact [.][4], [.][4], [.][3] (relit/delta null for plain NeuS)
+  float* gcol; float* relit; float* delta;                            // full-size, pre-zeroed
+};
+
 struct ReduceEik { const float* partial; long R; float* sums /*[2]*/; float* sums_out /*[2] or null*/; float* gradient_error; };
 
 struct CompositeBwd {
@@ -144,6 +160,10 @@ void be_fine_setup(const FineSetup& p, cnr_stream s);
 void be_grad_finish(const GradFinish& p, cnr_stream s);
 void be_composite_fwd(const CompositeFwd& p, cnr_stream s);
 void be_reduce_eik(const ReduceEik& p, cnr_stream s);
+void be_prune_count(const PruneCount& p, cnr_stream s);
+void be_prune_scan(const PruneScan& p, cnr_stream s);
+void be_prune_gather(const PruneGather& p, cnr_stream s);
+void be_prune_scatter(const PruneScatter& p, cnr_stream s);
 void be_composite_bwd(const CompositeBwd& p, cnr_stream s);
 void be_coltop_bwd(const ColTopBwd& p, cnr_stream s);
 void be_gbar_finish(const GbarFinish& p, cnr_stream s);

@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
   float* Bs = smem + 2 * LG_BM * LG_LD;        // [2][NT*32][LG_LD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long row0 = (long)blockIdx.x * LG_BM;
+  const long Pn = g.P_dev ? (long)*g.P_dev : g.P;   // compacted inputs: tiles past the device-side count have nothing to do
+  if (row0 >= Pn) return;
   const int nslab = (g.K + LG_BK - 1) / LG_BK;
   constexpr int NB = (NT * 32 * 4 + 255) / 256;   // float4 of W per thread per slab
   constexpr bool NB_EXACT = (NT * 32 * 4) % 256 == 0;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
   f4 rw[NB];
   const int ar0 = tid >> 2, ar1 = (tid + 256) >> 2, ac4 = (tid & 3) * 4;
   long arow0 = row0 + ar0, arow1 = row0 + ar1;
-  if (arow0 >= g.P) arow0 = g.P - 1;           // clamp: rows beyond P are computed on valid data and dropped in the epilogue
-  if (arow1 >= g.P) arow1 = g.P - 1;
+  if (arow0 >= Pn) arow0 = Pn - 1;             // clamp: rows beyond P are computed on valid data and dropped in the epilogue
+  if (arow1 >= Pn) arow1 = Pn - 1;
   const View A = g.A;
   const bool has_b = A.kind == VK_SIGMUL || A.kind == VK_SIGMUL_ROW;
   const float* a0p = A.a + arow0 * A.lda + ac4;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
   float* T = smem + wave * (32 * LG_TLD);
   const Epi e = g.E;
   const int ncols_live = e.n_out + (e.tail_src ? e.tail_n : 0);
-  lg_epilogue_tiles<NT, 0>(acc, e, T, row0 + wave * 32, g.P, lane, ncols_live, g.col0);
+  lg_epilogue_tiles<NT, 0>(acc, e, T, row0 + wave * 32, Pn, lane, ncols_live, g.col0);
 }
 
 template <int NT>

@@ -768,6 +768,109 @@ void be_composite_bwd(const CompositeBwd& p, cnr_stream s) {
   CNR_LAUNCH_CHECK("composite_bwd");
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// early-termination compaction (inference): wavefront ballot + popcount prefix per ray
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prune_count_kernel(const PruneCount p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= p.R) return;
+  int cnt = 0;
+  for (int base = 0; base < p.M; base += 64) {
+    const int j = base + lane;
+    const bool keep = j < p.M && p.weights[ray * p.M + j] >= p.eps;
+    cnt += __popcll(__ballot(keep));
+  }
+  if (lane == 0) p.counts[ray] = cnt;
+}
+void be_prune_count(const PruneCount& p, cnr_stream s) {
+  TimingScope ts_("prune_count", 2, 0, p.R, 0, 0, 0, s);
+  hipLaunchKernelGGL(prune_count_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("prune_count");
+}
+
+// exclusive scan of the per-ray counts (one workgroup; R is a few thousand)
+__global__ __launch_bounds__(1024) void prune_scan_kernel(const PruneScan p) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (long base = 0; base < p.R; base += 1024) {
+    const long i = base + tid;
+    int x = i < p.R ? p.counts[i] : 0;
+    int incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int carry = carry_s;
+    if (i < p.R) p.offsets[i] = carry + woff + incl - x;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (tid == 0) p.offsets[p.R] = carry_s;
+}
+void be_prune_scan(const PruneScan& p, cnr_stream s) {
+  TimingScope ts_("prune_scan", 2, 0, p.R, 0, 0, 0, s);
+  hipLaunchKernelGGL(prune_scan_kernel, dim3(1), dim3(1024), 0, s, p);
+  CNR_LAUNCH_CHECK("prune_scan");
+}
+
+__global__ __launch_bounds__(256) void prune_gather_kernel(const PruneGather p) {
+  __shared__ int list[4][kMaxRaySamples];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= p.R) return;
+  int carry = 0;
+  for (int base = 0; base < p.M; base += 64) {
+    const int j = base + lane;
+    const bool keep = j < p.M && p.weights[ray * p.M + j] >= p.eps;
+    const unsigned long long mask = __ballot(keep);
+    const int pos = carry + __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep) list[wave][pos] = j;
+    carry += __popcll(mask);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int off = p.offsets[ray];
+  for (int k = lane; k < carry; k += 64) p.idx[off + k] = (int)(ray * p.M + list[wave][k]);
+  const int nf4 = p.ldfx / 4;
+  for (int k = 0; k < carry; ++k) {
+    const long src = ray * p.M + list[wave][k];
+    const long dst = off + k;
+    for (int c = lane; c < nf4; c += 64)
+      reinterpret_cast<f4*>(p.featx_c + dst * p.ldfx)[c] = reinterpret_cast<const f4*>(p.featx + src * p.ldfx)[c];
+    if (lane < kAux / 4) reinterpret_cast<f4*>(p.aux_c + dst * kAux)[lane] = reinterpret_cast<const f4*>(p.aux + src * kAux)[lane];
+  }
+}
+void be_prune_gather(const PruneGather& p, cnr_stream s) {
+  TimingScope ts_("prune_gather", 2, 0, p.R, 0, 0, 0, s);
+  hipLaunchKernelGGL(prune_gather_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("prune_gather");
+}
+
+__global__ __launch_bounds__(256) void prune_scatter_kernel(const PruneScatter p) {
+  const long n = *p.count;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long pt = p.idx[i];
+    reinterpret_cast<f4*>(p.gcol)[pt] = reinterpret_cast<const f4*>(p.gcol_c)[i];
+    if (p.relit) reinterpret_cast<f4*>(p.relit)[pt] = reinterpret_cast<const f4*>(p.relit_c)[i];
+    if (p.delta) for (int c = 0; c < 3; ++c) p.delta[pt * 3 + c] = p.delta_c[i * 3 + c];
+  }
+}
+void be_prune_scatter(const PruneScatter& p, cnr_stream s) {
+  long blocks = (p.P + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  TimingScope ts_("prune_scatter", 2, 0, p.P, 0, 0, 0, s);
+  hipLaunchKernelGGL(prune_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("prune_scatter");
+}
+
 // d rays: one wavefront per ray
 __global__ __launch_bounds__(256) void rays_grad_finish_kernel(const RaysGradFinish p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

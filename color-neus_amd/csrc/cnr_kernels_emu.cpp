@@ -19,7 +19,9 @@ int be_check_last_error(char*, size_t) { return 0; }
 void be_memset_zero(void* p, size_t bytes, cnr_stream) { memset(p, 0, bytes); }
 void be_grid_points(float*, cnr_stream) {}
 
-void be_layer_gemm(const LayerGemm& g, cnr_stream) {
+void be_layer_gemm(const LayerGemm& g0, cnr_stream) {
+  LayerGemm g = g0;
+  if (g.P_dev) g.P = *g.P_dev;
   const int kp = round_up(g.K, 4);
   std::vector<float> arow(kp + 4);
 #pragma omp parallel for firstprivate(arow)
@@ -379,4 +381,40 @@ void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream) {
   }
 }
 
+}  // namespace cnr
+
+namespace cnr {
+void be_prune_count(const PruneCount& p, cnr_stream) {
+  for (long r = 0; r < p.R; ++r) {
+    int c = 0;
+    for (int j = 0; j < p.M; ++j) c += p.weights[r * p.M + j] >= p.eps ? 1 : 0;
+    p.counts[r] = c;
+  }
+}
+void be_prune_scan(const PruneScan& p, cnr_stream) {
+  int run = 0;
+  for (long r = 0; r < p.R; ++r) { p.offsets[r] = run; run += p.counts[r]; }
+  p.offsets[p.R] = run;
+}
+void be_prune_gather(const PruneGather& p, cnr_stream) {
+  for (long r = 0; r < p.R; ++r) {
+    int k = p.offsets[r];
+    for (int j = 0; j < p.M; ++j) {
+      long pt = r * p.M + j;
+      if (!(p.weights[pt] >= p.eps)) continue;
+      p.idx[k] = (int)pt;
+      memcpy(p.featx_c + (long)k * p.ldfx, p.featx + pt * p.ldfx, sizeof(float) * p.ldfx);
+      memcpy(p.aux_c + (long)k * kAux, p.aux + pt * kAux, sizeof(float) * kAux);
+      ++k;
+    }
+  }
+}
+void be_prune_scatter(const PruneScatter& p, cnr_stream) {
+  for (long i = 0; i < *p.count; ++i) {
+    long pt = p.idx[i];
+    for (int c = 0; c < 4; ++c) p.gcol[pt * 4 + c] = p.gcol_c[i * 4 + c];
+    if (p.relit) for (int c = 0; c < 4; ++c) p.relit[pt * 4 + c] = p.relit_c[i * 4 + c];
+    if (p.delta) for (int c = 0; c < 3; ++c) p.delta[pt * 3 + c] = p.delta_c[i * 3 + c];
+  }
+}
 }  // namespace cnr

@@ -221,6 +221,8 @@ struct Arena {
 struct Ctx {   // forward-saved state
   // effective weights live in the Lin structs
   float *E, *AUX, *sdf, *featx, *hry, *CE0, *CES, *gcol, *relit, *eik_partial, *eik_sums;
+  // early-termination compaction (inference): compact copies of the colour-chain inputs/outputs + index list
+  float *featx_c, *aux_c, *gcol_c, *relit_c, *delta_c; int *p_idx, *p_counts, *p_offsets;
   int ldfx = 0, ldy = 0;   // row strides of featx = [feat | aux | 0] and hry = [relight hidden | global colour | 0]
   std::vector<float*> Z, V, HC, HR;
   // sampler scratch (forward only)
@@ -274,6 +276,14 @@ static void layout_ctx(Model& m, long R, Arena& a, Ctx& x) {
   x.s_sdf = a.f((size_t)R * m.M);
   x.s_newz = a.f((size_t)R * 64);
   x.s_newsdf = a.f((size_t)R * 64);
+  x.featx_c = a.f((size_t)P * x.ldfx);
+  x.aux_c = a.f((size_t)P * kAux);
+  x.gcol_c = a.f((size_t)P * 4);
+  x.relit_c = a.f((size_t)P * 4);
+  x.delta_c = a.f((size_t)P * 4);
+  x.p_idx = reinterpret_cast<int*>(a.f(P));
+  x.p_counts = reinterpret_cast<int*>(a.f(R));
+  x.p_offsets = reinterpret_cast<int*>(a.f(R + 1));
   x.ldztop = round_up(m.F + 1, 16);
   a.f(1024);   // slack: GEMM tiles may read (never use) a few columns past the last row of a buffer
 }
@@ -452,12 +462,12 @@ static View color_input_view(const Model& m, int l, const Ctx& x) {
   return v;
 }
 
-static void color_chain(const Model& m, long P, const Ctx& x, cnr_stream s) {
+static void color_chain(const Model& m, long P, const Ctx& x, cnr_stream s, const int* P_dev = nullptr) {
   for (int l = 0; l < m.NC; ++l) {
     const Lin& q = m.col[l];
     LayerGemm g;
     g.A = color_input_view(m, l, x);
-    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
+    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.bias = q.bias; g.E.n_out = q.n;
     if (l + 1 < m.NC) { g.E.kind = EK_RELU; g.E.o1 = x.HC[l]; g.E.ld1 = m.Hc; }
     else {
@@ -476,12 +486,12 @@ static View relight_input_view(const Model& m, int i /* rl_mlp index, -1 = in_la
   return v;
 }
 
-static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out, cnr_stream s) {
+static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out, cnr_stream s, const int* P_dev = nullptr) {
   {
     const Lin& q = m.rel[0];
     LayerGemm g;
     g.A = relight_input_view(m, -1, x);
-    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
+    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.kind = EK_RELU; g.E.bias = q.bias; g.E.n_out = q.n; g.E.o1 = x.HR[0]; g.E.ld1 = hr_ld(m, x, 0);
     be_layer_gemm(g, s);
   }
@@ -489,7 +499,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
     const Lin& q = m.rel[1 + i];
     LayerGemm g;
     g.A = relight_input_view(m, i, x);
-    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
+    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.bias = q.bias; g.E.n_out = q.n;
     if (i + 1 < m.NR) { g.E.kind = EK_RELU; g.E.o1 = x.HR[i + 1]; g.E.ld1 = hr_ld(m, x, i + 1); }
     else {
@@ -543,9 +553,6 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   gf.P = P; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
   gf.grad_out = out->gradients; gf.AUX = x.AUX; gf.neg_g_as_view = 0; gf.multires_view = m.mv;
   be_grad_finish(gf, s);
-  color_chain(m, P, x, s);
-  if (m.has_relight) relight_chain(m, P, x, out->delta_relight, s);
-
   CompositeFwd cf;
   cf.o = in->rays_o; cf.d = in->rays_d; cf.z = out->z_vals; cf.R = R; cf.M = m.M; cf.sample_dist = 2.0f / (float)m.S;
   cf.sdf = x.sdf; cf.g = out->gradients;
@@ -555,6 +562,34 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   cf.color_fine = out->color_fine; cf.s_val = out->s_val; cf.cdf_fine = out->cdf_fine; cf.weight_sum = out->weight_sum;
   cf.weight_max = out->weight_max; cf.weights = out->weights; cf.inside_sphere = out->inside_sphere; cf.depth = out->depth;
   cf.global_color = m.has_relight ? out->global_color : nullptr; cf.eik_partial = x.eik_partial;
+
+  if (in->prune_eps > 0.0f) {
+    // inference-only early termination: weights first (they need only sdf and its gradient), then the colour / relight networks
+    // on the compacted list of samples with weight >= eps, scattered back into zero-filled per-sample buffers
+    be_memset_zero(x.gcol, (size_t)P * 4 * sizeof(float), s);
+    be_memset_zero(x.relit, (size_t)P * 4 * sizeof(float), s);
+    if (m.has_relight) be_memset_zero(out->delta_relight, (size_t)P * 3 * sizeof(float), s);
+    be_composite_fwd(cf, s);
+    PruneCount pc; pc.weights = out->weights; pc.R = R; pc.M = m.M; pc.eps = in->prune_eps; pc.counts = x.p_counts;
+    be_prune_count(pc, s);
+    PruneScan ps; ps.counts = x.p_counts; ps.R = R; ps.offsets = x.p_offsets;
+    be_prune_scan(ps, s);
+    PruneGather pg; pg.weights = out->weights; pg.R = R; pg.M = m.M; pg.eps = in->prune_eps; pg.offsets = x.p_offsets; pg.idx = x.p_idx;
+    pg.featx = x.featx; pg.ldfx = x.ldfx; pg.featx_c = x.featx_c; pg.aux = x.AUX; pg.aux_c = x.aux_c;
+    be_prune_gather(pg, s);
+    Ctx xc = x;   // the chains run on the compact buffers; only the device knows how many rows they hold
+    xc.featx = x.featx_c; xc.AUX = x.aux_c; xc.gcol = x.gcol_c; xc.relit = x.relit_c;
+    const int* kept = x.p_offsets + R;
+    color_chain(m, P, xc, s, kept);
+    if (m.has_relight) relight_chain(m, P, xc, x.delta_c, s, kept);
+    PruneScatter sc; sc.P = P; sc.count = kept; sc.idx = x.p_idx; sc.gcol_c = x.gcol_c; sc.relit_c = m.has_relight ? x.relit_c : nullptr;
+    sc.delta_c = m.has_relight ? x.delta_c : nullptr; sc.gcol = x.gcol; sc.relit = m.has_relight ? x.relit : nullptr;
+    sc.delta = m.has_relight ? out->delta_relight : nullptr;
+    be_prune_scatter(sc, s);
+  } else {
+    color_chain(m, P, x, s);
+    if (m.has_relight) relight_chain(m, P, x, out->delta_relight, s);
+  }
   be_composite_fwd(cf, s);
   ReduceEik re;
   re.partial = x.eik_partial; re.R = R; re.sums = x.eik_sums; re.sums_out = out->eik_sums; re.gradient_error = out->gradient_error;
@@ -584,6 +619,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   Model m;
   if (build_model(cfg, m)) return -1;
   if (!params || !in || !out || !ctx || !go || !gi || !gi->d_params || !scratch) return fail("null argument");
+  if (in->prune_eps > 0.0f) return fail("cnr_render_backward: the forward pass ran with prune_eps > 0 (inference-only early termination)");
   const long R = in->n_rays;
   const long P = R * m.M;
   Arena a(const_cast<void*>(ctx));

@@ -258,6 +258,7 @@ struct LayerGemm {
   long P = 0;
   Epi E;
   int col0 = 0;               // first output column handled by this launch (a wide layer may be split into column ranges)
+  const int* P_dev = nullptr; // optional device-side row count (<= P): compacted point lists whose length only the GPU knows
 };
 
 // dW[N x K] (+)= sum over points of X[pt][n] * Y[pt][k]   (up to two operand pairs share the accumulators)

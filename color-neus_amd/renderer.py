@@ -32,7 +32,7 @@ class _RenderFunction(torch.autograd.Function):
     """autograd edge around cnr_render_forward / cnr_render_backward."""
 
     @staticmethod
-    def forward(ctx, owner, rays_o, rays_d, near, far, t_rand, z_override, background_rgb, cos_anneal_ratio, *params):
+    def forward(ctx, owner, rays_o, rays_d, near, far, t_rand, z_override, background_rgb, cos_anneal_ratio, prune_eps, *params):
         lib, ccfg, cfg = owner._lib, owner._ccfg, owner.rcfg
         dev = rays_o.device
         R, M = rays_o.shape[0], cfg.n_total
@@ -53,7 +53,8 @@ class _RenderFunction(torch.autograd.Function):
         parr = (C.c_void_p * len(plist))(*[p.data_ptr() for p in plist])
         cin = _lib.CnrInputs(rays_o=_ptr(rays_o_c), rays_d=_ptr(rays_d_c), near_=_ptr(near_c), far_=_ptr(far_c),
                              t_rand=_ptr(t_rand), z_vals_override=_ptr(out["z_vals"]) if z_override is not None else None,
-                             background_rgb=_ptr(background_rgb), n_rays=R, cos_anneal_ratio=float(cos_anneal_ratio))
+                             background_rgb=_ptr(background_rgb), n_rays=R, cos_anneal_ratio=float(cos_anneal_ratio),
+                             prune_eps=float(prune_eps))
         cout = _lib.CnrOutputs(**{k: _ptr(out[k]) for k in _lib.OUTPUT_FIELDS})
         nbytes = lib.lib.cnr_ctx_bytes(C.byref(ccfg), R)
         ctx_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -62,7 +63,8 @@ class _RenderFunction(torch.autograd.Function):
         ctx.owner = owner
         # tensors go through save_for_backward (outputs held in a plain attribute would form an uncollectable
         # tensor -> grad_fn -> ctx -> tensor cycle and leak the multi-GB context buffer every step)
-        ctx.cfg_aux = (float(cos_anneal_ratio), z_override is not None, t_rand is not None, background_rgb is not None, len(plist))
+        ctx.cfg_aux = (float(cos_anneal_ratio), z_override is not None, t_rand is not None, background_rgb is not None, len(plist),
+                       float(prune_eps))
         saved = [rays_o_c, rays_d_c, near_c, far_c, out["z_vals"], out["gradients"], ctx_buf]
         if t_rand is not None:
             saved.append(t_rand)
@@ -78,7 +80,9 @@ class _RenderFunction(torch.autograd.Function):
     def backward(ctx, *gouts):
         owner = ctx.owner
         lib, ccfg, cfg = owner._lib, owner._ccfg, owner.rcfg
-        car, had_override, has_trand, has_bg, nparams = ctx.cfg_aux
+        car, had_override, has_trand, has_bg, nparams, prune_eps = ctx.cfg_aux
+        if prune_eps > 0:
+            raise RuntimeError("prune_eps > 0 is inference-only (early-termination compaction); call under torch.no_grad()")
         sv = list(ctx.saved_tensors)
         rays_o, rays_d, near, far, z_vals, gradients, ctx_buf = sv[:7]
         pos = 7
@@ -109,7 +113,7 @@ class _RenderFunction(torch.autograd.Function):
         rc = lib.lib.cnr_render_backward(C.byref(ccfg), parr, C.byref(cin), C.byref(cout), _ptr(ctx_buf), ctx_buf.numel(),
                                          C.byref(cg), C.byref(gin), _ptr(scratch), nbytes, _stream_of(rays_o))
         lib.check(rc, "cnr_render_backward")
-        return (None, d_o, d_d, None, None, None, None, None, None) + tuple(dparams)
+        return (None, d_o, d_d, None, None, None, None, None, None, None) + tuple(dparams)
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -265,9 +269,11 @@ class NeuSRenderer(nn.Module):
 
     # -- NeuS.forward (NeuS.py:294-408) -------------------------------------------------------------------------------
     def forward(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0, z_vals=None,
-                **kwargs):
+                prune_eps=0.0, **kwargs):
         """input: rays_o [n_rays,3], rays_d [n_rays,3], near/far [n_rays].  Extra kwarg ``z_vals`` (not in the reference)
-        overrides the sampler so that render_core can be checked at fixed sample positions."""
+        overrides the sampler so that render_core can be checked at fixed sample positions; ``prune_eps`` > 0 (inference only, not in the
+        reference) skips the colour / relight networks for samples whose compositing weight is below it (NeuS_Trainer.validate_image
+        consumes only color_fine and depth, :244-245)."""
         n_rays = len(rays_o)
         dev = rays_d.device
         perturb = self.perturb
@@ -280,7 +286,7 @@ class NeuSRenderer(nn.Module):
         if background_rgb is not None:
             bg = torch.as_tensor(background_rgb, dtype=torch.float32, device=dev).reshape(-1)[:3].contiguous()
         params = self._ordered_params()
-        res = _RenderFunction.apply(self, rays_o, rays_d, near, far, t_rand, z_vals, bg, cos_anneal_ratio, *params)
+        res = _RenderFunction.apply(self, rays_o, rays_d, near, far, t_rand, z_vals, bg, cos_anneal_ratio, prune_eps, *params)
         names = [k for k in _OUT_DIFF if not (k in ("global_color", "delta_relight") and self.rcfg.type != "Color_NeuS")]
         out = dict(zip(names + ["inside_sphere", "z_vals", "eik_sums"], res))
         ret = {k: out[k] for k in ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",

@@ -53,6 +53,9 @@ typedef struct cnr_render_inputs {
   const float* background_rgb;  /* [3] or NULL */
   int64_t n_rays;
   float cos_anneal_ratio;
+  float prune_eps;              /* > 0: INFERENCE ONLY early-termination compaction -- the colour / relight networks run only on samples
+                                   whose compositing weight is >= prune_eps (pixel error < prune_eps per skipped sample); per-sample
+                                   colour outputs of skipped samples are zero and cnr_render_backward must not be called */
 } cnr_render_inputs;
 
 /* the reference's return dict (NeuS.py:387-408) plus the final z_vals; M = n_samples + n_importance */

@@ -8,7 +8,9 @@ dev = torch.device("cuda:0")
 cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)
 torch.manual_seed(0)
 r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg, library=os.environ.get('CNR_LIB'))).to(dev)
-o, d, n, f, gt, m = [x[:R] for x in synthetic.synthetic_view(seed=1, device=dev)]
+views = synthetic.synthetic_view(seed=1, device=dev)
+sel = torch.randperm(views[0].shape[0], generator=torch.Generator().manual_seed(7))[:R].to(dev)
+o, d, n, f, gt, m = [x[sel] for x in views]
 lib = cn.load_library(os.environ.get('CNR_LIB'))
 def step():
     out = r(o, d, n, f)
