@@ -226,6 +226,162 @@ __global__ __launch_bounds__(512, 1) void gemm_v3(const float* __restrict__ A, c
   }
 }
 
+
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_v4(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                     float* __restrict__ C, long P, int K, int lda, int ldw, int ldc) {
+  constexpr int NT = 4, BK = 16, LD = 20;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * 128 * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row0 = (long)blockIdx.x * 128;
+  const int col0 = blockIdx.y * 128;
+  const int nslab = K / BK;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  f4 ra[2], rb[2];
+  const int r0 = tid >> 2, c4 = (tid & 3) * 4;
+  long ar0 = row0 + r0, ar1 = row0 + r0 + 64;
+  if (ar0 >= P) ar0 = P - 1;
+  if (ar1 >= P) ar1 = P - 1;
+  const float* ap0 = A + ar0 * lda + c4; const float* ap1 = A + ar1 * lda + c4;
+  const float* wp0 = W + (long)(col0 + r0) * ldw + c4; const float* wp1 = W + (long)(col0 + r0 + 64) * ldw + c4;
+#define L4(s_) { ra[0] = *reinterpret_cast<const f4*>(ap0 + (s_) * BK); ra[1] = *reinterpret_cast<const f4*>(ap1 + (s_) * BK); \
+                 rb[0] = *reinterpret_cast<const f4*>(wp0 + (s_) * BK); rb[1] = *reinterpret_cast<const f4*>(wp1 + (s_) * BK); }
+#define S4(b_) { *reinterpret_cast<f4*>(As + ((b_) * 128 + r0) * LD + c4) = ra[0]; *reinterpret_cast<f4*>(As + ((b_) * 128 + r0 + 64) * LD + c4) = ra[1]; \
+                 *reinterpret_cast<f4*>(Bs + ((b_) * 128 + r0) * LD + c4) = rb[0]; *reinterpret_cast<f4*>(Bs + ((b_) * 128 + r0 + 64) * LD + c4) = rb[1]; }
+  L4(0) S4(0) __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) L4(s + 1)
+    const float* Ab = As + (buf * 128 + wave * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+    const float* Bb = Bs + (buf * 128 + (lane & 31)) * LD + (lane >> 5) * 4;
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      const f4 a = *reinterpret_cast<const f4*>(Ab + kb * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f4 b = *reinterpret_cast<const f4*>(Bb + nt * 32 * LD + kb * 8);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nslab) S4(buf ^ 1)
+    __syncthreads();
+  }
+  constexpr int TLD = 36;
+  float* T = smem + wave * (32 * TLD);
+  const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * TLD + cl] = acc[nt][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (lane >> 3) + 8 * i, cc = lane & 7;
+      const long row = row0 + wave * 32 + rr;
+      const int col = col0 + nt * 32 + cc * 4;
+      f4 v = *reinterpret_cast<const f4*>(T + rr * TLD + cc * 4);
+      const f4 bb = *reinterpret_cast<const f4*>(bias + col);
+      v.x = fmaxf(v.x + bb.x, 0.f); v.y = fmaxf(v.y + bb.y, 0.f); v.z = fmaxf(v.z + bb.z, 0.f); v.w = fmaxf(v.w + bb.w, 0.f);
+      if (row < P) *reinterpret_cast<f4*>(C + row * ldc + col) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
+// v5: v3 (256-point tile, 8 waves) with prefetch distance 2: loads for slab s+2 are issued while slab s is computed; two register sets
+template <int NT>
+__global__ __launch_bounds__(512, 1) void gemm_v5(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                  float* __restrict__ C, long P, int K, int lda, int ldw, int ldc) {
+  constexpr int BK = 16, LD = 20, BM = 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row0 = (long)blockIdx.x * BM;
+  const int nslab = K / BK;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  f4 xa[2], xb[2], ya[2], yb[2];
+  const int r0 = tid >> 2, c4 = (tid & 3) * 4;
+  long ar0 = row0 + r0, ar1 = row0 + r0 + 128;
+  if (ar0 >= P) ar0 = P - 1;
+  if (ar1 >= P) ar1 = P - 1;
+  const float* ap0 = A + ar0 * lda + c4; const float* ap1 = A + ar1 * lda + c4;
+  const float* wp0 = W + (long)r0 * ldw + c4; const float* wp1 = W + (long)(r0 + 128) * ldw + c4;
+#define L5(a_, b_, s_) { a_[0] = *reinterpret_cast<const f4*>(ap0 + (s_) * BK); a_[1] = *reinterpret_cast<const f4*>(ap1 + (s_) * BK); \
+                         b_[0] = *reinterpret_cast<const f4*>(wp0 + (s_) * BK); b_[1] = *reinterpret_cast<const f4*>(wp1 + (s_) * BK); }
+#define S5(a_, b_, bf_) { *reinterpret_cast<f4*>(As + ((bf_) * BM + r0) * LD + c4) = a_[0]; *reinterpret_cast<f4*>(As + ((bf_) * BM + r0 + 128) * LD + c4) = a_[1]; \
+                          *reinterpret_cast<f4*>(Bs + ((bf_) * NT * 32 + r0) * LD + c4) = b_[0]; *reinterpret_cast<f4*>(Bs + ((bf_) * NT * 32 + r0 + 128) * LD + c4) = b_[1]; }
+#define C5(bf_)                                                                                  \
+  {                                                                                              \
+    const float* Ab = As + ((bf_) * BM + wave * 32 + (lane & 31)) * LD + (lane >> 5) * 4;        \
+    const float* Bb = Bs + ((bf_) * NT * 32 + (lane & 31)) * LD + (lane >> 5) * 4;               \
+    _Pragma("unroll") for (int kb = 0; kb < BK / 8; ++kb) {                                      \
+      const f4 a = *reinterpret_cast<const f4*>(Ab + kb * 8);                                    \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                        \
+        const f4 b = *reinterpret_cast<const f4*>(Bb + nt * 32 * LD + kb * 8);                   \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);              \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);              \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);              \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);              \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  // x holds slab s+1 (to be published at the end of iteration s), y receives slab s+2
+  L5(xa, xb, 0) S5(xa, xb, 0)
+  if (nslab > 1) L5(xa, xb, 1)
+  __syncthreads();
+  for (int s = 0; s < nslab; s += 2) {
+    if (s + 2 < nslab) L5(ya, yb, s + 2)
+    C5(0)
+    if (s + 1 < nslab) S5(xa, xb, 1)
+    __syncthreads();
+    if (s + 1 < nslab) {
+      if (s + 3 < nslab) L5(xa, xb, s + 3)
+      C5(1)
+      if (s + 2 < nslab) S5(ya, yb, 0)
+      __syncthreads();
+    }
+  }
+  constexpr int TLD = 36;
+  float* T = smem + wave * (32 * TLD);
+  const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * TLD + cl] = acc[nt][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (lane >> 3) + 8 * i, cc = lane & 7;
+      const long row = row0 + wave * 32 + rr;
+      const int col = nt * 32 + cc * 4;
+      f4 v = *reinterpret_cast<const f4*>(T + rr * TLD + cc * 4);
+      const f4 bb = *reinterpret_cast<const f4*>(bias + col);
+      v.x = fmaxf(v.x + bb.x, 0.f); v.y = fmaxf(v.y + bb.y, 0.f); v.z = fmaxf(v.z + bb.z, 0.f); v.w = fmaxf(v.w + bb.w, 0.f);
+      if (row < P) *reinterpret_cast<f4*>(C + row * ldc + col) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <class KFn>
 static double time_kernel(KFn fn, int iters) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -295,5 +451,19 @@ int main(int argc, char** argv) {
   RUN3("v3 BM256 8 waves", (gemm_v3<8, 0>))
   RUN3("v3 abl1 no loads", (gemm_v3<8, 1>))
   RUN3("v3 abl3 no loads/stores", (gemm_v3<8, 3>))
+
+#define RUN4(NAME, KERNEL)                                                                                        \
+  {                                                                                                               \
+    size_t lds = (size_t)(2 * 128 * 20 + 2 * 128 * 20) * 4;                                                       \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    CK(hipMemset(C, 0, (size_t)P * N * 4));                                                                       \
+    double ms = time_kernel([&] { hipLaunchKernelGGL(KERNEL, dim3((unsigned)((P + 127) / 128), 2), dim3(256), lds, 0, A, W, b, C, P, K, K, K, N); }, 10); \
+    CK(hipGetLastError());                                                                                        \
+    printf("%-28s %.3f ms  %.1f TF/s  (lds %zu)\n", NAME, ms, flop / (ms * 1e-3) / 1e12, lds);                    \
+    check(NAME);                                                                                                  \
+  }
+  RUN3("v5 BM256 prefetch dist 2", (gemm_v5<8>))
+  RUN4("v4 128x128 tiles 3wg/CU", (gemm_v4<3>))
+  RUN4("v4 128x128 tiles 4wg/CU", (gemm_v4<4>))
   return 0;
 }
