@@ -151,6 +151,9 @@ struct PbarFinish {   // total cotangent of p: colour/relight aux inputs + SDF v
 void be_layer_gemm(const LayerGemm& g, cnr_stream s);
 void be_dw_gemm(const DwGemm& g, cnr_stream s);
 void be_prep_weight(const PrepWeight& p, cnr_stream s);
+// fp32 matrix [rows][ld] -> two f16 planes of the row-scaled matrix (x * 2^e = hi + lo, 22 significand bits) + 1/2^e per row,
+// for the weight-stationary f16-split GEMM (cnr_gemm.hip)
+void be_split_planes(const float* src, int rows, int ld, unsigned short* planes, float* inv_scale, cnr_stream s);
 void be_finish_weight(const FinishWeight& p, cnr_stream s);
 void be_embed_z(const EmbedZ& p, cnr_stream s);
 void be_embed_pts(const EmbedPts& p, cnr_stream s);

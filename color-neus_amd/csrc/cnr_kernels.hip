@@ -297,6 +297,33 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(const PrepWeight p) {
   }
   if (tid == 0) p.bias[n] = real && p.b ? p.b[nr] : 0.0f;
 }
+
+// fp32 matrix -> two f16 planes of the row-scaled matrix: x * 2^e = hi + lo with e chosen per row so that max|x| * 2^e is in
+// [2^13, 2^14) (exact scaling; 11 + 11 significand bits), plus 1 / 2^e per row.  One 64-thread block per row.
+__global__ __launch_bounds__(64) void split_planes_kernel(const float* src, int ld, unsigned short* planes, long plane_stride, float* inv_scale) {
+  const int r = blockIdx.x;
+  const float* row = src + (long)r * ld;
+  float mx = 0.0f;
+  for (int k = threadIdx.x; k < ld; k += 64) mx = fmaxf(mx, fabsf(row[k]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  float sc = 1.0f;
+  if (mx > 0.0f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); if (e < -100) e = -100; sc = ldexpf(1.0f, 14 - e); }
+  for (int k = threadIdx.x; k < ld; k += 64) {
+    const float x = row[k] * sc;
+    const _Float16 h1 = (_Float16)x;
+    const _Float16 h2 = (_Float16)(x - (float)h1);
+    planes[(long)r * ld + k] = __builtin_bit_cast(unsigned short, h1);
+    planes[plane_stride + (long)r * ld + k] = __builtin_bit_cast(unsigned short, h2);
+  }
+  if (threadIdx.x == 0) inv_scale[r] = 1.0f / sc;
+}
+void be_split_planes(const float* src, int rows, int ld, unsigned short* planes, float* inv_scale, cnr_stream s) {
+  TimingScope ts_("split_planes", 2, 0, rows, 0, 0, 0, s);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(rows), dim3(64), 0, s, src, ld, planes, (long)rows * ld, inv_scale);
+  CNR_LAUNCH_CHECK("split_planes");
+}
+
 void be_prep_weight(const PrepWeight& p, cnr_stream s) {
   TimingScope ts_("prep_weight", 2, 0, p.npad, 0, 0, 0, s);
   hipLaunchKernelGGL(prep_weight_kernel, dim3(p.npad), dim3(256), 0, s, p);

@@ -13,6 +13,7 @@
 namespace cnr {
 
 const char* be_name() { return "cpu-emu"; }
+void be_split_planes(const float*, int, int, unsigned short*, float*, cnr_stream) {}
 void be_timing_enable(int) {}
 int be_timing_collect(KernelTiming*, int) { return 0; }
 int be_check_last_error(char*, size_t) { return 0; }

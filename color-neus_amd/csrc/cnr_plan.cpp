@@ -40,6 +40,8 @@ struct Lin {
   int row_rot = 0;            // internal row i = reference row (i + row_rot) % n
   int p_b = -1, p_g = -1, p_v = -1;
   float *W = nullptr, *Wt = nullptr, *bias = nullptr;
+  unsigned short *Wp = nullptr, *Wtp = nullptr;   // two f16 planes (hi, lo) of the row-scaled W / Wt
+  float *Wps = nullptr, *Wtps = nullptr;          // per-row inverse scales
   std::string name;
   void finish_dims() {
     ldw = round_up(k_int, 16);
@@ -237,6 +239,10 @@ static void layout_weights(Model& m, Arena& a) {
     q.W = a.f((size_t)q.npad * q.ldw);
     q.Wt = a.f((size_t)q.kpad * q.ldwt);
     q.bias = a.f(q.npad);
+    q.Wp = reinterpret_cast<unsigned short*>(a.f((size_t)q.npad * q.ldw));
+    q.Wtp = reinterpret_cast<unsigned short*>(a.f((size_t)q.kpad * q.ldwt));
+    q.Wps = a.f(q.npad);
+    q.Wtps = a.f(q.kpad);
   };
   for (auto& q : m.sdf) place(q);
   for (auto& q : m.col) place(q);
@@ -349,6 +355,8 @@ static void prep_all(Model& m, const float* const* params, cnr_stream s) {
     p.Wt = q.Wt; p.ldwt = q.ldwt; p.kpad = q.kpad;
     p.bias = q.bias; p.row_rot = q.row_rot;
     be_prep_weight(p, s);
+    be_split_planes(q.W, q.npad, q.ldw, q.Wp, q.Wps, s);
+    be_split_planes(q.Wt, q.kpad, q.ldwt, q.Wtp, q.Wtps, s);
   };
   for (auto& q : m.sdf) prep(q);
   for (auto& q : m.col) prep(q);
@@ -375,7 +383,7 @@ static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, f
     const Lin& q = m.sdf[l];
     LayerGemm g;
     g.A = sdf_input_view(m, l, E, Z);
-    g.W = q.W; g.ldw = q.ldw; g.K = q.k_int; g.P = n;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.K = q.k_int; g.P = n;
     if (l < m.L) {
       g.N = q.n;
       g.E.kind = EK_STORE; g.E.n_out = q.n; g.E.bias = q.bias; g.E.o1 = Z[l]; g.E.ld1 = m.Hs;
@@ -385,7 +393,7 @@ static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, f
       g.E.kind = EK_SDF_TOP; g.E.n_out = q.n; g.E.bias = q.bias; g.E.scale = top_scale; g.E.split = m.F;
       g.E.o1 = feat_out; g.E.ld1 = ld_feat; g.E.o2 = sdf_out;
     } else {   // value only: just the sdf row (last internal row)
-      g.W = q.W + (long)m.F * q.ldw; g.N = 1;
+      g.W = q.W + (long)m.F * q.ldw; g.N = 1; g.Wp = nullptr;
       g.E.kind = EK_STORE; g.E.n_out = 1; g.E.bias = q.bias + m.F; g.E.scale = top_scale; g.E.o1 = sdf_out; g.E.ld1 = 1;
     }
     be_layer_gemm(g, s);
@@ -436,7 +444,7 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
     g.A.a = Z[l]; g.A.lda = m.Hs;
     if (l == m.L - 1) { g.A.kind = VK_SIGMUL_ROW; g.A.b = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; g.A.scale = inv_scale; }   // v_{L-1} = W_top[0,:]/scale
     else { g.A.kind = VK_SIGMUL; g.A.b = V[l]; g.A.ldb = m.Hs; }
-    g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+    g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
     if (l == 0) {
       g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = CE0; g.E.ld1 = kEmb;
     } else if (m.skip(l)) {
@@ -467,7 +475,7 @@ static void color_chain(const Model& m, long P, const Ctx& x, cnr_stream s, cons
     const Lin& q = m.col[l];
     LayerGemm g;
     g.A = color_input_view(m, l, x);
-    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.bias = q.bias; g.E.n_out = q.n;
     if (l + 1 < m.NC) { g.E.kind = EK_RELU; g.E.o1 = x.HC[l]; g.E.ld1 = m.Hc; }
     else {
@@ -491,7 +499,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
     const Lin& q = m.rel[0];
     LayerGemm g;
     g.A = relight_input_view(m, -1, x);
-    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.kind = EK_RELU; g.E.bias = q.bias; g.E.n_out = q.n; g.E.o1 = x.HR[0]; g.E.ld1 = hr_ld(m, x, 0);
     be_layer_gemm(g, s);
   }
@@ -499,7 +507,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
     const Lin& q = m.rel[1 + i];
     LayerGemm g;
     g.A = relight_input_view(m, i, x);
-    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.bias = q.bias; g.E.n_out = q.n;
     if (i + 1 < m.NR) { g.E.kind = EK_RELU; g.E.o1 = x.HR[i + 1]; g.E.ld1 = hr_ld(m, x, i + 1); }
     else {
@@ -664,7 +672,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       const int ldo = (i == m.NR - 1) ? kTop : m.Hr;
       LayerGemm g;
       g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo;
-      g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+      g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
       g.E.kind = EK_RELU_MASK; g.E.n_out = q.k_int; g.E.split = m.Hr; g.E.o1 = b.D[i]; g.E.ld1 = m.Hr;
       g.E.aux = x.HR[i]; g.E.ldaux = hr_ld(m, x, i); g.E.o2 = (i == y) ? b.gc_b : nullptr; g.E.ld2 = 4;
       be_layer_gemm(g, s);
@@ -678,7 +686,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       const Lin& q = m.rel[0];
       LayerGemm g;
       g.A.kind = VK_DIRECT; g.A.a = b.D[0]; g.A.lda = m.Hr;
-      g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+      g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
       g.E.kind = EK_STORE; g.E.n_out = q.k_int; g.E.o1 = b.dAUXr; g.E.ld1 = kAux;
       be_layer_gemm(g, s);
       DwGemm d;
@@ -699,7 +707,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     const int ldo = (l == m.NC - 1) ? kTop : m.Hc;
     LayerGemm g;
     g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo;
-    g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+    g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
     if (l > 0) {
       g.E.kind = EK_RELU_MASK; g.E.n_out = q.k_int; g.E.o1 = b.DC[l - 1]; g.E.ld1 = m.Hc; g.E.aux = x.HC[l - 1]; g.E.ldaux = m.Hc;
     } else {   // cotangent of [feat | aux]: feat part lands in ZTOP[., 0:F] (the sdf cotangent sits in column F), aux part in dAUXc
@@ -731,7 +739,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     const Lin& q = m.sdf[l];
     LayerGemm g;
     g.A = qbar_view(l);
-    g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = P;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P;
     g.E.kind = EK_SWEEP; g.E.n_out = q.n; g.E.z = x.Z[l]; g.E.ldz = m.Hs;
     if (l == m.L - 1) { g.E.v = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; g.E.ldv = 0; g.E.vscale = inv_scale; }
     else { g.E.v = x.V[l]; g.E.ldv = m.Hs; }
@@ -745,7 +753,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     LayerGemm g;
     if (l == m.L) { g.A.kind = VK_DIRECT; g.A.a = b.ZTOP; g.A.lda = x.ldztop; }
     else { g.A.kind = VK_DIRECT; g.A.a = b.Z2[l]; g.A.lda = m.Hs; }
-    g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+    g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
     g.E.kind = EK_VBACK; g.E.n_out = q.k_int; g.E.z = x.Z[l - 1]; g.E.ldz = m.Hs; g.E.o1 = b.Z2[l - 1]; g.E.ld1 = m.Hs;
     if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; }
     be_layer_gemm(g, s);
@@ -754,7 +762,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     const Lin& q = m.sdf[0];
     LayerGemm g;
     g.A.kind = VK_DIRECT; g.A.a = b.Z2[0]; g.A.lda = m.Hs;
-    g.W = q.Wt; g.ldw = q.ldwt; g.N = q.k_int; g.K = q.n; g.P = P;
+    g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
     g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = b.ebar0; g.E.ld1 = kEmb;
     be_layer_gemm(g, s);
   }
@@ -996,7 +1004,7 @@ int cnr_vertex_color(const cnr_config* cfg, const float* const* params, const fl
       const Lin& q = m.col[l];
       LayerGemm g;
       g.A = color_input_view(m, l, x);
-      g.W = q.W; g.ldw = q.ldw; g.N = q.n; g.K = q.k_int; g.P = cnt;
+      g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = cnt;
       g.E.bias = q.bias; g.E.n_out = q.n;
       if (l + 1 < m.NC) { g.E.kind = EK_RELU; g.E.o1 = x.HC[l]; g.E.ld1 = m.Hc; }
       else { g.E.kind = m.c.col_squeeze_out ? EK_SIGMOID : EK_LINEAR_SIG; g.E.o1 = rgb + start * 3; g.E.ld1 = 3; }

@@ -258,6 +258,9 @@ struct LayerGemm {
   long P = 0;
   Epi E;
   int col0 = 0;               // first output column handled by this launch (a wide layer may be split into column ranges)
+  const unsigned short* Wp = nullptr;   // optional: W as two f16 planes (hi, lo) of the row-scaled weights, same [rows][ldw] layout each
+  long wp_stride = 0;                   // elements between planes
+  const float* wscale = nullptr;        // per W row: 1 / (power-of-two scale applied before the f16 split)
   const int* P_dev = nullptr; // optional device-side row count (<= P): compacted point lists whose length only the GPU knows
 };
 
