@@ -41,7 +41,7 @@ class CnrOutGrads(C.Structure):
 
 class CnrKernelTiming(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("kind", C.c_int32), ("nt", C.c_int32), ("P", C.c_long), ("N", C.c_int32),
-                ("K", C.c_int32), ("pairs", C.c_int32), ("ms", C.c_float)]
+                ("K", C.c_int32), ("pairs", C.c_int32), ("ms", C.c_float), ("bytes", C.c_double)]
 
 
 class CnrInGrads(C.Structure):
@@ -117,10 +117,10 @@ class RenderLibrary:
         self.lib.cnr_timing_enable(1 if on else 0)
 
     def timing_collect(self, max_records=65536):
-        """Per-launch records [(name, kind, nt, P, N, K, pairs, ms)] since the last collect (synchronises the events)."""
+        """Per-launch records [(name, kind, nt, P, N, K, pairs, ms, bytes)] since the last collect (synchronises the events)."""
         buf = (CnrKernelTiming * max_records)()
         n = self.lib.cnr_timing_collect(buf, max_records)
-        return [(buf[i].name.decode(), buf[i].kind, buf[i].nt, buf[i].P, buf[i].N, buf[i].K, buf[i].pairs, buf[i].ms)
+        return [(buf[i].name.decode(), buf[i].kind, buf[i].nt, buf[i].P, buf[i].N, buf[i].K, buf[i].pairs, buf[i].ms, buf[i].bytes)
                 for i in range(min(n, max_records))]
 
     def param_inventory(self, ccfg):

@@ -175,7 +175,7 @@ void be_pbar_finish(const PbarFinish& p, cnr_stream s);
 void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s);
 void be_memset_zero(void* p, size_t bytes, cnr_stream s);
 void be_grid_points(float* pts /*unused*/, cnr_stream s);
-struct KernelTiming { char name[32]; int kind; int nt; long P; int N, K, pairs; float ms; };
+struct KernelTiming { char name[32]; int kind; int nt; long P; int N, K, pairs; float ms; double bytes; };
 void be_timing_enable(int on);
 int be_timing_collect(KernelTiming* out, int max_records);   // synchronises the recorded events, returns #records, resets
 const char* be_name();

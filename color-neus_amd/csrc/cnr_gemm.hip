@@ -161,7 +161,7 @@ static void launch_layer_gemm(const LayerGemm& g, cnr_stream s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  TimingScope ts_("layer_gemm", 0, NT, g.P, g.N, g.K, 1, s);
+  TimingScope ts_("layer_gemm", 0, NT, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
   hipLaunchKernelGGL(layer_gemm_kernel<NT>, dim3(grid), dim3(256), lds, s, g);
 }
 
@@ -196,7 +196,13 @@ __device__ __forceinline__ void ws_put4(const f4& v, float sc, unsigned char* ds
   *reinterpret_cast<f16x4*>(dst + aplane) = h2;
 }
 
-__global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const LayerGemm g, int tiles_per_wg, int wrows) {
+// VK / EK >= 0 pin the view / epilogue kind at compile time: the interpreted switches of cnr_views.h fold away and each
+// instantiation only allocates the registers its own prologue and epilogue need (-1 = generic, interpreted at run time).
+template <int VK, int EK>
+__global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const LayerGemm g_in, int tiles_per_wg, int wrows) {
+  LayerGemm g = g_in;
+  if (VK >= 0) g.A.kind = VK;
+  if (EK >= 0) g.E.kind = EK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long Pn = g.P_dev ? (long)*g.P_dev : g.P;
@@ -229,6 +235,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   }
   f4 wsc = {1.f, 1.f, 1.f, 1.f};               // inverse column scales of the 4 columns this lane finishes in the epilogue
   if (has_w) wsc = *reinterpret_cast<const f4*>(g.wscale + c0 + (lane & 7) * 4);
+  const int ecol = c0 + (lane & 7) * 4;         // ... and their epilogue path / bias (fixed per lane for the whole launch)
+  const bool efast = epi_fast4(g.E, ecol);
+  f4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (efast) bias4 = epi_bias4(g.E, ecol);
 
   // ---- staging map: 16 threads per row, 4 consecutive columns each, up to 4 passes of 64 columns
   const int srow = tid >> 4, scol = (tid & 15) * 4;
@@ -286,7 +296,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       WS_MFMA(0) WS_MFMA(1) WS_MFMA(2) WS_MFMA(3) WS_MFMA(4) WS_MFMA(5) WS_MFMA(6) WS_MFMA(7)
       WS_MFMA(8) WS_MFMA(9) WS_MFMA(10) WS_MFMA(11) WS_MFMA(12) WS_MFMA(13) WS_MFMA(14) WS_MFMA(15)
     }
-    // epilogue of this 32 x 32 tile: undo the exact row / column scales, then the fused epilogue on 4 columns per lane
+    // epilogue of this 32 x 32 tile: undo the exact row / column scales, then the fused epilogue on 4 columns per lane.
+    // The side inputs of all four row groups are requested first: one memory round trip per tile, and no load has to
+    // wait behind the stores of the previous row group.
     if (c0 < ncols_live) {
       const float* rs = reinterpret_cast<const float*>(smem_b + buf * abuf + 2 * aplane);
       const int hi = lane >> 5, cl = lane & 31;
@@ -294,14 +306,28 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * WS_TLD + cl] = acc[r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      constexpr int EG = (EK == EK_SWEEP) ? 2 : 4;   // row groups whose side inputs are in flight together (register budget)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr = (lane >> 3) + 8 * i, cc = (lane & 7) * 4;
-        const long row = t * WS_TP + rr;
-        const float rsc = rs[rr];
-        f4 v = *reinterpret_cast<const f4*>(T + rr * WS_TLD + cc);
-        v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
-        if (row < Pn) epi_apply4(g.E, row, c0 + cc, v);
+      for (int i0 = 0; i0 < 4; i0 += EG) {
+        EpiRaw4 er[EG];
+#pragma unroll
+        for (int i = 0; i < EG; ++i) {
+          long row = t * WS_TP + (lane >> 3) + 8 * (i0 + i);
+          if (row >= Pn) row = Pn - 1;
+          if (efast) er[i] = epi_fetch4(g.E, row, ecol);
+        }
+#pragma unroll
+        for (int i = 0; i < EG; ++i) {
+          const int rr = (lane >> 3) + 8 * (i0 + i), cc = (lane & 7) * 4;
+          const long row = t * WS_TP + rr;
+          const float rsc = rs[rr];
+          f4 v = *reinterpret_cast<const f4*>(T + rr * WS_TLD + cc);
+          v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
+          if (row < Pn) {
+            if (efast) epi_finish4(g.E, row, ecol, v, bias4, er[i]);
+            else epi_apply4(g.E, row, ecol, v);
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -314,7 +340,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
 #undef WS_MFMA
 }
 
-static void launch_layer_gemm_ws(const LayerGemm& g, int wrows, cnr_stream s) {
+template <int VK, int EK>
+static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
   const int nkb = (g.K + 15) / 16;
   const int abuf = 2 * WS_TP * (nkb * 32 + 16) + 128;
   const size_t lds = (size_t)2 * abuf + (size_t)8 * 32 * WS_TLD * sizeof(float);
@@ -325,11 +352,24 @@ static void launch_layer_gemm_ws(const LayerGemm& g, int wrows, cnr_stream s) {
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s);
-  hipLaunchKernelGGL(layer_gemm_ws_kernel, dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
+  TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
+  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
+}
+
+static void launch_layer_gemm_ws(const LayerGemm& g, int wrows, cnr_stream s) {
+  static const bool generic_only = getenv("CNR_WS_GENERIC") != nullptr;   // debugging aid: interpreted kernel for every combination
+  const int vk = g.A.kind, ek = g.E.kind;
+#define WS_CASE(V_, E_) if (!generic_only && vk == V_ && ek == E_) { launch_ws_t<V_, E_>(g, wrows, s); return; }
+  // the combinations the render plan issues on 256-wide layers (cnr_plan.cpp)
+  WS_CASE(VK_SOFTPLUS, EK_STORE) WS_CASE(VK_DIRECT, EK_STORE) WS_CASE(VK_SOFTPLUS, EK_SDF_TOP)
+  WS_CASE(VK_SIGMUL, EK_STORE) WS_CASE(VK_SIGMUL_ROW, EK_STORE) WS_CASE(VK_SIGMUL, EK_SPLIT)
+  WS_CASE(VK_DIRECT, EK_RELU) WS_CASE(VK_DIRECT, EK_RELU_MASK) WS_CASE(VK_DIRECT, EK_SPLIT)
+  WS_CASE(VK_DIRECT, EK_SWEEP) WS_CASE(VK_DIRECT, EK_VBACK)
+#undef WS_CASE
+  launch_ws_t<-1, -1>(g, wrows, s);
 }
 
 static void dispatch_layer_gemm(const LayerGemm& g, int nt, cnr_stream s) {
@@ -511,19 +551,221 @@ static void launch_dw(const DwGemm& g, int n0, int k0, cnr_stream s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_kernel<WR, WC, MT, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  TimingScope ts_("dw_gemm", 1, WR * 1000 + WC * 100 + MT * 10 + KT, g.P, (g.N - n0) < TN ? (g.N - n0) : TN,
-                  (g.K - k0) < TK ? (g.K - k0) : TK, g.npairs, s);
+  const int tn_ = (g.N - n0) < TN ? (g.N - n0) : TN, tk_ = (g.K - k0) < TK ? (g.K - k0) : TK;
+  TimingScope ts_("dw_gemm", 1, WR * 1000 + WC * 100 + MT * 10 + KT, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
   hipLaunchKernelGGL((dw_gemm_kernel<WR, WC, MT, KT>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
+}
+
+// ================================================================================================
+// weight-gradient GEMM, 256 x 256 output tile, split-bf16 matrix cores
+//
+// Same output-stationary structure as dw_gemm_kernel<4,2,2,4> (128 accumulator registers per wave, one workgroup per point
+// chunk), but each fp32 operand element is split into three bf16 terms x = x1 + x2 + x3 (8 + 8 + 8 significand bits, the fp32
+// exponent range is kept, so no scaling is needed along the contraction over points) and each product is evaluated as six
+// v_mfma_f32_32x32x16_bf16 (x1y1 + x1y2 + x2y1 + x2y2 + x1y3 + x3y1, small terms first; the dropped terms are < 2^-25
+// relative).  6 x 32 cycles per 32x32x16 block against 8 x 64 for v_mfma_f32_32x32x2_f32: 2.7x the matrix rate at fp32 accuracy.
+//
+// LDS: per operand and plane the 16-point slab is stored as [half h][j = n % 4][c = n / 4][8 points] bf16 with 1088-byte
+// j-regions: the staging threads (4 columns x 4 points each) write 8-byte point quads, adjacent lanes adjacent quads
+// (conflict-free), and an MFMA lane reads the 16 bytes of its row n / point half h (conflict-free: 16 lanes cover 16
+// distinct 16-byte bank groups).
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int DX_JREG = 1088;                 // bytes per j-region (64 columns x 16 bytes + 64 bytes of bank rotation)
+constexpr int DX_HALF = 4 * DX_JREG;          // one point half (8 points) of one plane
+constexpr int DX_PLANE = 2 * DX_HALF;         // one bf16 plane of a 16-point x 256-column slab
+constexpr int DX_OPER = 3 * DX_PLANE;         // three planes
+constexpr int DX_BUF = 2 * DX_OPER;           // X and Y
+
+__device__ __forceinline__ void dx_split3(float x, __bf16& h1, __bf16& h2, __bf16& h3) {
+  h1 = (__bf16)x;
+  float r = x - (float)h1;
+  h2 = (__bf16)r;
+  r = r - (float)h2;
+  h3 = (__bf16)r;
+}
+
+// XK0 / YK0 / XK1 / YK1 >= 0 pin the view kinds of the operand pairs at compile time (-1 = interpreted at run time)
+template <int XK0, int YK0, int XK1, int YK1>
+__global__ __launch_bounds__(512, 1) void dw_gemm_bx_kernel(const DwGemm g_in, int n0, int k0) {
+  DwGemm g = g_in;
+  if (XK0 >= 0) g.X[0].kind = XK0;
+  if (YK0 >= 0) g.Y[0].kind = YK0;
+  if (XK1 >= 0) g.X[1].kind = XK1;
+  if (YK1 >= 0) g.Y[1].kind = YK1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;               // 4 x 2 waves, 64 x 128 outputs each
+  // 16-point slabs are dealt round-robin to the workgroups (slab = i * nchunk + chunk): at any moment the CUs read one
+  // contiguous stretch of X and Y, which spreads over all HBM channels; the partial sums stay in a fixed order
+  const long chunk = blockIdx.x;
+  const long p_end = g.P;
+  const long total_slabs = (g.P + 15) / 16;
+  const int nslab_pair = chunk < total_slabs ? (int)((total_slabs - chunk + g.nchunk - 1) / g.nchunk) : 0;
+  const int nslab = nslab_pair * g.npairs;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // staging role: threads 0..255 stage X, 256..511 stage Y; each 4 columns x 4 points
+  const bool is_y = tid >= 256;
+  const int st = tid & 255;
+  const int qlo = st & 1, c4 = (st >> 1) & 63, qhi = st >> 7;
+  const int q = qhi * 2 + qlo;                          // point quad of the slab
+  const int scol = (is_y ? k0 : n0) + c4 * 4;
+  unsigned char* const sdst = smem_d + (is_y ? DX_OPER : 0) + qhi * DX_HALF + c4 * 16 + qlo * 8;
+  f4 ra[4], rb[4];
+  bool okp[4];
+  int staged_pair = 0;
+  f4 csum = {0.f, 0.f, 0.f, 0.f};
+  const bool want_colsum = g.colsum != nullptr && k0 == 0;
+
+#define DX_FETCH_(V_)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+    long pt = pbase_ + i;                                                                  \
+    okp[i] = pt < p_end;                                                                   \
+    if (!okp[i]) pt = p_end - 1;                                                           \
+    const Raw4 q_ = view_fetch4(V_, pt, scol);                                             \
+    ra[i] = q_.a; rb[i] = q_.b;                                                            \
+  }
+#define DX_LOAD_SLAB(s_)                                                                   \
+  {                                                                                        \
+    const int pair_ = (s_) / nslab_pair;                                                   \
+    staged_pair = pair_;                                                                   \
+    const long pbase_ = ((long)((s_) - pair_ * nslab_pair) * g.nchunk + chunk) * 16 + q * 4; \
+    if (pair_ == 0) { if (is_y) { DX_FETCH_(g.Y[0]) } else { DX_FETCH_(g.X[0]) } }         \
+    else { if (is_y) { DX_FETCH_(g.Y[1]) } else { DX_FETCH_(g.X[1]) } }                    \
+  }
+#define DX_FINISH_(V_)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+    Raw4 q_; q_.a = ra[i]; q_.b = rb[i];                                                   \
+    v_[i] = okp[i] ? view_finish4(V_, q_, scol) : z4_;                                     \
+  }
+#define DX_STORE_SLAB(buf_)                                                                \
+  {                                                                                        \
+    const f4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                   \
+    f4 v_[4];                                                                              \
+    if (staged_pair == 0) { if (is_y) { DX_FINISH_(g.Y[0]) } else { DX_FINISH_(g.X[0]) } } \
+    else { if (is_y) { DX_FINISH_(g.Y[1]) } else { DX_FINISH_(g.X[1]) } }                  \
+    if (want_colsum && !is_y && staged_pair == 0) {                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) { csum.x += v_[i].x; csum.y += v_[i].y; csum.z += v_[i].z; csum.w += v_[i].w; } \
+    }                                                                                      \
+    unsigned char* d_ = sdst + (buf_) * DX_BUF;                                            \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+      bf16x4 h1, h2, h3;                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) { __bf16 a_, b_, c_; dx_split3(v_[i][j], a_, b_, c_); h1[i] = a_; h2[i] = b_; h3[i] = c_; } \
+      *reinterpret_cast<bf16x4*>(d_ + j * DX_JREG) = h1;                                   \
+      *reinterpret_cast<bf16x4*>(d_ + DX_PLANE + j * DX_JREG) = h2;                        \
+      *reinterpret_cast<bf16x4*>(d_ + 2 * DX_PLANE + j * DX_JREG) = h3;                    \
+    }                                                                                      \
+  }
+
+  if (nslab > 0) {
+    DX_LOAD_SLAB(0)
+    DX_STORE_SLAB(0)
+  }
+  __syncthreads();
+  // operand fragment addresses of this lane: row / column (lane & 31) of each 32-wide tile, point half (lane >> 5)
+  const int ln = lane & 31, lh = lane >> 5;
+  const int xoff = lh * DX_HALF + (ln & 3) * DX_JREG + (wr * 16 + (ln >> 2)) * 16;              // + i * 8 * 16 per n-tile
+  const int yoff = DX_OPER + lh * DX_HALF + (ln & 3) * DX_JREG + (wc * 32 + (ln >> 2)) * 16;    // + j * 8 * 16 per k-tile
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) DX_LOAD_SLAB(s + 1)
+    const unsigned char* B_ = smem_d + buf * DX_BUF;
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(B_ + xoff + p * DX_PLANE + i * 128);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(B_ + yoff + p * DX_PLANE + j * 128);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    }
+    if (s + 1 < nslab) DX_STORE_SLAB(buf ^ 1)
+    __syncthreads();
+  }
+#undef DX_LOAD_SLAB
+#undef DX_STORE_SLAB
+#undef DX_FETCH_
+#undef DX_FINISH_
+
+  float* out = g.partial + chunk * (long)g.Npad * g.ldk;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = k0 + wc * 128 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < g.Npad && kk < g.ldk) out[(long)n * g.ldk + kk] = acc[i][j][r];
+      }
+    }
+  if (want_colsum) {   // bias gradient: the four point-quad owners of a column group add their sums in a fixed order
+    float* cs = reinterpret_cast<float*>(smem_d);          // [4 quads][256 columns]; the slab buffers are dead now
+    if (!is_y) *reinterpret_cast<f4*>(cs + q * 256 + c4 * 4) = csum;
+    __syncthreads();
+    if (tid < 256 && n0 + tid < g.Npad) g.colsum[chunk * g.Npad + n0 + tid] = ((cs[tid] + cs[256 + tid]) + cs[512 + tid]) + cs[768 + tid];
+  }
+}
+
+template <int XK0, int YK0, int XK1, int YK1>
+static void launch_dw_bx_t(const DwGemm& g, int n0, int k0, cnr_stream s) {
+  const size_t lds = (size_t)2 * DX_BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_bx_kernel<XK0, YK0, XK1, YK1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int tn_ = (g.N - n0) < 256 ? (g.N - n0) : 256, tk_ = (g.K - k0) < 256 ? (g.K - k0) : 256;
+  TimingScope ts_("dw_gemm_bx", 1, 4224, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
+  hipLaunchKernelGGL((dw_gemm_bx_kernel<XK0, YK0, XK1, YK1>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
+}
+
+static void launch_dw_bx(const DwGemm& g, int n0, int k0, cnr_stream s) {
+  const int x0 = g.X[0].kind, y0 = g.Y[0].kind, x1 = g.npairs > 1 ? g.X[1].kind : -1, y1 = g.npairs > 1 ? g.Y[1].kind : -1;
+#define DX_CASE(A_, B_, C_, D_) if (x0 == A_ && y0 == B_ && x1 == C_ && y1 == D_) { launch_dw_bx_t<A_, B_, C_, D_>(g, n0, k0, s); return; }
+  // the operand combinations of the render plan (cnr_plan.cpp): MLP layers, SDF value + gradient-chain pairs
+  DX_CASE(VK_DIRECT, VK_DIRECT, -1, -1)
+  DX_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL, VK_DIRECT)
+  DX_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL_ROW, VK_DIRECT)
+  DX_CASE(VK_DIRECT, VK_SOFTPLUS, VK_CONST_COL0, VK_DIRECT)
+#undef DX_CASE
+  launch_dw_bx_t<-1, -1, -1, -1>(g, n0, k0, s);
 }
 
 void be_dw_gemm(const DwGemm& g, cnr_stream s) {
   // tile the [Npad x ldk] output: 256x256 main tiles, 256x64 column tails, 32x256 row tails
+  static const bool dw_fp32 = getenv("CNR_DW_FP32") != nullptr;   // debugging aid: FP32-MFMA kernel for the main tiles too
   for (int n0 = 0; n0 < g.N; n0 += 256) {
     const int nrem = g.N - n0;
     for (int k0 = 0; k0 < g.K;) {
       const int krem = g.K - k0;
       if (nrem > 32) {
-        if (krem > 64) { launch_dw<4, 2, 2, 4>(g, n0, k0, s); k0 += 256; }
+        if (krem > 64) {
+          if (dw_fp32) launch_dw<4, 2, 2, 4>(g, n0, k0, s); else launch_dw_bx(g, n0, k0, s);
+          k0 += 256;
+        }
         else { launch_dw<8, 1, 1, 2>(g, n0, k0, s); k0 += 64; }
       } else {
         launch_dw<1, 8, 1, 1>(g, n0, k0, s); k0 += 256;

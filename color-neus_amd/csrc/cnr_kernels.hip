@@ -38,11 +38,11 @@ static hipEvent_t get_event() {
   (void)hipEventCreate(&e);
   return e;
 }
-void timing_begin(const char* name, int kind, int nt, long P, int N, int K, int pairs, hipStream_t s) {
+void timing_begin(const char* name, int kind, int nt, long P, int N, int K, int pairs, hipStream_t s, double bytes) {
   if (!g_timing_on) return;
   TimingRec r;
   snprintf(r.t.name, sizeof r.t.name, "%s", name);
-  r.t.kind = kind; r.t.nt = nt; r.t.P = P; r.t.N = N; r.t.K = K; r.t.pairs = pairs; r.t.ms = 0.f;
+  r.t.kind = kind; r.t.nt = nt; r.t.P = P; r.t.N = N; r.t.K = K; r.t.pairs = pairs; r.t.ms = 0.f; r.t.bytes = bytes;
   r.e0 = get_event(); r.e1 = get_event();
   (void)hipEventRecord(r.e0, s);
   g_timing.push_back(r);

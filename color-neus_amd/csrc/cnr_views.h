@@ -172,74 +172,112 @@ CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
 }
 
 // 4 consecutive accumulator columns (col % 4 == 0): 16-byte fast paths for the bandwidth-heavy kinds, element-wise otherwise
+// ---- 16-byte epilogue path, split into "is it applicable" / "side loads" / "math + stores" so that a kernel can issue the
+// side loads of several rows back to back (one memory round trip per tile instead of one per row group)
+struct EpiRaw4 { f4 a; f4 b; };
+
+// true when 4 consecutive columns starting at col (col % 4 == 0) take the 16-byte path; depends on the column only
+CNR_HD bool epi_fast4(const Epi& e, int col) {
+  if (!(col + 4 <= e.n_out && col + 4 <= e.split)) return false;
+  switch (e.kind) {
+    case EK_SDF_TOP: return (e.ld1 & 3) == 0 && e.o1 != nullptr;
+    case EK_SPLIT:
+    case EK_STORE: return ((e.ld1 | e.o1_off) & 3) == 0;
+    case EK_RELU: return (e.ld1 & 3) == 0;
+    case EK_SWEEP: return ((e.ld1 | e.ld2 | e.ldz | e.ldv) & 3) == 0 && e.o2 != nullptr;
+    case EK_VBACK: return ((e.ld1 | e.ldz) & 3) == 0;
+    case EK_RELU_MASK: return ((e.ld1 | e.ldaux) & 3) == 0;
+    default: return false;
+  }
+}
+// the per-row side inputs of the fast path (only valid when epi_fast4)
+CNR_HD EpiRaw4 epi_fetch4(const Epi& e, long row, int col) {
+  EpiRaw4 r;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  r.a = zero; r.b = zero;
+  switch (e.kind) {
+    case EK_SWEEP:
+      r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
+      r.b = e.ldv ? *reinterpret_cast<const f4*>(e.v + row * e.ldv + col) : *reinterpret_cast<const f4*>(e.v + col);
+      break;
+    case EK_VBACK:
+      r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
+      r.b = *reinterpret_cast<const f4*>(e.o1 + row * e.ld1 + col);
+      break;
+    case EK_RELU_MASK:
+      r.a = *reinterpret_cast<const f4*>(e.aux + row * e.ldaux + col);
+      break;
+    default: break;
+  }
+  return r;
+}
+// bias of 4 columns (zero when the epilogue has none)
+CNR_HD f4 epi_bias4(const Epi& e, int col) {
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  return e.bias ? *reinterpret_cast<const f4*>(e.bias + col) : zero;
+}
+CNR_HD void epi_finish4(const Epi& e, long row, int col, const f4& acc, const f4& b, const EpiRaw4& raw) {
+  switch (e.kind) {
+    case EK_SDF_TOP: {
+      f4 o;
+      o.x = acc.x + b.x; o.y = acc.y + b.y; o.z = acc.z + b.z; o.w = acc.w + b.w;
+      *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+    } break;
+    case EK_SPLIT:
+    case EK_STORE: {
+      f4 o;
+      o.x = (acc.x + b.x) * e.scale; o.y = (acc.y + b.y) * e.scale; o.z = (acc.z + b.z) * e.scale; o.w = (acc.w + b.w) * e.scale;
+      *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + e.o1_off + col) = o;
+    } break;
+    case EK_RELU: {
+      f4 o;
+      o.x = fmaxf(acc.x + b.x, 0.f); o.y = fmaxf(acc.y + b.y, 0.f); o.z = fmaxf(acc.z + b.z, 0.f); o.w = fmaxf(acc.w + b.w, 0.f);
+      *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+    } break;
+    case EK_SWEEP: {
+      const f4 zz = raw.a, vv = raw.b;
+      f4 o1, o2;
+      o1.x = softplus100_d2(zz.x) * (vv.x * e.vscale) * acc.x; o2.x = softplus100_d1(zz.x) * acc.x;
+      o1.y = softplus100_d2(zz.y) * (vv.y * e.vscale) * acc.y; o2.y = softplus100_d1(zz.y) * acc.y;
+      o1.z = softplus100_d2(zz.z) * (vv.z * e.vscale) * acc.z; o2.z = softplus100_d1(zz.z) * acc.z;
+      o1.w = softplus100_d2(zz.w) * (vv.w * e.vscale) * acc.w; o2.w = softplus100_d1(zz.w) * acc.w;
+      *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o1;
+      *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + col) = o2;
+    } break;
+    case EK_VBACK: {
+      const f4 zz = raw.a;
+      f4 o = raw.b;
+      o.x = softplus100_d1(zz.x) * (acc.x * e.scale) + o.x; o.y = softplus100_d1(zz.y) * (acc.y * e.scale) + o.y;
+      o.z = softplus100_d1(zz.z) * (acc.z * e.scale) + o.z; o.w = softplus100_d1(zz.w) * (acc.w * e.scale) + o.w;
+      *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+    } break;
+    case EK_RELU_MASK: {
+      const f4 m = raw.a;
+      f4 o;
+      o.x = m.x > 0.f ? acc.x : 0.f; o.y = m.y > 0.f ? acc.y : 0.f; o.z = m.z > 0.f ? acc.z : 0.f; o.w = m.w > 0.f ? acc.w : 0.f;
+      *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+    } break;
+    default: break;
+  }
+}
+
 CNR_HD void epi_apply4(const Epi& e, long row, int col, f4 acc) {
-  const bool interior = col + 4 <= e.n_out && col + 4 <= e.split;
-  if (interior) {
-    switch (e.kind) {
-      case EK_SDF_TOP:
-        if ((e.ld1 & 3) == 0 && e.o1) {
-          const f4 b = *reinterpret_cast<const f4*>(e.bias + col);
-          f4 o;
-          o.x = acc.x + b.x; o.y = acc.y + b.y; o.z = acc.z + b.z; o.w = acc.w + b.w;
-          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
-          return;
-        }
-        break;
-      case EK_SPLIT:
-      case EK_STORE:
-        if (((e.ld1 | e.o1_off) & 3) == 0) {
-          f4 b = {0.f, 0.f, 0.f, 0.f};
-          if (e.bias) b = *reinterpret_cast<const f4*>(e.bias + col);
-          f4 o;
-          o.x = (acc.x + b.x) * e.scale; o.y = (acc.y + b.y) * e.scale; o.z = (acc.z + b.z) * e.scale; o.w = (acc.w + b.w) * e.scale;
-          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + e.o1_off + col) = o;
-          return;
-        }
-        break;
-      case EK_RELU:
-        if ((e.ld1 & 3) == 0) {
-          const f4 b = *reinterpret_cast<const f4*>(e.bias + col);
-          f4 o;
-          o.x = fmaxf(acc.x + b.x, 0.f); o.y = fmaxf(acc.y + b.y, 0.f); o.z = fmaxf(acc.z + b.z, 0.f); o.w = fmaxf(acc.w + b.w, 0.f);
-          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
-          return;
-        }
-        break;
-      case EK_SWEEP:
-        if (((e.ld1 | e.ld2 | e.ldz | e.ldv) & 3) == 0 && e.o2) {
-          const f4 zz = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
-          f4 vv = e.ldv ? *reinterpret_cast<const f4*>(e.v + row * e.ldv + col) : *reinterpret_cast<const f4*>(e.v + col);
-          f4 o1, o2;
-          o1.x = softplus100_d2(zz.x) * (vv.x * e.vscale) * acc.x; o2.x = softplus100_d1(zz.x) * acc.x;
-          o1.y = softplus100_d2(zz.y) * (vv.y * e.vscale) * acc.y; o2.y = softplus100_d1(zz.y) * acc.y;
-          o1.z = softplus100_d2(zz.z) * (vv.z * e.vscale) * acc.z; o2.z = softplus100_d1(zz.z) * acc.z;
-          o1.w = softplus100_d2(zz.w) * (vv.w * e.vscale) * acc.w; o2.w = softplus100_d1(zz.w) * acc.w;
-          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o1;
-          *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + col) = o2;
-          return;
-        }
-        break;
-      case EK_VBACK:
-        if (((e.ld1 | e.ldz) & 3) == 0) {
-          const f4 zz = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
-          f4* p = reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col);
-          f4 o = *p;
-          o.x = softplus100_d1(zz.x) * (acc.x * e.scale) + o.x; o.y = softplus100_d1(zz.y) * (acc.y * e.scale) + o.y;
-          o.z = softplus100_d1(zz.z) * (acc.z * e.scale) + o.z; o.w = softplus100_d1(zz.w) * (acc.w * e.scale) + o.w;
-          *p = o;
-          return;
-        }
-        break;
-      case EK_RELU_MASK:
-        if (((e.ld1 | e.ldaux) & 3) == 0) {
-          const f4 m = *reinterpret_cast<const f4*>(e.aux + row * e.ldaux + col);
-          f4 o;
-          o.x = m.x > 0.f ? acc.x : 0.f; o.y = m.y > 0.f ? acc.y : 0.f; o.z = m.z > 0.f ? acc.z : 0.f; o.w = m.w > 0.f ? acc.w : 0.f;
-          *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
-          return;
-        }
-        break;
-      default: break;
+  if (epi_fast4(e, col)) {
+    epi_finish4(e, row, col, acc, epi_bias4(e, col), epi_fetch4(e, row, col));
+    return;
+  }
+  if (col >= e.n_out && e.tail_src && col + 4 <= e.n_out + e.tail_n) {   // tail fill: 4 scalar reads (source is unaligned), one 16-byte store
+    const float* t = e.tail_src + row * e.ld_tail + (col - e.n_out);
+    const f4 tv = {t[0], t[1], t[2], t[3]};
+    if (e.kind == EK_STORE && ((e.ld1 | e.o1_off) & 3) == 0) {
+      *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + e.o1_off + col) = tv;
+      return;
+    }
+    if (e.kind == EK_SWEEP && ((e.ld1 | e.ld2) & 3) == 0 && e.o2) {
+      const f4 zero = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + col) = tv;
+      *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = zero;
+      return;
     }
   }
   epi_apply(e, row, col, acc.x);
@@ -277,5 +315,41 @@ struct DwGemm {
   int Npad = 0, ldk = 0;
   float* colsum = nullptr;    // optional [nchunk][Npad]: column sums of X[0] (bias gradient)
 };
+
+// Algorithmic HBM bytes of one launch: every operand matrix read once, every output written once (weights and bias are
+// noise at these sizes and are left out).  Used only for the roofline figures of the timing records.
+inline double view_bytes(const View& v, long P, int K) {
+  switch (v.kind) {
+    case VK_SIGMUL: return 8.0 * (double)P * K;
+    case VK_CONST_COL0: return 0.0;
+    default: return 4.0 * (double)P * K;
+  }
+}
+inline double layer_gemm_bytes(const LayerGemm& g) {
+  const Epi& e = g.E;
+  const double P = (double)g.P;
+  const int lo = g.col0, hi = g.col0 + g.N;                     // output column range of this launch
+  auto span = [&](int a, int b) { int x = a > lo ? a : lo, y = b < hi ? b : hi; return y > x ? (double)(y - x) : 0.0; };
+  const double n = span(0, e.n_out), nlo = span(0, e.split < e.n_out ? e.split : e.n_out), nhi = n - nlo;
+  const double tail = e.tail_src ? span(e.n_out, e.n_out + e.tail_n) : 0.0;
+  double b = view_bytes(g.A, g.P, g.K);
+  switch (e.kind) {
+    case EK_STORE: b += 4 * P * (n + 2 * tail); break;
+    case EK_SPLIT: b += 4 * P * (nlo + (e.o2 ? nhi : 0.0)); break;
+    case EK_SDF_TOP: b += 4 * P * ((e.o1 ? nlo : 0.0) + nhi); break;
+    case EK_RELU: b += 4 * P * n; break;
+    case EK_SIGMOID: case EK_LINEAR_SIG: b += 4 * P * n * (e.o2 ? 2 : 1); break;
+    case EK_RELIGHT_TOP: b += 4 * P * n * 3; break;
+    case EK_SWEEP: b += 4 * P * (n * (e.ldv ? 4 : 3) + 2 * tail); break;
+    case EK_VBACK: b += 4 * P * (3 * nlo + nhi); break;
+    case EK_RELU_MASK: b += 4 * P * (2 * nlo + (e.o2 ? nhi : 0.0)); break;
+  }
+  return b;
+}
+inline double dw_gemm_bytes(const DwGemm& g, int n, int k) {
+  double b = 0;
+  for (int i = 0; i < g.npairs; ++i) b += view_bytes(g.X[i], g.P, n) + view_bytes(g.Y[i], g.P, k);
+  return b + 4.0 * g.nchunk * (double)n * k;
+}
 
 }  // namespace cnr

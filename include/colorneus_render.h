@@ -97,6 +97,7 @@ typedef struct cnr_kernel_timing {
   long P;           /* points (rows) or rays */
   int32_t N, K, pairs;
   float ms;
+  double bytes;     /* algorithmic HBM bytes of the launch (operands read once + outputs written once); 0 = not modelled */
 } cnr_kernel_timing;
 void cnr_timing_enable(int on);
 int cnr_timing_collect(cnr_kernel_timing* out, int max_records);

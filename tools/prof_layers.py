@@ -20,10 +20,10 @@ def step():
 for _ in range(2): step()
 torch.cuda.synchronize()
 lib.timing_enable(True); step(); torch.cuda.synchronize(); recs = lib.timing_collect(); lib.timing_enable(False)
-tot = sum(x[-1] for x in recs)
+tot = sum(x[7] for x in recs)
 print("total kernel ms %.2f over %d launches" % (tot, len(recs)))
 if os.environ.get("CNR_BRIEF"):
     recs = []
-for i, (name, kind, nt, P, N, K, pairs, ms) in enumerate(recs):
+for i, (name, kind, nt, P, N, K, pairs, ms, nb) in enumerate(recs):
     fl = 2.0 * P * N * K * max(pairs, 1) if kind != 2 else 0
-    print("%3d %-16s nt=%-5d P=%-8d N=%-4d K=%-4d pairs=%d  %8.3f ms  %6.1f TF/s" % (i, name, nt, P, N, K, pairs, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
+    print("%3d %-16s nt=%-5d P=%-8d N=%-4d K=%-4d pairs=%d  %8.3f ms  %6.1f TF/s %7.1f GB/s" % (i, name, nt, P, N, K, pairs, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0, nb / (ms * 1e-3) / 1e9 if ms > 0 else 0))
