@@ -198,11 +198,13 @@ __device__ __forceinline__ void ws_put4(const f4& v, float sc, unsigned char* ds
 
 // VK / EK >= 0 pin the view / epilogue kind at compile time: the interpreted switches of cnr_views.h fold away and each
 // instantiation only allocates the registers its own prologue and epilogue need (-1 = generic, interpreted at run time).
-template <int VK, int EK>
+// PLAIN promises an epilogue without tail fill and without a split point (most launches): that code folds away as well.
+template <int VK, int EK, bool PLAIN>
 __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const LayerGemm g_in, int tiles_per_wg, int wrows) {
   LayerGemm g = g_in;
   if (VK >= 0) g.A.kind = VK;
   if (EK >= 0) g.E.kind = EK;
+  if (PLAIN) { g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30; }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long Pn = g.P_dev ? (long)*g.P_dev : g.P;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * WS_TLD + cl] = acc[r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      constexpr int EG = (EK == EK_SWEEP) ? 2 : 4;   // row groups whose side inputs are in flight together (register budget)
+      constexpr int EG = (EK == EK_SWEEP || EK == EK_VBACK) ? 2 : 4;   // row groups whose side inputs are in flight together (register budget)
 #pragma unroll
       for (int i0 = 0; i0 < 4; i0 += EG) {
         EpiRaw4 er[EG];
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
 #undef WS_MFMA
 }
 
-template <int VK, int EK>
+template <int VK, int EK, bool PLAIN>
 static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
   const int nkb = (g.K + 15) / 16;
   const int abuf = 2 * WS_TP * (nkb * 32 + 16) + 128;
@@ -352,24 +354,30 @@ static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
-  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
+  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
 }
 
 static void launch_layer_gemm_ws(const LayerGemm& g, int wrows, cnr_stream s) {
   static const bool generic_only = getenv("CNR_WS_GENERIC") != nullptr;   // debugging aid: interpreted kernel for every combination
   const int vk = g.A.kind, ek = g.E.kind;
-#define WS_CASE(V_, E_) if (!generic_only && vk == V_ && ek == E_) { launch_ws_t<V_, E_>(g, wrows, s); return; }
+  const bool plain = g.E.tail_src == nullptr && g.E.split == (1 << 30);
+#define WS_CASE(V_, E_)                                              \
+  if (!generic_only && vk == V_ && ek == E_) {                       \
+    if (plain) launch_ws_t<V_, E_, true>(g, wrows, s);               \
+    else launch_ws_t<V_, E_, false>(g, wrows, s);                    \
+    return;                                                          \
+  }
   // the combinations the render plan issues on 256-wide layers (cnr_plan.cpp)
   WS_CASE(VK_SOFTPLUS, EK_STORE) WS_CASE(VK_DIRECT, EK_STORE) WS_CASE(VK_SOFTPLUS, EK_SDF_TOP)
   WS_CASE(VK_SIGMUL, EK_STORE) WS_CASE(VK_SIGMUL_ROW, EK_STORE) WS_CASE(VK_SIGMUL, EK_SPLIT)
   WS_CASE(VK_DIRECT, EK_RELU) WS_CASE(VK_DIRECT, EK_RELU_MASK) WS_CASE(VK_DIRECT, EK_SPLIT)
   WS_CASE(VK_DIRECT, EK_SWEEP) WS_CASE(VK_DIRECT, EK_VBACK)
 #undef WS_CASE
-  launch_ws_t<-1, -1>(g, wrows, s);
+  launch_ws_t<-1, -1, false>(g, wrows, s);
 }
 
 static void dispatch_layer_gemm(const LayerGemm& g, int nt, cnr_stream s) {
@@ -410,11 +418,13 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
 // weight-gradient GEMM:  dW[n][k] = sum_pt X[pt][n] * Y[pt][k]
 // 8 waves as WR x WC, each wave (MT*32) x (KT*32); block tile TN x TK; points streamed 16 at a time.
 // ================================================================================================
-constexpr int DW_BP = 16;
+// points per slab: 16 for the square tile; the skinny tail tiles are latency-bound streams, so they take 32 at a time
+constexpr int dw_bp(int tn, int tk) { return tn + tk <= 320 ? 32 : 16; }
 
 template <int WR, int WC, int MT, int KT>
 __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, int k0) {
   constexpr int TN = WR * MT * 32, TK = WC * KT * 32;
+  constexpr int DW_BP = dw_bp(TN, TK);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                       // [2][16][TN]
   float* Ys = smem + 2 * DW_BP * TN;      // [2][16][TK]
@@ -545,6 +555,7 @@ __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, in
 template <int WR, int WC, int MT, int KT>
 static void launch_dw(const DwGemm& g, int n0, int k0, cnr_stream s) {
   constexpr int TN = WR * MT * 32, TK = WC * KT * 32;
+  constexpr int DW_BP = dw_bp(TN, TK);
   const size_t lds = (size_t)(2 * DW_BP * (TN + TK)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

@@ -435,6 +435,13 @@ static void run_sampler(const Model& m, const cnr_render_inputs* in, float* z, C
 }
 
 // analytic gradient chain: cotangent of `sdf` pushed down through the layers
+// The cotangents of the skip-connection embedding leave the split epilogues through o2 at column offset split % 4, which makes
+// their 16-byte stores aligned; every reader of those buffers (CES, ebars) adds the same offset.
+static int skip_off(const Model& m) {
+  for (int l = 1; l < m.L; ++l) if (m.skip(l)) return m.sdf[l - 1].n & 3;
+  return 0;
+}
+
 static void sdf_grad_chain(const Model& m, long P, const float* E, const float* const* Z, float* const* V, float* CE0, float* CES,
                            cnr_stream s) {
   const float inv_scale = 1.0f / m.c.sdf_scale;
@@ -449,7 +456,7 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
       g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = CE0; g.E.ld1 = kEmb;
     } else if (m.skip(l)) {
       g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n;
-      g.E.o1 = V[l - 1]; g.E.ld1 = m.Hs; g.E.o2 = CES; g.E.ld2 = kEmb;
+      g.E.o1 = V[l - 1]; g.E.ld1 = m.Hs; g.E.o2 = CES; g.E.ld2 = kEmb; g.E.o2_off = skip_off(m);
     } else {
       g.E.kind = EK_STORE; g.E.n_out = q.k_int; g.E.o1 = V[l - 1]; g.E.ld1 = m.Hs;
     }
@@ -558,7 +565,7 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   sdf_grad_chain(m, P, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s);
   GradFinish gf;
   gf.featx = x.featx; gf.ldfx = x.ldfx; gf.F = m.F;
-  gf.P = P; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
+  gf.P = P; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES + skip_off(m) : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
   gf.grad_out = out->gradients; gf.AUX = x.AUX; gf.neg_g_as_view = 0; gf.multires_view = m.mv;
   be_grad_finish(gf, s);
   CompositeFwd cf;
@@ -755,7 +762,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     else { g.A.kind = VK_DIRECT; g.A.a = b.Z2[l]; g.A.lda = m.Hs; }
     g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
     g.E.kind = EK_VBACK; g.E.n_out = q.k_int; g.E.z = x.Z[l - 1]; g.E.ldz = m.Hs; g.E.o1 = b.Z2[l - 1]; g.E.ld1 = m.Hs;
-    if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; }
+    if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; g.E.o2_off = skip_off(m); }
     be_layer_gemm(g, s);
   }
   if (rays_grad) {
@@ -788,8 +795,8 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   // ---- 8. d rays (camera refinement configs)
   if (rays_grad) {
     PbarFinish pf;
-    pf.P = P; pf.daux_c = b.dAUXc; pf.daux_r = m.has_relight ? b.dAUXr : nullptr; pf.ebar0 = b.ebar0; pf.ebars = skipnet ? b.ebars : nullptr;
-    pf.E = x.E; pf.ce0 = x.CE0; pf.ces = skipnet ? x.CES : nullptr; pf.gbar_total = b.gbar_t; pf.scale = scale;
+    pf.P = P; pf.daux_c = b.dAUXc; pf.daux_r = m.has_relight ? b.dAUXr : nullptr; pf.ebar0 = b.ebar0; pf.ebars = skipnet ? b.ebars + skip_off(m) : nullptr;
+    pf.E = x.E; pf.ce0 = x.CE0; pf.ces = skipnet ? x.CES + skip_off(m) : nullptr; pf.gbar_total = b.gbar_t; pf.scale = scale;
     pf.multires = m.c.sdf_multires; pf.pbar = b.pbar;
     be_pbar_finish(pf, s);
     RaysGradFinish rg;
@@ -995,7 +1002,7 @@ int cnr_vertex_color(const cnr_config* cfg, const float* const* params, const fl
     sdf_chain(m, cnt, x.E, x.Z.data(), x.sdf, x.featx, x.ldfx, 1.0f / scale, s);
     sdf_grad_chain(m, cnt, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s);
     GradFinish gf;
-    gf.P = cnt; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
+    gf.P = cnt; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES + skip_off(m) : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
     gf.grad_out = x.relit; gf.AUX = x.AUX; gf.neg_g_as_view = (m.c.col_mode != 1) ? 1 : 0; gf.multires_view = m.mv;
     gf.featx = x.featx; gf.ldfx = x.ldfx; gf.F = m.F;
     be_grad_finish(gf, s);

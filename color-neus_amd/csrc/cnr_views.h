@@ -126,7 +126,7 @@ CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
       float b = e.bias ? e.bias[col] : 0.0f;
       float v = (acc + b) * e.scale;
       if (col < e.split) e.o1[row * e.ld1 + e.o1_off + col] = v;
-      else if (e.o2) e.o2[row * e.ld2 + (col - e.split)] = v;
+      else if (e.o2) e.o2[row * e.ld2 + (col - e.split) + e.o2_off] = v;
     } break;
     case EK_SDF_TOP: {
       float v = acc + e.bias[col];
@@ -161,7 +161,7 @@ CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
         float* p = e.o1 + row * e.ld1 + col;
         *p = softplus100_d1(e.z[row * e.ldz + col]) * h + *p;
       } else if (e.o2) {
-        e.o2[row * e.ld2 + (col - e.split)] = h;
+        e.o2[row * e.ld2 + (col - e.split) + e.o2_off] = h;
       }
     } break;
     default: {  // EK_RELU_MASK
@@ -178,7 +178,13 @@ struct EpiRaw4 { f4 a; f4 b; };
 
 // true when 4 consecutive columns starting at col (col % 4 == 0) take the 16-byte path; depends on the column only
 CNR_HD bool epi_fast4(const Epi& e, int col) {
-  if (!(col + 4 <= e.n_out && col + 4 <= e.split)) return false;
+  // groups that straddle n_out or lie in the tail-fill range stay on this path too (EK_STORE / EK_SWEEP with a tail source)
+  const bool tail_ok = e.tail_src != nullptr && (e.kind == EK_STORE || e.kind == EK_SWEEP) && col + 4 <= e.n_out + e.tail_n;
+  // EK_SPLIT / EK_VBACK groups at or beyond the split point: the o2 columns land 16-byte aligned when o2_off == split % 4
+  // (the consumer reads o2 + o2_off); a straddling EK_SPLIT group also writes its beyond-split values into the pad columns of o1
+  const bool split_ok = (e.kind == EK_SPLIT || e.kind == EK_VBACK) && ((e.o2_off - e.split) & 3) == 0 && (e.ld2 & 3) == 0 &&
+                        (e.kind == EK_VBACK || e.o1_off == 0);
+  if (!((col + 4 <= e.n_out || tail_ok) && (col + 4 <= e.split || split_ok))) return false;
   switch (e.kind) {
     case EK_SDF_TOP: return (e.ld1 & 3) == 0 && e.o1 != nullptr;
     case EK_SPLIT:
@@ -201,8 +207,10 @@ CNR_HD EpiRaw4 epi_fetch4(const Epi& e, long row, int col) {
       r.b = e.ldv ? *reinterpret_cast<const f4*>(e.v + row * e.ldv + col) : *reinterpret_cast<const f4*>(e.v + col);
       break;
     case EK_VBACK:
-      r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
-      r.b = *reinterpret_cast<const f4*>(e.o1 + row * e.ld1 + col);
+      if (col < e.split) {
+        r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
+        r.b = *reinterpret_cast<const f4*>(e.o1 + row * e.ld1 + col);
+      }
       break;
     case EK_RELU_MASK:
       r.a = *reinterpret_cast<const f4*>(e.aux + row * e.ldaux + col);
@@ -213,8 +221,14 @@ CNR_HD EpiRaw4 epi_fetch4(const Epi& e, long row, int col) {
 }
 // bias of 4 columns (zero when the epilogue has none)
 CNR_HD f4 epi_bias4(const Epi& e, int col) {
-  const f4 zero = {0.f, 0.f, 0.f, 0.f};
-  return e.bias ? *reinterpret_cast<const f4*>(e.bias + col) : zero;
+  f4 b = {0.f, 0.f, 0.f, 0.f};
+  if (!e.bias) return b;
+  if (col + 4 <= e.n_out) return *reinterpret_cast<const f4*>(e.bias + col);
+  if (col < e.n_out) b.x = e.bias[col];
+  if (col + 1 < e.n_out) b.y = e.bias[col + 1];
+  if (col + 2 < e.n_out) b.z = e.bias[col + 2];
+  if (col + 3 < e.n_out) b.w = e.bias[col + 3];
+  return b;
 }
 CNR_HD void epi_finish4(const Epi& e, long row, int col, const f4& acc, const f4& b, const EpiRaw4& raw) {
   switch (e.kind) {
@@ -223,10 +237,22 @@ CNR_HD void epi_finish4(const Epi& e, long row, int col, const f4& acc, const f4
       o.x = acc.x + b.x; o.y = acc.y + b.y; o.z = acc.z + b.z; o.w = acc.w + b.w;
       *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
     } break;
-    case EK_SPLIT:
+    case EK_SPLIT: {
+      f4 o;
+      o.x = (acc.x + b.x) * e.scale; o.y = (acc.y + b.y) * e.scale; o.z = (acc.z + b.z) * e.scale; o.w = (acc.w + b.w) * e.scale;
+      if (col < e.split) *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + e.o1_off + col) = o;
+      if (col + 4 > e.split && e.o2) *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + (col - e.split) + e.o2_off) = o;
+    } break;
     case EK_STORE: {
       f4 o;
       o.x = (acc.x + b.x) * e.scale; o.y = (acc.y + b.y) * e.scale; o.z = (acc.z + b.z) * e.scale; o.w = (acc.w + b.w) * e.scale;
+      if (e.tail_src && col + 4 > e.n_out) {   // tail-fill columns (only the launches that materialise a skip concat have them)
+        const float* t = e.tail_src + row * e.ld_tail - e.n_out;
+        if (col >= e.n_out) o.x = t[col];
+        if (col + 1 >= e.n_out) o.y = t[col + 1];
+        if (col + 2 >= e.n_out) o.z = t[col + 2];
+        if (col + 3 >= e.n_out) o.w = t[col + 3];
+      }
       *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + e.o1_off + col) = o;
     } break;
     case EK_RELU: {
@@ -241,15 +267,29 @@ CNR_HD void epi_finish4(const Epi& e, long row, int col, const f4& acc, const f4
       o1.y = softplus100_d2(zz.y) * (vv.y * e.vscale) * acc.y; o2.y = softplus100_d1(zz.y) * acc.y;
       o1.z = softplus100_d2(zz.z) * (vv.z * e.vscale) * acc.z; o2.z = softplus100_d1(zz.z) * acc.z;
       o1.w = softplus100_d2(zz.w) * (vv.w * e.vscale) * acc.w; o2.w = softplus100_d1(zz.w) * acc.w;
+      if (e.tail_src && col + 4 > e.n_out) {
+        const float* t = e.tail_src + row * e.ld_tail - e.n_out;
+        if (col >= e.n_out) { o1.x = 0.f; o2.x = t[col]; }
+        if (col + 1 >= e.n_out) { o1.y = 0.f; o2.y = t[col + 1]; }
+        if (col + 2 >= e.n_out) { o1.z = 0.f; o2.z = t[col + 2]; }
+        if (col + 3 >= e.n_out) { o1.w = 0.f; o2.w = t[col + 3]; }
+      }
       *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o1;
       *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + col) = o2;
     } break;
     case EK_VBACK: {
-      const f4 zz = raw.a;
-      f4 o = raw.b;
-      o.x = softplus100_d1(zz.x) * (acc.x * e.scale) + o.x; o.y = softplus100_d1(zz.y) * (acc.y * e.scale) + o.y;
-      o.z = softplus100_d1(zz.z) * (acc.z * e.scale) + o.z; o.w = softplus100_d1(zz.w) * (acc.w * e.scale) + o.w;
-      *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+      f4 h;
+      h.x = acc.x * e.scale; h.y = acc.y * e.scale; h.z = acc.z * e.scale; h.w = acc.w * e.scale;
+      if (col < e.split) {
+        const f4 zz = raw.a;
+        f4 o = raw.b;
+        o.x = softplus100_d1(zz.x) * h.x + o.x;
+        if (col + 1 < e.split) o.y = softplus100_d1(zz.y) * h.y + o.y;
+        if (col + 2 < e.split) o.z = softplus100_d1(zz.z) * h.z + o.z;
+        if (col + 3 < e.split) o.w = softplus100_d1(zz.w) * h.w + o.w;
+        *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+      }
+      if (col + 4 > e.split && e.o2) *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + (col - e.split) + e.o2_off) = h;
     } break;
     case EK_RELU_MASK: {
       const f4 m = raw.a;
