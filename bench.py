@@ -177,7 +177,13 @@ def main():
             # point: at the f16x3 matrix rate (~830 TFLOP/s fp32-equivalent) the launch is bound by HBM, not by the MFMA pipe
             roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "fp32_equiv_tflops": round(tfl, 2)}
-        roof.update({"kernel": desc, "traffic": None, "avg_launch_ms": round(dom[0] / dom[2], 4),
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed summary
+        # of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_%drays.json" % R)
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile))["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+        roof.update({"kernel": desc, "traffic": traffic, "traffic_source": os.path.relpath(tfile, ROOT) if traffic else None, "avg_launch_ms": round(dom[0] / dom[2], 4),
                      "algorithmic_bytes_per_launch": round(dom[3] / dom[2]), "launches_per_step": dom[2] // nrep,
                      "share_of_kernel_time": round(dom[0] / tot_ms, 3)})
         result["roofline"] = roof

@@ -677,9 +677,14 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_bx_kernel(const DwGemm g_in, i
     }                                                                                      \
   }
 
+  // The X-staging waves (0..3) and the Y-staging waves (4..7) share the SIMDs pairwise and run half an iteration out of
+  // phase: while one wave of a SIMD issues its MFMAs, the other converts and stores its part of the next slab, so the
+  // matrix pipe and the VALU / LDS-store path overlap.  X waves: load(s+1) | MFMA(s) | store(s+1);  Y waves: store(s+1),
+  // load(s+2) | MFMA(s).  One barrier per slab.
   if (nslab > 0) {
     DX_LOAD_SLAB(0)
     DX_STORE_SLAB(0)
+    if (is_y && nslab > 1) DX_LOAD_SLAB(1)
   }
   __syncthreads();
   // operand fragment addresses of this lane: row / column (lane & 31) of each 32-wide tile, point half (lane >> 5)
@@ -688,7 +693,12 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_bx_kernel(const DwGemm g_in, i
   const int yoff = DX_OPER + lh * DX_HALF + (ln & 3) * DX_JREG + (wc * 32 + (ln >> 2)) * 16;    // + j * 8 * 16 per k-tile
   for (int s = 0; s < nslab; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nslab) DX_LOAD_SLAB(s + 1)
+    if (!is_y) {
+      if (s + 1 < nslab) DX_LOAD_SLAB(s + 1)
+    } else if (s + 1 < nslab) {
+      DX_STORE_SLAB(buf ^ 1)
+      if (s + 2 < nslab) DX_LOAD_SLAB(s + 2)
+    }
     const unsigned char* B_ = smem_d + buf * DX_BUF;
     bf16x8 a[2][3];
 #pragma unroll
@@ -700,19 +710,23 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_bx_kernel(const DwGemm g_in, i
       bf16x8 b[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(B_ + yoff + p * DX_PLANE + j * 128);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f32x16 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+      // the two row tiles alternate so that back-to-back MFMAs never depend on each other
+      f32x16 c0 = acc[0][j], c1 = acc[1][j];
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b[2], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b[2], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b[0], c1, 0, 0, 0);
+      acc[0][j] = c0; acc[1][j] = c1;
     }
-    if (s + 1 < nslab) DX_STORE_SLAB(buf ^ 1)
+    if (!is_y && s + 1 < nslab) DX_STORE_SLAB(buf ^ 1)
     __syncthreads();
   }
 #undef DX_LOAD_SLAB
