@@ -199,8 +199,10 @@ __device__ __forceinline__ void ws_put4(const f4& v, float sc, unsigned char* ds
 // VK / EK >= 0 pin the view / epilogue kind at compile time: the interpreted switches of cnr_views.h fold away and each
 // instantiation only allocates the registers its own prologue and epilogue need (-1 = generic, interpreted at run time).
 // PLAIN promises an epilogue without tail fill and without a split point (most launches): that code folds away as well.
-template <int VK, int EK, bool PLAIN>
+// K17 admits a 17th k16 block (K up to 272: the layers whose input is a 256-wide hidden vector plus a few concatenated columns).
+template <int VK, int EK, bool PLAIN, bool K17 = false>
 __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const LayerGemm g_in, int tiles_per_wg, int wrows) {
+  constexpr int NKB = K17 ? 17 : 16;
   LayerGemm g = g_in;
   if (VK >= 0) g.A.kind = VK;
   if (EK >= 0) g.E.kind = EK;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   if (t0 >= ntiles) return;
   long t1 = t0 + tiles_per_wg;
   if (t1 > ntiles) t1 = ntiles;
-  const int nkb = (g.K + 15) >> 4;              // 1..16 k16 blocks
+  const int nkb = (g.K + 15) >> 4;              // 1..NKB k16 blocks
   const int kpad = nkb * 16;
   const int ald = kpad * 2 + 16;                // bytes per LDS row of one plane (+16: conflict-free ds_read_b128)
   const int aplane = WS_TP * ald;
@@ -224,11 +226,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   const int ncols_live = g.E.n_out + (g.E.tail_src ? g.E.tail_n : 0);
 
   // ---- resident weights (two f16 planes of this wave's 32 rows of W)
-  f16x8 w1[16], w2[16];
+  f16x8 w1[NKB], w2[NKB];
   {
     const unsigned short* wp = g.Wp + (long)(has_w ? c0 + (lane & 31) : 0) * g.ldw + (lane >> 5) * 8;
 #pragma unroll
-    for (int kb = 0; kb < 16; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
       if (kb < nkb) {
         w1[kb] = *reinterpret_cast<const f16x8*>(wp + kb * 16);
         w2[kb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 16);
@@ -245,9 +247,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   // ---- staging map: 16 threads per row, 4 consecutive columns each, up to 4 passes of 64 columns
   const int srow = tid >> 4, scol = (tid & 15) * 4;
   const bool pv0 = scol < kpad, pv1 = 64 + scol < kpad, pv2 = 128 + scol < kpad, pv3 = 192 + scol < kpad;
-  Raw4 r0, r1, r2, r3;
+  const bool pv4 = K17 && 256 + scol < kpad;   // 17th block: 4 of the 16 threads of a row
+  Raw4 r0, r1, r2, r3, r4;
   const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-  r0.a = z4; r0.b = z4; r1 = r0; r2 = r0; r3 = r0;
+  r0.a = z4; r0.b = z4; r1 = r0; r2 = r0; r3 = r0; r4 = r0;
 #define WS_FETCH_TILE(tile_)                                                      \
   {                                                                               \
     long row_ = (tile_) * WS_TP + srow; if (row_ >= Pn) row_ = Pn - 1;            \
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     if (pv1) r1 = view_fetch4(g.A, row_, 64 + scol);                              \
     if (pv2) r2 = view_fetch4(g.A, row_, 128 + scol);                             \
     if (pv3) r3 = view_fetch4(g.A, row_, 192 + scol);                             \
+    if (K17 && pv4) r4 = view_fetch4(g.A, row_, 256 + scol);                      \
   }
 #define WS_PUT_TILE(buf_)                                                         \
   {                                                                               \
@@ -262,7 +266,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     const f4 v1 = pv1 ? view_finish4(g.A, r1, 64 + scol) : z4;                    \
     const f4 v2 = pv2 ? view_finish4(g.A, r2, 128 + scol) : z4;                   \
     const f4 v3 = pv3 ? view_finish4(g.A, r3, 192 + scol) : z4;                   \
-    float mx = fmaxf(fmaxf(ws_absmax4(v0), ws_absmax4(v1)), fmaxf(ws_absmax4(v2), ws_absmax4(v3))); \
+    const f4 v4 = (K17 && pv4) ? view_finish4(g.A, r4, 256 + scol) : z4;          \
+    float mx = fmaxf(fmaxf(fmaxf(ws_absmax4(v0), ws_absmax4(v1)), fmaxf(ws_absmax4(v2), ws_absmax4(v3))), ws_absmax4(v4)); \
     _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16)); \
     float sc = 1.0f;                                                              \
     if (mx > 0.0f && mx < 3.0e38f) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); } /* 2^e_ clamp: subnormal rows must not overflow the scale */ \
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     if (pv1) ws_put4(v1, sc, dst + 128, aplane);                                  \
     if (pv2) ws_put4(v2, sc, dst + 256, aplane);                                  \
     if (pv3) ws_put4(v3, sc, dst + 384, aplane);                                  \
+    if (K17 && pv4) ws_put4(v4, sc, dst + 512, aplane);                           \
     if ((tid & 15) == 0) reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
   }
 #define WS_MFMA(kb_)                                                                               \
@@ -282,14 +288,25 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb_], acc, 0, 0, 0);                       \
   }
 
+  // Waves 0..3 (rows 0..15 of a tile) and waves 4..7 (rows 16..31) share the SIMDs pairwise and run half an iteration out of
+  // phase: the late group converts + stores its half of tile t+1 (fetched one iteration earlier) and fetches tile t+2 BEFORE
+  // its MFMAs of tile t, the early group fetches tile t+1 before and stores it after -- so one wave of each SIMD is in the
+  // matrix pipe while the other does prologue math / LDS stores / epilogue.  One barrier per tile.
+  const bool late = wave >= 4;
   WS_FETCH_TILE(t0)
   WS_PUT_TILE(0)
+  if (late && t0 + 1 < t1) WS_FETCH_TILE(t0 + 1)
   __syncthreads();
 
   for (long t = t0; t < t1; ++t) {
     const int buf = (int)((t - t0) & 1);
     const bool more = t + 1 < t1;
-    if (more) WS_FETCH_TILE(t + 1)
+    if (!late) {
+      if (more) WS_FETCH_TILE(t + 1)
+    } else if (more) {
+      WS_PUT_TILE(buf ^ 1)
+      if (t + 2 < t1) WS_FETCH_TILE(t + 2)
+    }
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -297,6 +314,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     if (has_w) {
       WS_MFMA(0) WS_MFMA(1) WS_MFMA(2) WS_MFMA(3) WS_MFMA(4) WS_MFMA(5) WS_MFMA(6) WS_MFMA(7)
       WS_MFMA(8) WS_MFMA(9) WS_MFMA(10) WS_MFMA(11) WS_MFMA(12) WS_MFMA(13) WS_MFMA(14) WS_MFMA(15)
+      if (K17) { WS_MFMA(NKB - 1) }
     }
     // epilogue of this 32 x 32 tile: undo the exact row / column scales, then the fused epilogue on 4 columns per lane.
     // The side inputs of all four row groups are requested first: one memory round trip per tile, and no load has to
@@ -334,7 +352,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    if (more) WS_PUT_TILE(buf ^ 1)
+    if (!late && more) WS_PUT_TILE(buf ^ 1)
     __syncthreads();
   }
 #undef WS_FETCH_TILE
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
 #undef WS_MFMA
 }
 
-template <int VK, int EK, bool PLAIN>
+template <int VK, int EK, bool PLAIN, bool K17 = false>
 static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
   const int nkb = (g.K + 15) / 16;
   const int abuf = 2 * WS_TP * (nkb * 32 + 16) + 128;
@@ -354,17 +372,28 @@ static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN, K17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
-  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
+  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN, K17>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
+}
+
+// K in (256, 272]: only the combinations the plan needs are instantiated with the 17th k-block
+static bool ws_k17_supported(const LayerGemm& g) {
+  const bool plain = g.E.tail_src == nullptr && g.E.split == (1 << 30);
+  return plain && g.A.kind == VK_DIRECT && (g.E.kind == EK_RELU || g.E.kind == EK_VBACK);
 }
 
 static void launch_layer_gemm_ws(const LayerGemm& g, int wrows, cnr_stream s) {
   static const bool generic_only = getenv("CNR_WS_GENERIC") != nullptr;   // debugging aid: interpreted kernel for every combination
   const int vk = g.A.kind, ek = g.E.kind;
   const bool plain = g.E.tail_src == nullptr && g.E.split == (1 << 30);
+  if (g.K > 256) {
+    if (ek == EK_RELU) launch_ws_t<VK_DIRECT, EK_RELU, true, true>(g, wrows, s);
+    else launch_ws_t<VK_DIRECT, EK_VBACK, true, true>(g, wrows, s);
+    return;
+  }
 #define WS_CASE(V_, E_)                                              \
   if (!generic_only && vk == V_ && ek == E_) {                       \
     if (plain) launch_ws_t<V_, E_, true>(g, wrows, s);               \
@@ -408,7 +437,8 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
     part.col0 = c0;
     const int w = ncols - c0 < 256 ? ncols - c0 : 256;
     part.N = w;   // (only used for the timing record; the kernel takes its extents from K, P and the epilogue)
-    if (!ws_off && ((ws_kinds >> g.E.kind) & 1) && g.Wp != nullptr && g.wscale != nullptr && w >= 96 && g.K <= 256 && (g.A.lda & 3) == 0) launch_layer_gemm_ws(part, round_up(g.N, 32), s);
+    const bool k_ok = g.K <= 256 || (g.K <= 272 && ws_k17_supported(g));
+    if (!ws_off && ((ws_kinds >> g.E.kind) & 1) && g.Wp != nullptr && g.wscale != nullptr && w >= 96 && k_ok && (g.A.lda & 3) == 0) launch_layer_gemm_ws(part, round_up(g.N, 32), s);
     else dispatch_layer_gemm(part, (w + 31) / 32, s);
   }
   CNR_LAUNCH_CHECK("layer_gemm");
@@ -418,8 +448,8 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
 // weight-gradient GEMM:  dW[n][k] = sum_pt X[pt][n] * Y[pt][k]
 // 8 waves as WR x WC, each wave (MT*32) x (KT*32); block tile TN x TK; points streamed 16 at a time.
 // ================================================================================================
-// points per slab: 16 for the square tile; the skinny tail tiles are latency-bound streams, so they take 32 at a time
-constexpr int dw_bp(int tn, int tk) { return tn + tk <= 320 ? 32 : 16; }
+// points per slab: 16 for the square tile; the skinny tail tiles are latency-bound streams, so they take as many as LDS holds
+constexpr int dw_bp(int tn, int tk) { return tn + tk <= 288 ? 64 : (tn + tk <= 320 ? 48 : 16); }
 
 template <int WR, int WC, int MT, int KT>
 __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, int k0) {
