@@ -809,6 +809,119 @@ static void launch_dw_bx(const DwGemm& g, int n0, int k0, cnr_stream s) {
   launch_dw_bx_t<-1, -1, -1, -1>(g, n0, k0, s);
 }
 
+// ================================================================================================
+// weight-gradient strips with one very narrow side (<= 8 columns): the 3 / 6 extra input columns of the colour and
+// relight nets, the rgb / sdf output rows.  Pure HBM streams (<= 12 FLOP per loaded byte): no matrix cores, no LDS
+// staging.  One workgroup per point chunk, 16 waves, each wave walks its own points (slabs dealt round-robin as in
+// dw_gemm_bx); a lane owns 4 columns of the wide operand x all narrow columns in registers; the 8 waves are folded
+// through LDS in a fixed order.  NARROW_X: the narrow operand is X (rows of dW), otherwise Y (columns of dW).
+// ================================================================================================
+constexpr int SK_WAVES = 8;
+
+template <bool NARROW_X, bool NG2>
+__global__ __launch_bounds__(SK_WAVES * 64) void dw_skinny_kernel(const DwGemm g, int n0, int k0, int ncnt) {
+  constexpr int SK_UNROLL = NG2 ? 4 : 8;
+  extern __shared__ __attribute__((aligned(16))) float smem_k[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long chunk = blockIdx.x;
+  const int wide0 = NARROW_X ? k0 : n0, narrow0 = NARROW_X ? n0 : k0;
+  const int wide_lim = NARROW_X ? g.ldk : g.Npad;       // wide columns beyond the padded extent are neither read nor written
+  const int wcol = wide0 + lane * 4;
+  const bool wlive = wcol < wide_lim;
+  f4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[j].x = 0.f; acc[j].y = 0.f; acc[j].z = 0.f; acc[j].w = 0.f; }
+  f4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};       // column sums of the narrow X operand (bias gradient)
+  const bool want_colsum = NARROW_X && g.colsum != nullptr && k0 == 0;
+  // points of this workgroup: 16-point slabs chunk, chunk + nchunk, ...; wave w takes points w and w + 8 of each slab
+  const long total_slabs = (g.P + 15) / 16;
+  const long my_slabs = chunk < total_slabs ? (total_slabs - chunk + g.nchunk - 1) / g.nchunk : 0;
+  const long my_pts = my_slabs * (16 / SK_WAVES);       // per wave
+  const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int pair = 0; pair < g.npairs; ++pair) {
+    const View& Vn = NARROW_X ? g.X[pair] : g.Y[pair];
+    const View& Vw = NARROW_X ? g.Y[pair] : g.X[pair];
+    for (long i0 = 0; i0 < my_pts; i0 += SK_UNROLL) {
+      // all loads of the round are issued before any of the (interpreted) view math: one memory round trip per round
+      Raw4 wr[SK_UNROLL], nr0[SK_UNROLL], nr1[SK_UNROLL];
+      unsigned okmask = 0;
+#pragma unroll
+      for (int u = 0; u < SK_UNROLL; ++u) {
+        const long i = i0 + u;
+        const long pt = ((i >> 1) * g.nchunk + chunk) * 16 + wave + SK_WAVES * (i & 1);
+        const bool ok = i < my_pts && pt < g.P;
+        okmask |= ok ? (1u << u) : 0u;
+        const long ptc = ok ? pt : g.P - 1;
+        wr[u] = view_fetch4(Vw, ptc, wlive ? wcol : wide0);
+        nr0[u] = view_fetch4(Vn, ptc, narrow0);
+        if (NG2) nr1[u] = view_fetch4(Vn, ptc, narrow0 + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < SK_UNROLL; ++u) {
+        const bool ok = (okmask >> u) & 1;
+        const f4 w = (ok && wlive) ? view_finish4(Vw, wr[u], wcol) : z4;
+        const f4 a0 = ok ? view_finish4(Vn, nr0[u], narrow0) : z4;
+        f4 a1 = z4;
+        if (NG2 && ok) a1 = view_finish4(Vn, nr1[u], narrow0 + 4);
+#pragma unroll
+        for (int j = 0; j < (NG2 ? 8 : 4); ++j) {
+          const float nj = j < 4 ? a0[j & 3] : a1[j & 3];
+          acc[j].x += nj * w.x; acc[j].y += nj * w.y; acc[j].z += nj * w.z; acc[j].w += nj * w.w;
+        }
+        if (want_colsum && pair == 0) {
+          cs0.x += a0.x; cs0.y += a0.y; cs0.z += a0.z; cs0.w += a0.w;
+          cs1.x += a1.x; cs1.y += a1.y; cs1.z += a1.z; cs1.w += a1.w;
+        }
+      }
+    }
+  }
+  // fold the waves in a fixed order: LDS [wave][8 narrow][256 wide]
+  float* red = smem_k + (size_t)wave * 8 * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f4*>(red + j * 256) = acc[j];
+  float* csr = smem_k + (size_t)SK_WAVES * 8 * 256;
+  if (want_colsum && lane == 0) {
+    *reinterpret_cast<f4*>(csr + wave * 8) = cs0;
+    *reinterpret_cast<f4*>(csr + wave * 8 + 4) = cs1;
+  }
+  __syncthreads();
+  float* out = g.partial + chunk * (long)g.Npad * g.ldk;
+  for (int e = tid; e < 8 * 256; e += SK_WAVES * 64) {
+    const int j = e >> 8, c = e & 255;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) sum += smem_k[(size_t)w * 8 * 256 + e];
+    const int n = NARROW_X ? narrow0 + j : wide0 + c, k = NARROW_X ? wide0 + c : narrow0 + j;
+    if (j < ncnt && n < g.Npad && k < g.ldk) out[(long)n * g.ldk + k] = sum;
+  }
+  if (want_colsum && tid < ncnt) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) sum += csr[w * 8 + tid];
+    if (n0 + tid < g.Npad) g.colsum[chunk * g.Npad + n0 + tid] = sum;
+  }
+}
+
+template <bool NARROW_X, bool NG2>
+static void launch_dw_skinny_t(const DwGemm& g, int n0, int k0, int ncnt, cnr_stream s) {
+  const size_t lds = ((size_t)SK_WAVES * 8 * 256 + SK_WAVES * 8) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_skinny_kernel<NARROW_X, NG2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int wide = NARROW_X ? ((g.K - k0) < 256 ? (g.K - k0) : 256) : ((g.N - n0) < 256 ? (g.N - n0) : 256);
+  const int tn_ = NARROW_X ? ncnt : wide, tk_ = NARROW_X ? wide : ncnt;
+  TimingScope ts_("dw_skinny", 1, NARROW_X ? 1 : 2, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
+  hipLaunchKernelGGL((dw_skinny_kernel<NARROW_X, NG2>), dim3(g.nchunk), dim3(SK_WAVES * 64), lds, s, g, n0, k0, ncnt);
+}
+
+template <bool NARROW_X>
+static void launch_dw_skinny(const DwGemm& g, int n0, int k0, int ncnt, cnr_stream s) {
+  if (ncnt > 4) launch_dw_skinny_t<NARROW_X, true>(g, n0, k0, ncnt, s);
+  else launch_dw_skinny_t<NARROW_X, false>(g, n0, k0, ncnt, s);
+}
+
 void be_dw_gemm(const DwGemm& g, cnr_stream s) {
   // tile the [Npad x ldk] output: 256x256 main tiles, 256x64 column tails, 32x256 row tails
   static const bool dw_fp32 = getenv("CNR_DW_FP32") != nullptr;   // debugging aid: FP32-MFMA kernel for the main tiles too
@@ -821,7 +934,10 @@ void be_dw_gemm(const DwGemm& g, cnr_stream s) {
           if (dw_fp32) launch_dw<4, 2, 2, 4>(g, n0, k0, s); else launch_dw_bx(g, n0, k0, s);
           k0 += 256;
         }
+        else if (krem <= 8 && !dw_fp32 && !(g.colsum != nullptr && k0 == 0) && (k0 & 3) == 0) { launch_dw_skinny<false>(g, n0, k0, krem, s); k0 += 64; }
         else { launch_dw<8, 1, 1, 2>(g, n0, k0, s); k0 += 64; }
+      } else if (nrem <= 8 && !dw_fp32 && (n0 & 3) == 0) {
+        launch_dw_skinny<true>(g, n0, k0, nrem, s); k0 += 256;
       } else {
         launch_dw<1, 8, 1, 1>(g, n0, k0, s); k0 += 256;
       }

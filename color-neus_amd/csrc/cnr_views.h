@@ -37,7 +37,7 @@ CNR_HD Raw4 view_fetch4(const View& v, long row, int col) {
   r.a = *reinterpret_cast<const f4*>(v.a + row * v.lda + col);
   if (v.kind == VK_SIGMUL) r.b = *reinterpret_cast<const f4*>(v.b + row * v.ldb + col);
   else if (v.kind == VK_SIGMUL_ROW) r.b = *reinterpret_cast<const f4*>(v.b + col);
-  else r.b = r.a;
+  else { r.b.x = 0.f; r.b.y = 0.f; r.b.z = 0.f; r.b.w = 0.f; }   // (not a copy of r.a: that would make the caller wait for the load right here)
   return r;
 }
 
