@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     if (pv3) r3 = view_fetch4(g.A, row_, 192 + scol);                             \
     if (K17 && pv4) r4 = view_fetch4(g.A, row_, 256 + scol);                      \
   }
-#define WS_PUT_TILE(buf_)                                                         \
+#define WS_PUT_TILE(buf_, tile_)                                                  \
   {                                                                               \
     const f4 v0 = pv0 ? view_finish4(g.A, r0, scol) : z4;                         \
     const f4 v1 = pv1 ? view_finish4(g.A, r1, 64 + scol) : z4;                    \
@@ -277,7 +277,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     if (pv2) ws_put4(v2, sc, dst + 256, aplane);                                  \
     if (pv3) ws_put4(v3, sc, dst + 384, aplane);                                  \
     if (K17 && pv4) ws_put4(v4, sc, dst + 512, aplane);                           \
-    if ((tid & 15) == 0) reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
+    if ((tid & 15) == 0) {                                                        \
+      reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
+      const long prow_ = (tile_) * WS_TP + srow;                                  \
+      if (g.rs_out && prow_ < Pn) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : 0.0f; /* 0 marks an all-zero row */ \
+    }                                                                             \
   }
 #define WS_MFMA(kb_)                                                                               \
   if ((kb_) < nkb) {                                                                               \
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   // matrix pipe while the other does prologue math / LDS stores / epilogue.  One barrier per tile.
   const bool late = wave >= 4;
   WS_FETCH_TILE(t0)
-  WS_PUT_TILE(0)
+  WS_PUT_TILE(0, t0)
   if (late && t0 + 1 < t1) WS_FETCH_TILE(t0 + 1)
   __syncthreads();
 
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     if (!late) {
       if (more) WS_FETCH_TILE(t + 1)
     } else if (more) {
-      WS_PUT_TILE(buf ^ 1)
+      WS_PUT_TILE(buf ^ 1, t + 1)
       if (t + 2 < t1) WS_FETCH_TILE(t + 2)
     }
     f32x16 acc;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    if (!late && more) WS_PUT_TILE(buf ^ 1)
+    if (!late && more) WS_PUT_TILE(buf ^ 1, t + 1)
     __syncthreads();
   }
 #undef WS_FETCH_TILE
@@ -425,6 +429,20 @@ static void dispatch_layer_gemm(const LayerGemm& g, int nt, cnr_stream s) {
   }
 }
 
+// Row scales for a launch that does not go through the weight-stationary kernel (debug switches, unusual shapes): same
+// definition as WS_PUT_TILE, one thread per row.  Slow path, kept only so that LayerGemm::rs_out is always honoured.
+__global__ void row_scale_kernel(const LayerGemm g) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long Pn = g.P_dev ? (long)*g.P_dev : g.P;
+  if (row >= Pn) return;
+  const int kpad = ((g.K + 15) >> 4) * 16;
+  float mx = 0.0f;
+  for (int c = 0; c < kpad; c += 4) mx = fmaxf(mx, ws_absmax4(view_eval4(g.A, row, c)));
+  float sc = 0.0f;
+  if (mx > 0.0f && mx < 3.0e38f) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); }
+  g.rs_out[row] = sc;
+}
+
 void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
   static const bool ws_off = getenv("CNR_DISABLE_WS") != nullptr;   // debugging aid: force the FP32-MFMA kernel everywhere
   static const int ws_kinds = getenv("CNR_WS_KINDS") ? atoi(getenv("CNR_WS_KINDS")) : 0xffff;   // bit mask of epilogue kinds
@@ -438,8 +456,12 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
     const int w = ncols - c0 < 256 ? ncols - c0 : 256;
     part.N = w;   // (only used for the timing record; the kernel takes its extents from K, P and the epilogue)
     const bool k_ok = g.K <= 256 || (g.K <= 272 && ws_k17_supported(g));
+    part.rs_out = c0 == 0 ? g.rs_out : nullptr;   // one launch per operand writes the row scales
     if (!ws_off && ((ws_kinds >> g.E.kind) & 1) && g.Wp != nullptr && g.wscale != nullptr && w >= 96 && k_ok && (g.A.lda & 3) == 0) launch_layer_gemm_ws(part, round_up(g.N, 32), s);
-    else dispatch_layer_gemm(part, (w + 31) / 32, s);
+    else {
+      dispatch_layer_gemm(part, (w + 31) / 32, s);
+      if (part.rs_out && g.P > 0) hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, s, part);
+    }
   }
   CNR_LAUNCH_CHECK("layer_gemm");
 }
@@ -802,11 +824,227 @@ static void launch_dw_bx(const DwGemm& g, int n0, int k0, cnr_stream s) {
 #define DX_CASE(A_, B_, C_, D_) if (x0 == A_ && y0 == B_ && x1 == C_ && y1 == D_) { launch_dw_bx_t<A_, B_, C_, D_>(g, n0, k0, s); return; }
   // the operand combinations of the render plan (cnr_plan.cpp): MLP layers, SDF value + gradient-chain pairs
   DX_CASE(VK_DIRECT, VK_DIRECT, -1, -1)
+  DX_CASE(VK_DIRECT, VK_SOFTPLUS, -1, -1)
   DX_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL, VK_DIRECT)
   DX_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL_ROW, VK_DIRECT)
   DX_CASE(VK_DIRECT, VK_SOFTPLUS, VK_CONST_COL0, VK_DIRECT)
 #undef DX_CASE
   launch_dw_bx_t<-1, -1, -1, -1>(g, n0, k0, s);
+}
+
+// ================================================================================================
+// weight-gradient GEMM, 256 x 256 output tile, split-f16 matrix cores (three MFMAs per product instead of six)
+//
+// Along the contraction (points) a scale can only be used if it cancels per point: X'[pt] = X[pt] * sx[pt] (the power of
+// two that lifts the row into the top f16 binade -- emitted for free by the layer GEMM that consumed the same operand,
+// LayerGemm::rs_out) and Y'[pt] = Y[pt] * 2^G / sx[pt], so X'^T Y' = 2^G X^T Y exactly.  G = 1 + min over points of
+// log2(sx * sy) (be_dw_scale) keeps every Y' row below 2^15; points whose product is far below the largest one lose relative
+// precision in Y' but their absolute error stays below 2^-40 of the largest term.  Both operands are split hi + lo
+// (11 + 11 bits) and x1 y2 + x2 y1 + x1 y1 is accumulated in fp32; the result is scaled back by 2^-G (exact).
+// Structure, LDS layout and wave phase shift as dw_gemm_bx_kernel (two planes per operand instead of three).
+// ================================================================================================
+constexpr int DH_OPER = 2 * DX_PLANE;
+constexpr int DH_BUF = 2 * DH_OPER;
+
+template <int XK0, int YK0, int XK1, int YK1>
+__global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, int n0, int k0) {
+  DwGemm g = g_in;
+  if (XK0 >= 0) g.X[0].kind = XK0;
+  if (YK0 >= 0) g.Y[0].kind = YK0;
+  if (XK1 >= 0) g.X[1].kind = XK1;
+  if (YK1 >= 0) g.Y[1].kind = YK1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const long chunk = blockIdx.x;
+  const long p_end = g.P;
+  const long total_slabs = (g.P + 15) / 16;
+  const int nslab_pair = chunk < total_slabs ? (int)((total_slabs - chunk + g.nchunk - 1) / g.nchunk) : 0;
+  const int nslab = nslab_pair * g.npairs;
+  int G = *g.gexp;
+  if (G > 250 || G < -250) G = 0;                         // no point with two non-zero rows: everything is zero anyway
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const bool is_y = tid >= 256;
+  const int st = tid & 255;
+  const int qlo = st & 1, c4 = (st >> 1) & 63, qhi = st >> 7;
+  const int q = qhi * 2 + qlo;
+  const int scol = (is_y ? k0 : n0) + c4 * 4;
+  unsigned char* const sdst = smem_d + (is_y ? DH_OPER : 0) + qhi * DX_HALF + c4 * 16 + qlo * 8;
+  f4 ra[4], rb[4];
+  float rsx[4];                                           // sx of the 4 points this thread stages
+  bool okp[4];
+  int staged_pair = 0;
+  f4 csum = {0.f, 0.f, 0.f, 0.f};
+  const bool want_colsum = g.colsum != nullptr && k0 == 0;
+
+#define DH_FETCH_(V_)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+    long pt = pbase_ + i;                                                                  \
+    okp[i] = pt < p_end;                                                                   \
+    if (!okp[i]) pt = p_end - 1;                                                           \
+    const Raw4 q_ = view_fetch4(V_, pt, scol);                                             \
+    ra[i] = q_.a; rb[i] = q_.b;                                                            \
+    rsx[i] = sxp_[pt];                                                                     \
+  }
+#define DH_LOAD_SLAB(s_)                                                                   \
+  {                                                                                        \
+    const int pair_ = (s_) / nslab_pair;                                                   \
+    staged_pair = pair_;                                                                   \
+    const long pbase_ = ((long)((s_) - pair_ * nslab_pair) * g.nchunk + chunk) * 16 + q * 4; \
+    const float* sxp_ = pair_ == 0 ? g.sx[0] : g.sx[1];                                    \
+    if (pair_ == 0) { if (is_y) { DH_FETCH_(g.Y[0]) } else { DH_FETCH_(g.X[0]) } }         \
+    else { if (is_y) { DH_FETCH_(g.Y[1]) } else { DH_FETCH_(g.X[1]) } }                    \
+  }
+#define DH_FINISH_(V_)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+    Raw4 q_; q_.a = ra[i]; q_.b = rb[i];                                                   \
+    v_[i] = okp[i] ? view_finish4(V_, q_, scol) : z4_;                                     \
+  }
+#define DH_STORE_SLAB(buf_)                                                                \
+  {                                                                                        \
+    const f4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                   \
+    f4 v_[4];                                                                              \
+    if (staged_pair == 0) { if (is_y) { DH_FINISH_(g.Y[0]) } else { DH_FINISH_(g.X[0]) } } \
+    else { if (is_y) { DH_FINISH_(g.Y[1]) } else { DH_FINISH_(g.X[1]) } }                  \
+    if (want_colsum && !is_y && staged_pair == 0) {                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) { csum.x += v_[i].x; csum.y += v_[i].y; csum.z += v_[i].z; csum.w += v_[i].w; } \
+    }                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+      float f_ = rsx[i];                                                                   \
+      if (is_y) f_ = f_ > 0.0f ? ldexpf(1.0f / f_, G) : 0.0f;                              \
+      v_[i].x *= f_; v_[i].y *= f_; v_[i].z *= f_; v_[i].w *= f_;                          \
+    }                                                                                      \
+    unsigned char* d_ = sdst + (buf_) * DH_BUF;                                            \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+      f16x4 h1, h2;                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) { const float x_ = v_[i][j]; h1[i] = (_Float16)x_; h2[i] = (_Float16)(x_ - (float)h1[i]); } \
+      *reinterpret_cast<f16x4*>(d_ + j * DX_JREG) = h1;                                    \
+      *reinterpret_cast<f16x4*>(d_ + DX_PLANE + j * DX_JREG) = h2;                         \
+    }                                                                                      \
+  }
+
+  if (nslab > 0) {
+    DH_LOAD_SLAB(0)
+    DH_STORE_SLAB(0)
+    if (is_y && nslab > 1) DH_LOAD_SLAB(1)
+  }
+  __syncthreads();
+  const int ln = lane & 31, lh = lane >> 5;
+  const int xoff = lh * DX_HALF + (ln & 3) * DX_JREG + (wr * 16 + (ln >> 2)) * 16;
+  const int yoff = DH_OPER + lh * DX_HALF + (ln & 3) * DX_JREG + (wc * 32 + (ln >> 2)) * 16;
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (!is_y) {
+      if (s + 1 < nslab) DH_LOAD_SLAB(s + 1)
+    } else if (s + 1 < nslab) {
+      DH_STORE_SLAB(buf ^ 1)
+      if (s + 2 < nslab) DH_LOAD_SLAB(s + 2)
+    }
+    const unsigned char* B_ = smem_d + buf * DH_BUF;
+    f16x8 a[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const f16x8*>(B_ + xoff + p * DX_PLANE + i * 128);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x8 b[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) b[p] = *reinterpret_cast<const f16x8*>(B_ + yoff + p * DX_PLANE + j * 128);
+      f32x16 c0 = acc[0][j], c1 = acc[1][j];
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], b[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b[0], c1, 0, 0, 0);
+      acc[0][j] = c0; acc[1][j] = c1;
+    }
+    if (!is_y && s + 1 < nslab) DH_STORE_SLAB(buf ^ 1)
+    __syncthreads();
+  }
+#undef DH_LOAD_SLAB
+#undef DH_STORE_SLAB
+#undef DH_FETCH_
+#undef DH_FINISH_
+
+  // undo 2^G in two exact steps (G can exceed the fp32 exponent range of a single factor)
+  const float u1 = ldexpf(1.0f, -(G / 2)), u2 = ldexpf(1.0f, -(G - G / 2));
+  float* out = g.partial + chunk * (long)g.Npad * g.ldk;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = k0 + wc * 128 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < g.Npad && kk < g.ldk) out[(long)n * g.ldk + kk] = acc[i][j][r] * u1 * u2;
+      }
+    }
+  if (want_colsum) {
+    float* cs = reinterpret_cast<float*>(smem_d);
+    if (!is_y) *reinterpret_cast<f4*>(cs + q * 256 + c4 * 4) = csum;
+    __syncthreads();
+    if (tid < 256 && n0 + tid < g.Npad) g.colsum[chunk * g.Npad + n0 + tid] = ((cs[tid] + cs[256 + tid]) + cs[512 + tid]) + cs[768 + tid];
+  }
+}
+
+template <int XK0, int YK0, int XK1, int YK1>
+static void launch_dw_hx_t(const DwGemm& g, int n0, int k0, cnr_stream s) {
+  const size_t lds = (size_t)2 * DH_BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_hx_kernel<XK0, YK0, XK1, YK1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int tn_ = (g.N - n0) < 256 ? (g.N - n0) : 256, tk_ = (g.K - k0) < 256 ? (g.K - k0) : 256;
+  TimingScope ts_("dw_gemm_hx", 1, 4224, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
+  hipLaunchKernelGGL((dw_gemm_hx_kernel<XK0, YK0, XK1, YK1>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
+}
+
+static void launch_dw_hx(const DwGemm& g, int n0, int k0, cnr_stream s) {
+  const int x0 = g.X[0].kind, y0 = g.Y[0].kind, x1 = g.npairs > 1 ? g.X[1].kind : -1, y1 = g.npairs > 1 ? g.Y[1].kind : -1;
+#define DH_CASE(A_, B_, C_, D_) if (x0 == A_ && y0 == B_ && x1 == C_ && y1 == D_) { launch_dw_hx_t<A_, B_, C_, D_>(g, n0, k0, s); return; }
+  DH_CASE(VK_DIRECT, VK_DIRECT, -1, -1)
+  DH_CASE(VK_DIRECT, VK_SOFTPLUS, -1, -1)
+  DH_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL, VK_DIRECT)
+  DH_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL_ROW, VK_DIRECT)
+#undef DH_CASE
+  launch_dw_hx_t<-1, -1, -1, -1>(g, n0, k0, s);
+}
+
+// G = 1 + min over points (both pairs) of log2(sx * sy), rows with a zero scale (all-zero rows) excluded.  *gexp must hold a large
+// value on entry (be_dw_scale fills it with 0x7f bytes).  min is order independent, so the atomic keeps results deterministic.
+__global__ void dw_scale_kernel(const float* sx0, const float* sy0, const float* sx1, const float* sy1, long P, int* gexp) {
+  int best = 0x7f7f7f7f;
+  for (long pt = (long)blockIdx.x * blockDim.x + threadIdx.x; pt < P; pt += (long)gridDim.x * blockDim.x) {
+    const float a = sx0[pt], b = sy0[pt];
+    if (a > 0.0f && b > 0.0f) { const int e = ilogbf(a) + ilogbf(b) + 1; best = e < best ? e : best; }
+    if (sx1) {
+      const float c = sx1[pt], d = sy1[pt];
+      if (c > 0.0f && d > 0.0f) { const int e = ilogbf(c) + ilogbf(d) + 1; best = e < best ? e : best; }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(best, d); best = o < best ? o : best; }
+  if ((threadIdx.x & 63) == 0) atomicMin(gexp, best);
+}
+
+void be_dw_scale(const DwGemm& g, int* gexp, cnr_stream s) {
+  (void)hipMemsetAsync(gexp, 0x7f, sizeof(int), s);
+  TimingScope ts_("dw_scale", 2, 0, g.P, 0, 0, 0, s);
+  hipLaunchKernelGGL(dw_scale_kernel, dim3(512), dim3(256), 0, s, g.sx[0], g.sy[0], g.npairs > 1 ? g.sx[1] : nullptr,
+                     g.npairs > 1 ? g.sy[1] : nullptr, g.P, gexp);
+  CNR_LAUNCH_CHECK("dw_scale");
 }
 
 // ================================================================================================
@@ -925,13 +1163,24 @@ static void launch_dw_skinny(const DwGemm& g, int n0, int k0, int ncnt, cnr_stre
 void be_dw_gemm(const DwGemm& g, cnr_stream s) {
   // tile the [Npad x ldk] output: 256x256 main tiles, 256x64 column tails, 32x256 row tails
   static const bool dw_fp32 = getenv("CNR_DW_FP32") != nullptr;   // debugging aid: FP32-MFMA kernel for the main tiles too
+  static const bool dw_bf16 = getenv("CNR_DW_BF16") != nullptr;   // debugging aid: split-bf16 kernel even when row scales are available
   for (int n0 = 0; n0 < g.N; n0 += 256) {
     const int nrem = g.N - n0;
     for (int k0 = 0; k0 < g.K;) {
       const int krem = g.K - k0;
       if (nrem > 32) {
         if (krem > 64) {
-          if (dw_fp32) launch_dw<4, 2, 2, 4>(g, n0, k0, s); else launch_dw_bx(g, n0, k0, s);
+          // the gradient-chain pair of the top SDF layer is a unit vector at the sdf row: it adds nothing to other row tiles
+          DwGemm gm = g;
+          if (gm.npairs == 2 && gm.X[1].kind == VK_CONST_COL0) {
+            const int hot = gm.X[1].math_split == (1 << 30) ? 0 : gm.X[1].math_split;
+            if (hot < n0 || hot >= n0 + 256) gm.npairs = 1;
+          }
+          bool scaled = !dw_bf16 && gm.gexp != nullptr;
+          for (int i = 0; i < gm.npairs; ++i) scaled = scaled && gm.sx[i] != nullptr && gm.sy[i] != nullptr;
+          if (dw_fp32) launch_dw<4, 2, 2, 4>(g, n0, k0, s);
+          else if (scaled) launch_dw_hx(gm, n0, k0, s);
+          else launch_dw_bx(gm, n0, k0, s);
           k0 += 256;
         }
         else if (krem <= 8 && !dw_fp32 && !(g.colsum != nullptr && k0 == 0) && (k0 & 3) == 0) { launch_dw_skinny<false>(g, n0, k0, krem, s); k0 += 64; }

@@ -227,6 +227,9 @@ struct Ctx {   // forward-saved state
   float *featx_c, *aux_c, *gcol_c, *relit_c, *delta_c; int *p_idx, *p_counts, *p_offsets;
   int ldfx = 0, ldy = 0;   // row strides of featx = [feat | aux | 0] and hry = [relight hidden | global colour | 0]
   std::vector<float*> Z, V, HC, HR;
+  // per-point row scales of GEMM operands that the weight-gradient GEMMs read again (LayerGemm::rs_out -> DwGemm::sx / sy):
+  // rsY[l] input of SDF layer l, rsX1[l] = sigma'(z_l) v_l, rsC[l] input of colour layer l, rsR[i] input of relight rl_mlp layer i
+  std::vector<float*> rsY, rsX1, rsC, rsR;
   // sampler scratch (forward only)
   float *sE, *sZa, *sZb, *s_sdf0, *s_sdf, *s_newz, *s_newsdf;
   int ldztop;
@@ -291,12 +294,20 @@ static void layout_ctx(Model& m, long R, Arena& a, Ctx& x) {
   x.p_counts = reinterpret_cast<int*>(a.f(R));
   x.p_offsets = reinterpret_cast<int*>(a.f(R + 1));
   x.ldztop = round_up(m.F + 1, 16);
+  x.rsY.assign(m.L + 1, nullptr); x.rsX1.assign(m.L, nullptr); x.rsC.assign(m.NC, nullptr); x.rsR.assign(m.NR, nullptr);
+  for (int l = 1; l <= m.L; ++l) x.rsY[l] = a.f(P);
+  for (int l = 1; l < m.L; ++l) x.rsX1[l] = a.f(P);
+  for (int l = 0; l + 1 < m.NC; ++l) x.rsC[l] = a.f(P);
+  for (int i = 0; i + 1 < m.NR; ++i) x.rsR[i] = a.f(P);
   a.f(1024);   // slack: GEMM tiles may read (never use) a few columns past the last row of a buffer
 }
 
 struct Bwd {   // backward scratch
   float *ZTOP, *gbar_a, *dtop, *gc_a, *gc_b, *dctop, *dinvs, *drd_alpha, *dAUXc, *dAUXr, *gbar_t, *cbar, *ebar0, *ebars, *pbar;
   std::vector<float*> D, DC, VB, Z2;
+  std::vector<float*> rsX0, rsY1;   // row scales of the SDF cotangents z-bar_l (value pair) and q-bar_l (gradient-chain pair)
+  float* rsD;                       // row scales of the colour / relight cotangent consumed right after its layer GEMM
+  int* gexp;                        // common exponent of the current split-f16 weight-gradient GEMM
   float *partial, *colsum;
   int nchunk; long chunk_pts;
   size_t partial_floats;
@@ -338,6 +349,11 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   b.partial_floats = mx;
   b.partial = a.f((size_t)b.nchunk * mx);
   b.colsum = a.f((size_t)b.nchunk * 320);
+  b.rsX0.assign(m.L + 1, nullptr); b.rsY1.assign(m.L + 1, nullptr);
+  for (int l = 1; l <= m.L; ++l) b.rsX0[l] = a.f(P);
+  for (int l = 1; l < m.L; ++l) b.rsY1[l] = a.f(P);
+  b.rsD = a.f(P);
+  b.gexp = reinterpret_cast<int*>(a.f(16));
   a.f(1024);   // slack (see layout_ctx)
 }
 
@@ -378,12 +394,13 @@ static View sdf_input_view(const Model& m, int l, const float* E, const float* c
 // SDF value chain on n points; Z[l] receive the pre-activations of the hidden layers.  If value_only the top
 // layer only evaluates row 0 (the sdf) and writes sign*sdf/scale... (sign folded by the caller through `top_scale`).
 static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, float* sdf_out, float* feat_out, int ld_feat,
-                      float top_scale, cnr_stream s) {
+                      float top_scale, cnr_stream s, float* const* rs = nullptr /* [L+1] row scales of the layer inputs, see Ctx::rsY */) {
   for (int l = 0; l <= m.L; ++l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;
     g.A = sdf_input_view(m, l, E, Z);
     g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.K = q.k_int; g.P = n;
+    if (rs && (l < m.L || feat_out)) g.rs_out = rs[l];
     if (l < m.L) {
       g.N = q.n;
       g.E.kind = EK_STORE; g.E.n_out = q.n; g.E.bias = q.bias; g.E.o1 = Z[l]; g.E.ld1 = m.Hs;
@@ -443,7 +460,7 @@ static int skip_off(const Model& m) {
 }
 
 static void sdf_grad_chain(const Model& m, long P, const float* E, const float* const* Z, float* const* V, float* CE0, float* CES,
-                           cnr_stream s) {
+                           cnr_stream s, float* const* rs = nullptr /* [L] row scales of sigma'(z_l) v_l, see Ctx::rsX1 */) {
   const float inv_scale = 1.0f / m.c.sdf_scale;
   for (int l = m.L - 1; l >= 0; --l) {
     const Lin& q = m.sdf[l];
@@ -452,6 +469,7 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
     if (l == m.L - 1) { g.A.kind = VK_SIGMUL_ROW; g.A.b = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; g.A.scale = inv_scale; }   // v_{L-1} = W_top[0,:]/scale
     else { g.A.kind = VK_SIGMUL; g.A.b = V[l]; g.A.ldb = m.Hs; }
     g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
+    if (rs) g.rs_out = rs[l];
     if (l == 0) {
       g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = CE0; g.E.ld1 = kEmb;
     } else if (m.skip(l)) {
@@ -484,6 +502,7 @@ static void color_chain(const Model& m, long P, const Ctx& x, cnr_stream s, cons
     g.A = color_input_view(m, l, x);
     g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.bias = q.bias; g.E.n_out = q.n;
+    if (!P_dev && (size_t)l < x.rsC.size()) g.rs_out = x.rsC[l];
     if (l + 1 < m.NC) { g.E.kind = EK_RELU; g.E.o1 = x.HC[l]; g.E.ld1 = m.Hc; }
     else {
       g.E.kind = m.c.col_squeeze_out ? EK_SIGMOID : EK_LINEAR_SIG; g.E.o1 = x.gcol; g.E.ld1 = 4;
@@ -516,6 +535,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
     g.A = relight_input_view(m, i, x);
     g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.bias = q.bias; g.E.n_out = q.n;
+    if (!P_dev && (size_t)i < x.rsR.size()) g.rs_out = x.rsR[i];
     if (i + 1 < m.NR) { g.E.kind = EK_RELU; g.E.o1 = x.HR[i + 1]; g.E.ld1 = hr_ld(m, x, i + 1); }
     else {
       g.E.kind = EK_RELIGHT_TOP; g.E.o1 = delta_out; g.E.ld1 = 3; g.E.o2 = x.relit; g.E.ld2 = 4;
@@ -559,10 +579,10 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   fs.o = in->rays_o; fs.d = in->rays_d; fs.z = out->z_vals; fs.R = R; fs.M = m.M; fs.sample_dist = 2.0f / (float)m.S;
   fs.scale = scale; fs.multires = m.c.sdf_multires; fs.multires_view = m.mv; fs.E = x.E; fs.AUX = x.AUX;
   be_fine_setup(fs, s);
-  sdf_chain(m, P, x.E, x.Z.data(), x.sdf, x.featx, x.ldfx, 1.0f / scale, s);
+  sdf_chain(m, P, x.E, x.Z.data(), x.sdf, x.featx, x.ldfx, 1.0f / scale, s, x.rsY.data());
   for (int l = 1; l < m.L; ++l)   // V[l-1] feeds a GEMM over round_up(n,16) columns: its unwritten pad columns must be finite
     if (m.skip(l) && x.V[l - 1]) be_memset_zero(x.V[l - 1], (size_t)P * m.Hs * sizeof(float), s);
-  sdf_grad_chain(m, P, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s);
+  sdf_grad_chain(m, P, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s, x.rsX1.data());
   GradFinish gf;
   gf.featx = x.featx; gf.ldfx = x.ldfx; gf.F = m.F;
   gf.P = P; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES + skip_off(m) : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
@@ -617,6 +637,16 @@ static void run_dw(const Model& m, const Lin& q, DwGemm& g, const Bwd& b, const 
                    bool with_bias, cnr_stream s) {
   g.N = q.n; g.K = q.k_int; g.nchunk = b.nchunk; g.chunk_pts = b.chunk_pts;
   g.partial = b.partial; g.Npad = q.npad; g.ldk = q.ldw; g.colsum = with_bias ? b.colsum : nullptr;
+  // split-f16 tiles need the row scales of every operand of the 256 x 256 tiles (the top SDF layer's unit-vector pair is dropped there)
+  const int need = (g.npairs == 2 && g.X[1].kind == VK_CONST_COL0) ? 1 : g.npairs;
+  bool scaled = q.n > 32 && q.k_int > 64;
+  for (int i = 0; i < need; ++i) scaled = scaled && g.sx[i] && g.sy[i];
+  if (scaled) {
+    DwGemm t = g;
+    t.npairs = need;
+    be_dw_scale(t, b.gexp, s);
+    g.gexp = b.gexp;
+  }
   be_dw_gemm(g, s);
   FinishWeight f;
   f.partial = b.partial; f.nchunk = b.nchunk; f.npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? b.colsum : nullptr;
@@ -682,10 +712,11 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
       g.E.kind = EK_RELU_MASK; g.E.n_out = q.k_int; g.E.split = m.Hr; g.E.o1 = b.D[i]; g.E.ld1 = m.Hr;
       g.E.aux = x.HR[i]; g.E.ldaux = hr_ld(m, x, i); g.E.o2 = (i == y) ? b.gc_b : nullptr; g.E.ld2 = 4;
+      if (q.n > 32) g.rs_out = b.rsD;
       be_layer_gemm(g, s);
       DwGemm d;
       d.npairs = 1; d.P = P;
-      d.X[0] = g.A;
+      d.X[0] = g.A; d.sx[0] = g.rs_out; d.sy[0] = x.rsR[i];
       d.Y[0] = relight_input_view(m, i, x);
       run_dw(m, q, d, b, params, dP, true, s);
     }
@@ -721,10 +752,11 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.split = m.F; g.E.o1 = b.ZTOP; g.E.ld1 = x.ldztop; g.E.o1_off = 0;
       g.E.o2 = b.dAUXc; g.E.ld2 = kAux;
     }
+    if (q.n > 32) g.rs_out = b.rsD;
     be_layer_gemm(g, s);
     DwGemm d;
     d.npairs = 1; d.P = P;
-    d.X[0] = g.A;
+    d.X[0] = g.A; d.sx[0] = g.rs_out; d.sy[0] = x.rsC[l];
     d.Y[0] = color_input_view(m, l, x);
     run_dw(m, q, d, b, params, dP, true, s);
   }
@@ -752,6 +784,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     else { g.E.v = x.V[l]; g.E.ldv = m.Hs; }
     g.E.o1 = b.Z2[l]; g.E.ld1 = m.Hs; g.E.o2 = b.VB[l]; g.E.ld2 = m.Hs;
     if (m.skip(l + 1)) { g.E.tail_src = b.cbar; g.E.ld_tail = kEmb; g.E.tail_n = m.emb; }
+    g.rs_out = b.rsY1[l];
     be_layer_gemm(g, s);
   }
   // ---- 6. value-path backward through the SDF net (in place: Z2[l] becomes the total cotangent of z_l)
@@ -763,6 +796,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
     g.E.kind = EK_VBACK; g.E.n_out = q.k_int; g.E.z = x.Z[l - 1]; g.E.ldz = m.Hs; g.E.o1 = b.Z2[l - 1]; g.E.ld1 = m.Hs;
     if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; g.E.o2_off = skip_off(m); }
+    g.rs_out = b.rsX0[l];
     be_layer_gemm(g, s);
   }
   if (rays_grad) {
@@ -790,6 +824,8 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       else { d.X[1].kind = VK_SIGMUL; d.X[1].b = x.V[l]; d.X[1].ldb = m.Hs; }
       d.Y[1] = qbar_view(l);
     }
+    d.sx[0] = b.rsX0[l]; d.sy[0] = x.rsY[l];
+    if (l < m.L) { d.sx[1] = x.rsX1[l]; d.sy[1] = b.rsY1[l]; }
     run_dw(m, q, d, b, params, dP, true, s);
   }
   // ---- 8. d rays (camera refinement configs)

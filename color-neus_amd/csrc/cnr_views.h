@@ -340,6 +340,8 @@ struct LayerGemm {
   long wp_stride = 0;                   // elements between planes
   const float* wscale = nullptr;        // per W row: 1 / (power-of-two scale applied before the f16 split)
   const int* P_dev = nullptr; // optional device-side row count (<= P): compacted point lists whose length only the GPU knows
+  float* rs_out = nullptr;    // optional [P]: the power-of-two scale that lifts each (prologue-applied) operand row into the top f16
+                              // binade, 0 for an all-zero row; the weight-gradient GEMM re-uses it for the same operand
 };
 
 // dW[N x K] (+)= sum over points of X[pt][n] * Y[pt][k]   (up to two operand pairs share the accumulators)
@@ -354,6 +356,11 @@ struct DwGemm {
   float* partial = nullptr;   // [nchunk][Npad][ldk]
   int Npad = 0, ldk = 0;
   float* colsum = nullptr;    // optional [nchunk][Npad]: column sums of X[0] (bias gradient)
+  // optional per-point row scales of the operands (LayerGemm::rs_out of the launch that consumed the same view) and the common
+  // exponent G = 1 + min over points of log2(sx * sy) (be_dw_scale): with all of them present the 256 x 256 tiles run as f16 x 3
+  const float* sx[2] = {nullptr, nullptr};
+  const float* sy[2] = {nullptr, nullptr};
+  const int* gexp = nullptr;
 };
 
 // Algorithmic HBM bytes of one launch: every operand matrix read once, every output written once (weights and bias are
