@@ -371,8 +371,10 @@ static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
   const size_t lds = (size_t)2 * abuf + (size_t)8 * 32 * WS_TLD * sizeof(float);
   const long ntiles = (g.P + WS_TP - 1) / WS_TP;
   if (ntiles == 0) return;
-  long tpw = (ntiles + 511) / 512;       // ~2 workgroups per CU over the launch (1 resident): evens out the tail
-  if (tpw < 4) tpw = 4;
+  static const int ws_wgs = getenv("CNR_WS_WGS") ? atoi(getenv("CNR_WS_WGS")) : 256;       // tuning knobs (defaults measured on MI355X)
+  static const int ws_mintpw = getenv("CNR_WS_MINTPW") ? atoi(getenv("CNR_WS_MINTPW")) : 8;
+  long tpw = (ntiles + ws_wgs - 1) / ws_wgs;   // one workgroup per CU: the weights are loaded once per CU (measured best of 256 / 512 / 768 / 1024)
+  if (tpw < ws_mintpw) tpw = ws_mintpw;
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
   static bool attr_set = false;
   if (!attr_set) {
