@@ -16,404 +16,10 @@
 
 #include "cnr_backend.h"
 #include "cnr_hip_util.h"
+#include "cnr_gemm_int.h"
+#include "cnr_gemm_fp32.h"
 
 namespace cnr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// ================================================================================================
-// layer GEMM
-// ================================================================================================
-constexpr int LG_BM = 128;     // points per workgroup (4 waves x 32 rows)
-constexpr int LG_BK = 16;      // K slab
-constexpr int LG_LD = 20;      // LDS row stride in floats: 20 = 4*5 -> ds_read_b128 of 16 rows hits 64 distinct banks
-constexpr int LG_TLD = 36;     // row stride of the epilogue transpose tile (16-byte aligned rows -> ds_read_b128)
-
-// compile-time recursion over the N tiles: accumulator indices stay static (a runtime-indexed ext-vector array would be
-// placed in scratch memory)
-template <int NT, int I>
-__device__ __forceinline__ void lg_epilogue_tiles(const f32x16 (&acc)[NT], const Epi& e, float* T, long wave_row0, long P, int lane,
-                                                  int ncols_live, int col0) {
-  if constexpr (I < NT) {
-    if (col0 + I * 32 < ncols_live) {
-      const int hi = lane >> 5, cl = lane & 31;
-      const int er = lane >> 3, ec4 = (lane & 7) * 4;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * LG_TLD + cl] = acc[I][r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr = er + 8 * i;
-        const long row = wave_row0 + rr;
-        const f4 v = *reinterpret_cast<const f4*>(T + rr * LG_TLD + ec4);
-        if (row < P) epi_apply4(e, row, col0 + I * 32 + ec4, v);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    lg_epilogue_tiles<NT, I + 1>(acc, e, T, wave_row0, P, lane, ncols_live, col0);
-  }
-}
-
-template <int NT>
-__global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                            // [2][128][LG_LD]
-  float* Bs = smem + 2 * LG_BM * LG_LD;        // [2][NT*32][LG_LD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long row0 = (long)blockIdx.x * LG_BM;
-  const long Pn = g.P_dev ? (long)*g.P_dev : g.P;   // compacted inputs: tiles past the device-side count have nothing to do
-  if (row0 >= Pn) return;
-  const int nslab = (g.K + LG_BK - 1) / LG_BK;
-  constexpr int NB = (NT * 32 * 4 + 255) / 256;   // float4 of W per thread per slab
-  constexpr bool NB_EXACT = (NT * 32 * 4) % 256 == 0;
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
-
-  // staging registers (native vectors: stay in VGPRs)
-  f4 ra0, ra1, rb0a, rb1a;   // A: raw a / b operands of the two float4 this thread stages
-  f4 rw[NB];
-  const int ar0 = tid >> 2, ar1 = (tid + 256) >> 2, ac4 = (tid & 3) * 4;
-  long arow0 = row0 + ar0, arow1 = row0 + ar1;
-  if (arow0 >= Pn) arow0 = Pn - 1;             // clamp: rows beyond P are computed on valid data and dropped in the epilogue
-  if (arow1 >= Pn) arow1 = Pn - 1;
-  const View A = g.A;
-  const bool has_b = A.kind == VK_SIGMUL || A.kind == VK_SIGMUL_ROW;
-  const float* a0p = A.a + arow0 * A.lda + ac4;
-  const float* a1p = A.a + arow1 * A.lda + ac4;
-  const float* b0p = A.kind == VK_SIGMUL ? A.b + arow0 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a0p);
-  const float* b1p = A.kind == VK_SIGMUL ? A.b + arow1 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a1p);
-  const float* wp = g.W + (long)(g.col0 + (tid >> 2)) * g.ldw + ac4;
-
-#define LG_LOAD_SLAB(s_)                                                                     \
-  {                                                                                          \
-    const int ko_ = (s_) * LG_BK;                                                            \
-    ra0 = *reinterpret_cast<const f4*>(a0p + ko_);                                           \
-    ra1 = *reinterpret_cast<const f4*>(a1p + ko_);                                           \
-    if (has_b) {                                                                             \
-      rb0a = *reinterpret_cast<const f4*>(b0p + ko_);                                        \
-      rb1a = *reinterpret_cast<const f4*>(b1p + ko_);                                        \
-    }                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                         \
-      if (NB_EXACT || tid + i * 256 < NT * 32 * 4)                                           \
-        rw[i] = *reinterpret_cast<const f4*>(wp + (long)i * 64 * g.ldw + ko_);               \
-    }                                                                                        \
-  }
-#define LG_STORE_SLAB(buf_, s_)                                                              \
-  {                                                                                          \
-    const int kc_ = (s_) * LG_BK + ac4;                                                      \
-    Raw4 q0_, q1_;                                                                           \
-    q0_.a = ra0; q0_.b = has_b ? rb0a : ra0;                                                 \
-    q1_.a = ra1; q1_.b = has_b ? rb1a : ra1;                                                 \
-    *reinterpret_cast<f4*>(As + ((buf_) * LG_BM + ar0) * LG_LD + ac4) = view_finish4(A, q0_, kc_); \
-    *reinterpret_cast<f4*>(As + ((buf_) * LG_BM + ar1) * LG_LD + ac4) = view_finish4(A, q1_, kc_); \
-    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                         \
-      if (NB_EXACT || tid + i * 256 < NT * 32 * 4)                                           \
-        *reinterpret_cast<f4*>(Bs + ((buf_) * NT * 32 + (tid >> 2) + i * 64) * LG_LD + ac4) = rw[i]; \
-    }                                                                                        \
-  }
-
-  LG_LOAD_SLAB(0)
-  LG_STORE_SLAB(0, 0)
-  __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nslab) LG_LOAD_SLAB(s + 1)
-    const float* Ab = As + (buf * LG_BM + wave * 32 + (lane & 31)) * LG_LD + (lane >> 5) * 4;
-    const float* Bb = Bs + (buf * NT * 32 + (lane & 31)) * LG_LD + (lane >> 5) * 4;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const f4 a = *reinterpret_cast<const f4*>(Ab + kb * 8);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const f4 b = *reinterpret_cast<const f4*>(Bb + nt * 32 * LG_LD + kb * 8);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
-      }
-    }
-    if (s + 1 < nslab) LG_STORE_SLAB(buf ^ 1, s + 1)
-    __syncthreads();
-  }
-#undef LG_LOAD_SLAB
-#undef LG_STORE_SLAB
-
-  // ---- epilogue: transpose each 32x32 accumulator tile through a wave-private LDS tile, then 4 columns per lane
-  float* T = smem + wave * (32 * LG_TLD);
-  const Epi e = g.E;
-  const int ncols_live = e.n_out + (e.tail_src ? e.tail_n : 0);
-  lg_epilogue_tiles<NT, 0>(acc, e, T, row0 + wave * 32, Pn, lane, ncols_live, g.col0);
-}
-
-template <int NT>
-static void launch_layer_gemm(const LayerGemm& g, cnr_stream s) {
-  const size_t lds = (size_t)(2 * LG_BM * LG_LD + 2 * NT * 32 * LG_LD) * sizeof(float);
-  const unsigned grid = (unsigned)((g.P + LG_BM - 1) / LG_BM);
-  if (grid == 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  TimingScope ts_("layer_gemm", 0, NT, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
-  hipLaunchKernelGGL(layer_gemm_kernel<NT>, dim3(grid), dim3(256), lds, s, g);
-}
-
-
-// ================================================================================================
-// weight-stationary layer GEMM (K <= 256, up to 256 output columns per launch)
-//
-// The whole layer lives in the REGISTER FILE of one CU: 8 waves x 32 output columns; each wave keeps its slice of W as two f16
-// planes in MFMA B-operand layout (2 planes x 16 k-blocks x 4 VGPRs = 128 VGPRs).  Points stream through in 32-row tiles: a tile is
-// fetched once, gets the fused prologue (cnr_views.h), is scaled by an exact power of two per row, split into f16 hi + lo
-// (11 + 11 significand bits) on its way into LDS and read by all 8 waves.  Each product is three v_mfma_f32_32x32x16_f16
-// (a1 w1 + a1 w2 + a2 w1; the dropped a2 w2 is < 2^-22), fp32 accumulation, and the epilogue undoes the row / column scales
-// (exact).  Measured (tools/probes/ws_probe.hip): max error 8.3e-7 vs float64 where the FP32 FMA chain of v_mfma_f32_32x32x2_f32 has
-// 1.1e-6 -- also with rows spanning 12 orders of magnitude -- at 3 x 32 = 96 MFMA cycles per k16 block instead of 8 x 64 = 512.
-// No weight traffic after the prologue, 16 accumulator registers, one barrier per 32 points.
-// ================================================================================================
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-constexpr int WS_TP = 32;
-constexpr int WS_THREADS = 512;
-constexpr int WS_TLD = 36;
-
-__device__ __forceinline__ float ws_absmax4(const f4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
-__device__ __forceinline__ void ws_put4(const f4& v, float sc, unsigned char* dst, int aplane) {
-  f16x4 h1, h2;
-  float x;
-  x = v.x * sc; h1[0] = (_Float16)x; h2[0] = (_Float16)(x - (float)h1[0]);
-  x = v.y * sc; h1[1] = (_Float16)x; h2[1] = (_Float16)(x - (float)h1[1]);
-  x = v.z * sc; h1[2] = (_Float16)x; h2[2] = (_Float16)(x - (float)h1[2]);
-  x = v.w * sc; h1[3] = (_Float16)x; h2[3] = (_Float16)(x - (float)h1[3]);
-  *reinterpret_cast<f16x4*>(dst) = h1;
-  *reinterpret_cast<f16x4*>(dst + aplane) = h2;
-}
-
-// VK / EK >= 0 pin the view / epilogue kind at compile time: the interpreted switches of cnr_views.h fold away and each
-// instantiation only allocates the registers its own prologue and epilogue need (-1 = generic, interpreted at run time).
-// PLAIN promises an epilogue without tail fill and without a split point (most launches): that code folds away as well.
-// K17 admits a 17th k16 block (K up to 272: the layers whose input is a 256-wide hidden vector plus a few concatenated columns).
-template <int VK, int EK, bool PLAIN, bool K17 = false>
-__global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const LayerGemm g_in, int tiles_per_wg, int wrows) {
-  constexpr int NKB = K17 ? 17 : 16;
-  LayerGemm g = g_in;
-  if (VK >= 0) g.A.kind = VK;
-  if (EK >= 0) g.E.kind = EK;
-  if (PLAIN) { g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30; }
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long Pn = g.P_dev ? (long)*g.P_dev : g.P;
-  const long ntiles = (Pn + WS_TP - 1) / WS_TP;
-  const long t0 = (long)blockIdx.x * tiles_per_wg;
-  if (t0 >= ntiles) return;
-  long t1 = t0 + tiles_per_wg;
-  if (t1 > ntiles) t1 = ntiles;
-  const int nkb = (g.K + 15) >> 4;              // 1..NKB k16 blocks
-  const int kpad = nkb * 16;
-  const int ald = kpad * 2 + 16;                // bytes per LDS row of one plane (+16: conflict-free ds_read_b128)
-  const int aplane = WS_TP * ald;
-  const int abuf = 2 * aplane + 128;            // two planes + 32 row scales
-  float* T = reinterpret_cast<float*>(smem_b + 2 * abuf) + wave * (32 * WS_TLD);
-  const int c0 = g.col0 + wave * 32;            // this wave's first output column
-  const bool has_w = c0 < wrows;
-  const int ncols_live = g.E.n_out + (g.E.tail_src ? g.E.tail_n : 0);
-
-  // ---- resident weights (two f16 planes of this wave's 32 rows of W)
-  f16x8 w1[NKB], w2[NKB];
-  {
-    const unsigned short* wp = g.Wp + (long)(has_w ? c0 + (lane & 31) : 0) * g.ldw + (lane >> 5) * 8;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      if (kb < nkb) {
-        w1[kb] = *reinterpret_cast<const f16x8*>(wp + kb * 16);
-        w2[kb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 16);
-      }
-    }
-  }
-  f4 wsc = {1.f, 1.f, 1.f, 1.f};               // inverse column scales of the 4 columns this lane finishes in the epilogue
-  if (has_w) wsc = *reinterpret_cast<const f4*>(g.wscale + c0 + (lane & 7) * 4);
-  const int ecol = c0 + (lane & 7) * 4;         // ... and their epilogue path / bias (fixed per lane for the whole launch)
-  const bool efast = epi_fast4(g.E, ecol);
-  f4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (efast) bias4 = epi_bias4(g.E, ecol);
-
-  // ---- staging map: 16 threads per row, 4 consecutive columns each, up to 4 passes of 64 columns
-  const int srow = tid >> 4, scol = (tid & 15) * 4;
-  const bool pv0 = scol < kpad, pv1 = 64 + scol < kpad, pv2 = 128 + scol < kpad, pv3 = 192 + scol < kpad;
-  const bool pv4 = K17 && 256 + scol < kpad;   // 17th block: 4 of the 16 threads of a row
-  Raw4 r0, r1, r2, r3, r4;
-  const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-  r0.a = z4; r0.b = z4; r1 = r0; r2 = r0; r3 = r0; r4 = r0;
-#define WS_FETCH_TILE(tile_)                                                      \
-  {                                                                               \
-    long row_ = (tile_) * WS_TP + srow; if (row_ >= Pn) row_ = Pn - 1;            \
-    if (pv0) r0 = view_fetch4(g.A, row_, scol);                                   \
-    if (pv1) r1 = view_fetch4(g.A, row_, 64 + scol);                              \
-    if (pv2) r2 = view_fetch4(g.A, row_, 128 + scol);                             \
-    if (pv3) r3 = view_fetch4(g.A, row_, 192 + scol);                             \
-    if (K17 && pv4) r4 = view_fetch4(g.A, row_, 256 + scol);                      \
-  }
-#define WS_PUT_TILE(buf_, tile_)                                                  \
-  {                                                                               \
-    const f4 v0 = pv0 ? view_finish4(g.A, r0, scol) : z4;                         \
-    const f4 v1 = pv1 ? view_finish4(g.A, r1, 64 + scol) : z4;                    \
-    const f4 v2 = pv2 ? view_finish4(g.A, r2, 128 + scol) : z4;                   \
-    const f4 v3 = pv3 ? view_finish4(g.A, r3, 192 + scol) : z4;                   \
-    const f4 v4 = (K17 && pv4) ? view_finish4(g.A, r4, 256 + scol) : z4;          \
-    float mx = fmaxf(fmaxf(fmaxf(ws_absmax4(v0), ws_absmax4(v1)), fmaxf(ws_absmax4(v2), ws_absmax4(v3))), ws_absmax4(v4)); \
-    _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16)); \
-    float sc = 1.0f;                                                              \
-    if (mx > 0.0f && mx < 3.0e38f) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); } /* 2^e_ clamp: subnormal rows must not overflow the scale */ \
-    unsigned char* dst = smem_b + (buf_) * abuf + srow * ald + scol * 2;          \
-    if (pv0) ws_put4(v0, sc, dst, aplane);                                        \
-    if (pv1) ws_put4(v1, sc, dst + 128, aplane);                                  \
-    if (pv2) ws_put4(v2, sc, dst + 256, aplane);                                  \
-    if (pv3) ws_put4(v3, sc, dst + 384, aplane);                                  \
-    if (K17 && pv4) ws_put4(v4, sc, dst + 512, aplane);                           \
-    if ((tid & 15) == 0) {                                                        \
-      reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
-      const long prow_ = (tile_) * WS_TP + srow;                                  \
-      if (g.rs_out && prow_ < Pn) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : 0.0f; /* 0 marks an all-zero row */ \
-    }                                                                             \
-  }
-#define WS_MFMA(kb_)                                                                               \
-  if ((kb_) < nkb) {                                                                               \
-    const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + (kb_) * 32);                             \
-    const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + aplane + (kb_) * 32);                    \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb_], acc, 0, 0, 0);                       \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb_], acc, 0, 0, 0);                       \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb_], acc, 0, 0, 0);                       \
-  }
-
-  // Waves 0..3 (rows 0..15 of a tile) and waves 4..7 (rows 16..31) share the SIMDs pairwise and run half an iteration out of
-  // phase: the late group converts + stores its half of tile t+1 (fetched one iteration earlier) and fetches tile t+2 BEFORE
-  // its MFMAs of tile t, the early group fetches tile t+1 before and stores it after -- so one wave of each SIMD is in the
-  // matrix pipe while the other does prologue math / LDS stores / epilogue.  One barrier per tile.
-  const bool late = wave >= 4;
-  WS_FETCH_TILE(t0)
-  WS_PUT_TILE(0, t0)
-  if (late && t0 + 1 < t1) WS_FETCH_TILE(t0 + 1)
-  __syncthreads();
-
-  for (long t = t0; t < t1; ++t) {
-    const int buf = (int)((t - t0) & 1);
-    const bool more = t + 1 < t1;
-    if (!late) {
-      if (more) WS_FETCH_TILE(t + 1)
-    } else if (more) {
-      WS_PUT_TILE(buf ^ 1, t + 1)
-      if (t + 2 < t1) WS_FETCH_TILE(t + 2)
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-    const unsigned char* Ab = smem_b + buf * abuf + (lane & 31) * ald + (lane >> 5) * 16;
-    if (has_w) {
-      WS_MFMA(0) WS_MFMA(1) WS_MFMA(2) WS_MFMA(3) WS_MFMA(4) WS_MFMA(5) WS_MFMA(6) WS_MFMA(7)
-      WS_MFMA(8) WS_MFMA(9) WS_MFMA(10) WS_MFMA(11) WS_MFMA(12) WS_MFMA(13) WS_MFMA(14) WS_MFMA(15)
-      if (K17) { WS_MFMA(NKB - 1) }
-    }
-    // epilogue of this 32 x 32 tile: undo the exact row / column scales, then the fused epilogue on 4 columns per lane.
-    // The side inputs of all four row groups are requested first: one memory round trip per tile, and no load has to
-    // wait behind the stores of the previous row group.
-    if (c0 < ncols_live) {
-      const float* rs = reinterpret_cast<const float*>(smem_b + buf * abuf + 2 * aplane);
-      const int hi = lane >> 5, cl = lane & 31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * WS_TLD + cl] = acc[r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      constexpr int EG = (EK == EK_SWEEP || EK == EK_VBACK) ? 2 : 4;   // row groups whose side inputs are in flight together (register budget)
-#pragma unroll
-      for (int i0 = 0; i0 < 4; i0 += EG) {
-        EpiRaw4 er[EG];
-#pragma unroll
-        for (int i = 0; i < EG; ++i) {
-          long row = t * WS_TP + (lane >> 3) + 8 * (i0 + i);
-          if (row >= Pn) row = Pn - 1;
-          if (efast) er[i] = epi_fetch4(g.E, row, ecol);
-        }
-#pragma unroll
-        for (int i = 0; i < EG; ++i) {
-          const int rr = (lane >> 3) + 8 * (i0 + i), cc = (lane & 7) * 4;
-          const long row = t * WS_TP + rr;
-          const float rsc = rs[rr];
-          f4 v = *reinterpret_cast<const f4*>(T + rr * WS_TLD + cc);
-          v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
-          if (row < Pn) {
-            if (efast) epi_finish4(g.E, row, ecol, v, bias4, er[i]);
-            else epi_apply4(g.E, row, ecol, v);
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (!late && more) WS_PUT_TILE(buf ^ 1, t + 1)
-    __syncthreads();
-  }
-#undef WS_FETCH_TILE
-#undef WS_PUT_TILE
-#undef WS_MFMA
-}
-
-template <int VK, int EK, bool PLAIN, bool K17 = false>
-static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
-  const int nkb = (g.K + 15) / 16;
-  const int abuf = 2 * WS_TP * (nkb * 32 + 16) + 128;
-  const size_t lds = (size_t)2 * abuf + (size_t)8 * 32 * WS_TLD * sizeof(float);
-  const long ntiles = (g.P + WS_TP - 1) / WS_TP;
-  if (ntiles == 0) return;
-  static const int ws_wgs = getenv("CNR_WS_WGS") ? atoi(getenv("CNR_WS_WGS")) : 256;       // tuning knobs (defaults measured on MI355X)
-  static const int ws_mintpw = getenv("CNR_WS_MINTPW") ? atoi(getenv("CNR_WS_MINTPW")) : 8;
-  long tpw = (ntiles + ws_wgs - 1) / ws_wgs;   // one workgroup per CU: the weights are loaded once per CU (measured best of 256 / 512 / 768 / 1024)
-  if (tpw < ws_mintpw) tpw = ws_mintpw;
-  const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN, K17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
-  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN, K17>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
-}
-
-// K in (256, 272]: only the combinations the plan needs are instantiated with the 17th k-block
-static bool ws_k17_supported(const LayerGemm& g) {
-  const bool plain = g.E.tail_src == nullptr && g.E.split == (1 << 30);
-  return plain && g.A.kind == VK_DIRECT && (g.E.kind == EK_RELU || g.E.kind == EK_VBACK);
-}
-
-static void launch_layer_gemm_ws(const LayerGemm& g, int wrows, cnr_stream s) {
-  static const bool generic_only = getenv("CNR_WS_GENERIC") != nullptr;   // debugging aid: interpreted kernel for every combination
-  const int vk = g.A.kind, ek = g.E.kind;
-  const bool plain = g.E.tail_src == nullptr && g.E.split == (1 << 30);
-  if (g.K > 256) {
-    if (ek == EK_RELU) launch_ws_t<VK_DIRECT, EK_RELU, true, true>(g, wrows, s);
-    else launch_ws_t<VK_DIRECT, EK_VBACK, true, true>(g, wrows, s);
-    return;
-  }
-#define WS_CASE(V_, E_)                                              \
-  if (!generic_only && vk == V_ && ek == E_) {                       \
-    if (plain) launch_ws_t<V_, E_, true>(g, wrows, s);               \
-    else launch_ws_t<V_, E_, false>(g, wrows, s);                    \
-    return;                                                          \
-  }
-  // the combinations the render plan issues on 256-wide layers (cnr_plan.cpp)
-  WS_CASE(VK_SOFTPLUS, EK_STORE) WS_CASE(VK_DIRECT, EK_STORE) WS_CASE(VK_SOFTPLUS, EK_SDF_TOP)
-  WS_CASE(VK_SIGMUL, EK_STORE) WS_CASE(VK_SIGMUL_ROW, EK_STORE) WS_CASE(VK_SIGMUL, EK_SPLIT)
-  WS_CASE(VK_DIRECT, EK_RELU) WS_CASE(VK_DIRECT, EK_RELU_MASK) WS_CASE(VK_DIRECT, EK_SPLIT)
-  WS_CASE(VK_DIRECT, EK_SWEEP) WS_CASE(VK_DIRECT, EK_VBACK)
-#undef WS_CASE
-  launch_ws_t<-1, -1, false>(g, wrows, s);
-}
 
 static void dispatch_layer_gemm(const LayerGemm& g, int nt, cnr_stream s) {
   switch (nt) {
@@ -421,10 +27,7 @@ static void dispatch_layer_gemm(const LayerGemm& g, int nt, cnr_stream s) {
     case 2: launch_layer_gemm<2>(g, s); break;
     case 3: launch_layer_gemm<3>(g, s); break;
     case 4: launch_layer_gemm<4>(g, s); break;
-    case 5: launch_layer_gemm<5>(g, s); break;
-    case 6: launch_layer_gemm<6>(g, s); break;
-    case 7: launch_layer_gemm<7>(g, s); break;
-    case 8: launch_layer_gemm<8>(g, s); break;
+    case 5: case 6: case 7: case 8: launch_layer_gemm_wide(g, nt, s); break;   // cnr_gemm_wide.hip
     default:
       if (g_first_error == hipSuccess) { g_first_error = hipErrorInvalidValue; g_first_error_where = "layer_gemm: tile count"; }
       return;
@@ -466,735 +69,6 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
     }
   }
   CNR_LAUNCH_CHECK("layer_gemm");
-}
-
-// ================================================================================================
-// weight-gradient GEMM:  dW[n][k] = sum_pt X[pt][n] * Y[pt][k]
-// 8 waves as WR x WC, each wave (MT*32) x (KT*32); block tile TN x TK; points streamed 16 at a time.
-// ================================================================================================
-// points per slab: 16 for the square tile; the skinny tail tiles are latency-bound streams, so they take as many as LDS holds
-constexpr int dw_bp(int tn, int tk) { return tn + tk <= 288 ? 64 : (tn + tk <= 320 ? 48 : 16); }
-
-template <int WR, int WC, int MT, int KT>
-__global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, int k0) {
-  constexpr int TN = WR * MT * 32, TK = WC * KT * 32;
-  constexpr int DW_BP = dw_bp(TN, TK);
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;                       // [2][16][TN]
-  float* Ys = smem + 2 * DW_BP * TN;      // [2][16][TK]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave / WC, wc = wave % WC;
-  const long chunk = blockIdx.x;
-  const long p_begin = chunk * g.chunk_pts;
-  long p_end = p_begin + g.chunk_pts;
-  if (p_end > g.P) p_end = g.P;
-  const int nslab_pair = p_end > p_begin ? (int)((p_end - p_begin + DW_BP - 1) / DW_BP) : 0;
-  const int nslab = nslab_pair * g.npairs;
-  constexpr int NX = (DW_BP * TN / 4 + 511) / 512, NY = (DW_BP * TK / 4 + 511) / 512;
-  constexpr bool NX_EXACT = (DW_BP * TN / 4) % 512 == 0, NY_EXACT = (DW_BP * TK / 4) % 512 == 0;
-
-  f32x16 acc[MT][KT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < KT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  f4 rxa[NX], rxb[NX], rya[NY], ryb[NY];
-  bool okx[NX], oky[NY];
-  int staged_pair = 0;
-  float csum = 0.0f;
-  const bool want_colsum = g.colsum != nullptr && k0 == 0;
-
-#define DW_LOAD_SLAB(s_)                                                                                  \
-  {                                                                                                       \
-    const int pair_ = (s_) / nslab_pair;                                                                  \
-    staged_pair = pair_;                                                                                  \
-    const long pbase_ = p_begin + (long)((s_) - pair_ * nslab_pair) * DW_BP;                              \
-    const View& X_ = g.X[pair_];                                                                          \
-    const View& Y_ = g.Y[pair_];                                                                          \
-    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
-      const int idx = tid + i * 512;                                                                      \
-      if (NX_EXACT || idx < DW_BP * TN / 4) {                                                             \
-        const int pl = idx / (TN / 4), c4 = idx % (TN / 4);                                               \
-        long pt = pbase_ + pl;                                                                            \
-        okx[i] = pt < p_end;                                                                              \
-        if (!okx[i]) pt = p_end - 1;                                                                      \
-        const Raw4 q_ = view_fetch4(X_, pt, n0 + c4 * 4);                                                 \
-        rxa[i] = q_.a; rxb[i] = q_.b;                                                                     \
-      }                                                                                                   \
-    }                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < NY; ++i) {                                                      \
-      const int idx = tid + i * 512;                                                                      \
-      if (NY_EXACT || idx < DW_BP * TK / 4) {                                                             \
-        const int pl = idx / (TK / 4), c4 = idx % (TK / 4);                                               \
-        long pt = pbase_ + pl;                                                                            \
-        oky[i] = pt < p_end;                                                                              \
-        if (!oky[i]) pt = p_end - 1;                                                                      \
-        const Raw4 q_ = view_fetch4(Y_, pt, k0 + c4 * 4);                                                 \
-        rya[i] = q_.a; ryb[i] = q_.b;                                                                     \
-      }                                                                                                   \
-    }                                                                                                     \
-  }
-#define DW_STORE_SLAB(buf_)                                                                               \
-  {                                                                                                       \
-    const f4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                                  \
-    _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
-      const int idx = tid + i * 512;                                                                      \
-      if (NX_EXACT || idx < DW_BP * TN / 4) {                                                             \
-        Raw4 q_; q_.a = rxa[i]; q_.b = rxb[i];                                                            \
-        const f4 v_ = view_finish4(g.X[staged_pair], q_, n0 + (idx % (TN / 4)) * 4);                      \
-        *reinterpret_cast<f4*>(Xs + (buf_) * DW_BP * TN + idx * 4) = okx[i] ? v_ : z4_;                   \
-      }                                                                                                   \
-    }                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < NY; ++i) {                                                      \
-      const int idx = tid + i * 512;                                                                      \
-      if (NY_EXACT || idx < DW_BP * TK / 4) {                                                             \
-        Raw4 q_; q_.a = rya[i]; q_.b = ryb[i];                                                            \
-        const f4 v_ = view_finish4(g.Y[staged_pair], q_, k0 + (idx % (TK / 4)) * 4);                      \
-        *reinterpret_cast<f4*>(Ys + (buf_) * DW_BP * TK + idx * 4) = oky[i] ? v_ : z4_;                   \
-      }                                                                                                   \
-    }                                                                                                     \
-  }
-
-  if (nslab > 0) {
-    DW_LOAD_SLAB(0)
-    DW_STORE_SLAB(0)
-  }
-  __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nslab) DW_LOAD_SLAB(s + 1)
-    const float* Xb = Xs + buf * DW_BP * TN + (lane >> 5) * TN + wr * MT * 32 + (lane & 31);
-    const float* Yb = Ys + buf * DW_BP * TK + (lane >> 5) * TK + wc * KT * 32 + (lane & 31);
-#pragma unroll
-    for (int st = 0; st < DW_BP / 2; ++st) {
-      float a[MT], b[KT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = Xb[st * 2 * TN + i * 32];
-#pragma unroll
-      for (int j = 0; j < KT; ++j) b[j] = Yb[st * 2 * TK + j * 32];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (want_colsum && s < nslab_pair && tid < TN) {   // bias gradient: column sums of the first X operand
-      const float* xc = Xs + buf * DW_BP * TN + tid;
-#pragma unroll
-      for (int pl = 0; pl < DW_BP; ++pl) csum += xc[pl * TN];
-    }
-    if (s + 1 < nslab) DW_STORE_SLAB(buf ^ 1)
-    __syncthreads();
-  }
-#undef DW_LOAD_SLAB
-#undef DW_STORE_SLAB
-
-  float* out = g.partial + chunk * (long)g.Npad * g.ldk;
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-      const int kk = k0 + wc * KT * 32 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wr * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < g.Npad && kk < g.ldk) out[(long)n * g.ldk + kk] = acc[i][j][r];
-      }
-    }
-  if (want_colsum && tid < TN && n0 + tid < g.Npad) g.colsum[chunk * g.Npad + n0 + tid] = csum;
-}
-
-template <int WR, int WC, int MT, int KT>
-static void launch_dw(const DwGemm& g, int n0, int k0, cnr_stream s) {
-  constexpr int TN = WR * MT * 32, TK = WC * KT * 32;
-  constexpr int DW_BP = dw_bp(TN, TK);
-  const size_t lds = (size_t)(2 * DW_BP * (TN + TK)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_kernel<WR, WC, MT, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  const int tn_ = (g.N - n0) < TN ? (g.N - n0) : TN, tk_ = (g.K - k0) < TK ? (g.K - k0) : TK;
-  TimingScope ts_("dw_gemm", 1, WR * 1000 + WC * 100 + MT * 10 + KT, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
-  hipLaunchKernelGGL((dw_gemm_kernel<WR, WC, MT, KT>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
-}
-
-// ================================================================================================
-// weight-gradient GEMM, 256 x 256 output tile, split-bf16 matrix cores
-//
-// Same output-stationary structure as dw_gemm_kernel<4,2,2,4> (128 accumulator registers per wave, one workgroup per point
-// chunk), but each fp32 operand element is split into three bf16 terms x = x1 + x2 + x3 (8 + 8 + 8 significand bits, the fp32
-// exponent range is kept, so no scaling is needed along the contraction over points) and each product is evaluated as six
-// v_mfma_f32_32x32x16_bf16 (x1y1 + x1y2 + x2y1 + x2y2 + x1y3 + x3y1, small terms first; the dropped terms are < 2^-25
-// relative).  6 x 32 cycles per 32x32x16 block against 8 x 64 for v_mfma_f32_32x32x2_f32: 2.7x the matrix rate at fp32 accuracy.
-//
-// LDS: per operand and plane the 16-point slab is stored as [half h][j = n % 4][c = n / 4][8 points] bf16 with 1088-byte
-// j-regions: the staging threads (4 columns x 4 points each) write 8-byte point quads, adjacent lanes adjacent quads
-// (conflict-free), and an MFMA lane reads the 16 bytes of its row n / point half h (conflict-free: 16 lanes cover 16
-// distinct 16-byte bank groups).
-// ================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int DX_JREG = 1088;                 // bytes per j-region (64 columns x 16 bytes + 64 bytes of bank rotation)
-constexpr int DX_HALF = 4 * DX_JREG;          // one point half (8 points) of one plane
-constexpr int DX_PLANE = 2 * DX_HALF;         // one bf16 plane of a 16-point x 256-column slab
-constexpr int DX_OPER = 3 * DX_PLANE;         // three planes
-constexpr int DX_BUF = 2 * DX_OPER;           // X and Y
-
-__device__ __forceinline__ void dx_split3(float x, __bf16& h1, __bf16& h2, __bf16& h3) {
-  h1 = (__bf16)x;
-  float r = x - (float)h1;
-  h2 = (__bf16)r;
-  r = r - (float)h2;
-  h3 = (__bf16)r;
-}
-
-// XK0 / YK0 / XK1 / YK1 >= 0 pin the view kinds of the operand pairs at compile time (-1 = interpreted at run time)
-template <int XK0, int YK0, int XK1, int YK1>
-__global__ __launch_bounds__(512, 1) void dw_gemm_bx_kernel(const DwGemm g_in, int n0, int k0) {
-  DwGemm g = g_in;
-  if (XK0 >= 0) g.X[0].kind = XK0;
-  if (YK0 >= 0) g.Y[0].kind = YK0;
-  if (XK1 >= 0) g.X[1].kind = XK1;
-  if (YK1 >= 0) g.Y[1].kind = YK1;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;               // 4 x 2 waves, 64 x 128 outputs each
-  // 16-point slabs are dealt round-robin to the workgroups (slab = i * nchunk + chunk): at any moment the CUs read one
-  // contiguous stretch of X and Y, which spreads over all HBM channels; the partial sums stay in a fixed order
-  const long chunk = blockIdx.x;
-  const long p_end = g.P;
-  const long total_slabs = (g.P + 15) / 16;
-  const int nslab_pair = chunk < total_slabs ? (int)((total_slabs - chunk + g.nchunk - 1) / g.nchunk) : 0;
-  const int nslab = nslab_pair * g.npairs;
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  // staging role: threads 0..255 stage X, 256..511 stage Y; each 4 columns x 4 points
-  const bool is_y = tid >= 256;
-  const int st = tid & 255;
-  const int qlo = st & 1, c4 = (st >> 1) & 63, qhi = st >> 7;
-  const int q = qhi * 2 + qlo;                          // point quad of the slab
-  const int scol = (is_y ? k0 : n0) + c4 * 4;
-  unsigned char* const sdst = smem_d + (is_y ? DX_OPER : 0) + qhi * DX_HALF + c4 * 16 + qlo * 8;
-  f4 ra[4], rb[4];
-  bool okp[4];
-  int staged_pair = 0;
-  f4 csum = {0.f, 0.f, 0.f, 0.f};
-  const bool want_colsum = g.colsum != nullptr && k0 == 0;
-
-#define DX_FETCH_(V_)                                                                      \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
-    long pt = pbase_ + i;                                                                  \
-    okp[i] = pt < p_end;                                                                   \
-    if (!okp[i]) pt = p_end - 1;                                                           \
-    const Raw4 q_ = view_fetch4(V_, pt, scol);                                             \
-    ra[i] = q_.a; rb[i] = q_.b;                                                            \
-  }
-#define DX_LOAD_SLAB(s_)                                                                   \
-  {                                                                                        \
-    const int pair_ = (s_) / nslab_pair;                                                   \
-    staged_pair = pair_;                                                                   \
-    const long pbase_ = ((long)((s_) - pair_ * nslab_pair) * g.nchunk + chunk) * 16 + q * 4; \
-    if (pair_ == 0) { if (is_y) { DX_FETCH_(g.Y[0]) } else { DX_FETCH_(g.X[0]) } }         \
-    else { if (is_y) { DX_FETCH_(g.Y[1]) } else { DX_FETCH_(g.X[1]) } }                    \
-  }
-#define DX_FINISH_(V_)                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
-    Raw4 q_; q_.a = ra[i]; q_.b = rb[i];                                                   \
-    v_[i] = okp[i] ? view_finish4(V_, q_, scol) : z4_;                                     \
-  }
-#define DX_STORE_SLAB(buf_)                                                                \
-  {                                                                                        \
-    const f4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                   \
-    f4 v_[4];                                                                              \
-    if (staged_pair == 0) { if (is_y) { DX_FINISH_(g.Y[0]) } else { DX_FINISH_(g.X[0]) } } \
-    else { if (is_y) { DX_FINISH_(g.Y[1]) } else { DX_FINISH_(g.X[1]) } }                  \
-    if (want_colsum && !is_y && staged_pair == 0) {                                        \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) { csum.x += v_[i].x; csum.y += v_[i].y; csum.z += v_[i].z; csum.w += v_[i].w; } \
-    }                                                                                      \
-    unsigned char* d_ = sdst + (buf_) * DX_BUF;                                            \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
-      bf16x4 h1, h2, h3;                                                                   \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) { __bf16 a_, b_, c_; dx_split3(v_[i][j], a_, b_, c_); h1[i] = a_; h2[i] = b_; h3[i] = c_; } \
-      *reinterpret_cast<bf16x4*>(d_ + j * DX_JREG) = h1;                                   \
-      *reinterpret_cast<bf16x4*>(d_ + DX_PLANE + j * DX_JREG) = h2;                        \
-      *reinterpret_cast<bf16x4*>(d_ + 2 * DX_PLANE + j * DX_JREG) = h3;                    \
-    }                                                                                      \
-  }
-
-  // The X-staging waves (0..3) and the Y-staging waves (4..7) share the SIMDs pairwise and run half an iteration out of
-  // phase: while one wave of a SIMD issues its MFMAs, the other converts and stores its part of the next slab, so the
-  // matrix pipe and the VALU / LDS-store path overlap.  X waves: load(s+1) | MFMA(s) | store(s+1);  Y waves: store(s+1),
-  // load(s+2) | MFMA(s).  One barrier per slab.
-  if (nslab > 0) {
-    DX_LOAD_SLAB(0)
-    DX_STORE_SLAB(0)
-    if (is_y && nslab > 1) DX_LOAD_SLAB(1)
-  }
-  __syncthreads();
-  // operand fragment addresses of this lane: row / column (lane & 31) of each 32-wide tile, point half (lane >> 5)
-  const int ln = lane & 31, lh = lane >> 5;
-  const int xoff = lh * DX_HALF + (ln & 3) * DX_JREG + (wr * 16 + (ln >> 2)) * 16;              // + i * 8 * 16 per n-tile
-  const int yoff = DX_OPER + lh * DX_HALF + (ln & 3) * DX_JREG + (wc * 32 + (ln >> 2)) * 16;    // + j * 8 * 16 per k-tile
-  for (int s = 0; s < nslab; ++s) {
-    const int buf = s & 1;
-    if (!is_y) {
-      if (s + 1 < nslab) DX_LOAD_SLAB(s + 1)
-    } else if (s + 1 < nslab) {
-      DX_STORE_SLAB(buf ^ 1)
-      if (s + 2 < nslab) DX_LOAD_SLAB(s + 2)
-    }
-    const unsigned char* B_ = smem_d + buf * DX_BUF;
-    bf16x8 a[2][3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(B_ + xoff + p * DX_PLANE + i * 128);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bf16x8 b[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(B_ + yoff + p * DX_PLANE + j * 128);
-      // the two row tiles alternate so that back-to-back MFMAs never depend on each other
-      f32x16 c0 = acc[0][j], c1 = acc[1][j];
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][2], b[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][2], b[0], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b[2], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b[2], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b[1], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b[1], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], b[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][1], b[0], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b[1], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b[1], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][0], b[0], c1, 0, 0, 0);
-      acc[0][j] = c0; acc[1][j] = c1;
-    }
-    if (!is_y && s + 1 < nslab) DX_STORE_SLAB(buf ^ 1)
-    __syncthreads();
-  }
-#undef DX_LOAD_SLAB
-#undef DX_STORE_SLAB
-#undef DX_FETCH_
-#undef DX_FINISH_
-
-  float* out = g.partial + chunk * (long)g.Npad * g.ldk;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kk = k0 + wc * 128 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < g.Npad && kk < g.ldk) out[(long)n * g.ldk + kk] = acc[i][j][r];
-      }
-    }
-  if (want_colsum) {   // bias gradient: the four point-quad owners of a column group add their sums in a fixed order
-    float* cs = reinterpret_cast<float*>(smem_d);          // [4 quads][256 columns]; the slab buffers are dead now
-    if (!is_y) *reinterpret_cast<f4*>(cs + q * 256 + c4 * 4) = csum;
-    __syncthreads();
-    if (tid < 256 && n0 + tid < g.Npad) g.colsum[chunk * g.Npad + n0 + tid] = ((cs[tid] + cs[256 + tid]) + cs[512 + tid]) + cs[768 + tid];
-  }
-}
-
-template <int XK0, int YK0, int XK1, int YK1>
-static void launch_dw_bx_t(const DwGemm& g, int n0, int k0, cnr_stream s) {
-  const size_t lds = (size_t)2 * DX_BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_bx_kernel<XK0, YK0, XK1, YK1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  const int tn_ = (g.N - n0) < 256 ? (g.N - n0) : 256, tk_ = (g.K - k0) < 256 ? (g.K - k0) : 256;
-  TimingScope ts_("dw_gemm_bx", 1, 4224, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
-  hipLaunchKernelGGL((dw_gemm_bx_kernel<XK0, YK0, XK1, YK1>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
-}
-
-static void launch_dw_bx(const DwGemm& g, int n0, int k0, cnr_stream s) {
-  const int x0 = g.X[0].kind, y0 = g.Y[0].kind, x1 = g.npairs > 1 ? g.X[1].kind : -1, y1 = g.npairs > 1 ? g.Y[1].kind : -1;
-#define DX_CASE(A_, B_, C_, D_) if (x0 == A_ && y0 == B_ && x1 == C_ && y1 == D_) { launch_dw_bx_t<A_, B_, C_, D_>(g, n0, k0, s); return; }
-  // the operand combinations of the render plan (cnr_plan.cpp): MLP layers, SDF value + gradient-chain pairs
-  DX_CASE(VK_DIRECT, VK_DIRECT, -1, -1)
-  DX_CASE(VK_DIRECT, VK_SOFTPLUS, -1, -1)
-  DX_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL, VK_DIRECT)
-  DX_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL_ROW, VK_DIRECT)
-  DX_CASE(VK_DIRECT, VK_SOFTPLUS, VK_CONST_COL0, VK_DIRECT)
-#undef DX_CASE
-  launch_dw_bx_t<-1, -1, -1, -1>(g, n0, k0, s);
-}
-
-// ================================================================================================
-// weight-gradient GEMM, 256 x 256 output tile, split-f16 matrix cores (three MFMAs per product instead of six)
-//
-// Along the contraction (points) a scale can only be used if it cancels per point: X'[pt] = X[pt] * sx[pt] (the power of
-// two that lifts the row into the top f16 binade -- emitted for free by the layer GEMM that consumed the same operand,
-// LayerGemm::rs_out) and Y'[pt] = Y[pt] * 2^G / sx[pt], so X'^T Y' = 2^G X^T Y exactly.  G = 1 + min over points of
-// log2(sx * sy) (be_dw_scale) keeps every Y' row below 2^15; points whose product is far below the largest one lose relative
-// precision in Y' but their absolute error stays below 2^-40 of the largest term.  Both operands are split hi + lo
-// (11 + 11 bits) and x1 y2 + x2 y1 + x1 y1 is accumulated in fp32; the result is scaled back by 2^-G (exact).
-// Structure, LDS layout and wave phase shift as dw_gemm_bx_kernel (two planes per operand instead of three).
-// ================================================================================================
-constexpr int DH_OPER = 2 * DX_PLANE;
-constexpr int DH_BUF = 2 * DH_OPER;
-
-template <int XK0, int YK0, int XK1, int YK1>
-__global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, int n0, int k0) {
-  DwGemm g = g_in;
-  if (XK0 >= 0) g.X[0].kind = XK0;
-  if (YK0 >= 0) g.Y[0].kind = YK0;
-  if (XK1 >= 0) g.X[1].kind = XK1;
-  if (YK1 >= 0) g.Y[1].kind = YK1;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const long chunk = blockIdx.x;
-  const long p_end = g.P;
-  const long total_slabs = (g.P + 15) / 16;
-  const int nslab_pair = chunk < total_slabs ? (int)((total_slabs - chunk + g.nchunk - 1) / g.nchunk) : 0;
-  const int nslab = nslab_pair * g.npairs;
-  int G = *g.gexp;
-  if (G > 250 || G < -250) G = 0;                         // no point with two non-zero rows: everything is zero anyway
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  const bool is_y = tid >= 256;
-  const int st = tid & 255;
-  const int qlo = st & 1, c4 = (st >> 1) & 63, qhi = st >> 7;
-  const int q = qhi * 2 + qlo;
-  const int scol = (is_y ? k0 : n0) + c4 * 4;
-  unsigned char* const sdst = smem_d + (is_y ? DH_OPER : 0) + qhi * DX_HALF + c4 * 16 + qlo * 8;
-  f4 ra[4], rb[4];
-  float rsx[4];                                           // sx of the 4 points this thread stages
-  bool okp[4];
-  int staged_pair = 0;
-  f4 csum = {0.f, 0.f, 0.f, 0.f};
-  const bool want_colsum = g.colsum != nullptr && k0 == 0;
-
-#define DH_FETCH_(V_)                                                                      \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
-    long pt = pbase_ + i;                                                                  \
-    okp[i] = pt < p_end;                                                                   \
-    if (!okp[i]) pt = p_end - 1;                                                           \
-    const Raw4 q_ = view_fetch4(V_, pt, scol);                                             \
-    ra[i] = q_.a; rb[i] = q_.b;                                                            \
-    rsx[i] = sxp_[pt];                                                                     \
-  }
-#define DH_LOAD_SLAB(s_)                                                                   \
-  {                                                                                        \
-    const int pair_ = (s_) / nslab_pair;                                                   \
-    staged_pair = pair_;                                                                   \
-    const long pbase_ = ((long)((s_) - pair_ * nslab_pair) * g.nchunk + chunk) * 16 + q * 4; \
-    const float* sxp_ = pair_ == 0 ? g.sx[0] : g.sx[1];                                    \
-    if (pair_ == 0) { if (is_y) { DH_FETCH_(g.Y[0]) } else { DH_FETCH_(g.X[0]) } }         \
-    else { if (is_y) { DH_FETCH_(g.Y[1]) } else { DH_FETCH_(g.X[1]) } }                    \
-  }
-#define DH_FINISH_(V_)                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
-    Raw4 q_; q_.a = ra[i]; q_.b = rb[i];                                                   \
-    v_[i] = okp[i] ? view_finish4(V_, q_, scol) : z4_;                                     \
-  }
-#define DH_STORE_SLAB(buf_)                                                                \
-  {                                                                                        \
-    const f4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                   \
-    f4 v_[4];                                                                              \
-    if (staged_pair == 0) { if (is_y) { DH_FINISH_(g.Y[0]) } else { DH_FINISH_(g.X[0]) } } \
-    else { if (is_y) { DH_FINISH_(g.Y[1]) } else { DH_FINISH_(g.X[1]) } }                  \
-    if (want_colsum && !is_y && staged_pair == 0) {                                        \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) { csum.x += v_[i].x; csum.y += v_[i].y; csum.z += v_[i].z; csum.w += v_[i].w; } \
-    }                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-      float f_ = rsx[i];                                                                   \
-      if (is_y) f_ = f_ > 0.0f ? ldexpf(1.0f / f_, G) : 0.0f;                              \
-      v_[i].x *= f_; v_[i].y *= f_; v_[i].z *= f_; v_[i].w *= f_;                          \
-    }                                                                                      \
-    unsigned char* d_ = sdst + (buf_) * DH_BUF;                                            \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
-      f16x4 h1, h2;                                                                        \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) { const float x_ = v_[i][j]; h1[i] = (_Float16)x_; h2[i] = (_Float16)(x_ - (float)h1[i]); } \
-      *reinterpret_cast<f16x4*>(d_ + j * DX_JREG) = h1;                                    \
-      *reinterpret_cast<f16x4*>(d_ + DX_PLANE + j * DX_JREG) = h2;                         \
-    }                                                                                      \
-  }
-
-  if (nslab > 0) {
-    DH_LOAD_SLAB(0)
-    DH_STORE_SLAB(0)
-    if (is_y && nslab > 1) DH_LOAD_SLAB(1)
-  }
-  __syncthreads();
-  const int ln = lane & 31, lh = lane >> 5;
-  const int xoff = lh * DX_HALF + (ln & 3) * DX_JREG + (wr * 16 + (ln >> 2)) * 16;
-  const int yoff = DH_OPER + lh * DX_HALF + (ln & 3) * DX_JREG + (wc * 32 + (ln >> 2)) * 16;
-  for (int s = 0; s < nslab; ++s) {
-    const int buf = s & 1;
-    if (!is_y) {
-      if (s + 1 < nslab) DH_LOAD_SLAB(s + 1)
-    } else if (s + 1 < nslab) {
-      DH_STORE_SLAB(buf ^ 1)
-      if (s + 2 < nslab) DH_LOAD_SLAB(s + 2)
-    }
-    const unsigned char* B_ = smem_d + buf * DH_BUF;
-    f16x8 a[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const f16x8*>(B_ + xoff + p * DX_PLANE + i * 128);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f16x8 b[2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) b[p] = *reinterpret_cast<const f16x8*>(B_ + yoff + p * DX_PLANE + j * 128);
-      f32x16 c0 = acc[0][j], c1 = acc[1][j];
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b[1], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b[1], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], b[0], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b[0], c1, 0, 0, 0);
-      acc[0][j] = c0; acc[1][j] = c1;
-    }
-    if (!is_y && s + 1 < nslab) DH_STORE_SLAB(buf ^ 1)
-    __syncthreads();
-  }
-#undef DH_LOAD_SLAB
-#undef DH_STORE_SLAB
-#undef DH_FETCH_
-#undef DH_FINISH_
-
-  // undo 2^G in two exact steps (G can exceed the fp32 exponent range of a single factor)
-  const float u1 = ldexpf(1.0f, -(G / 2)), u2 = ldexpf(1.0f, -(G - G / 2));
-  float* out = g.partial + chunk * (long)g.Npad * g.ldk;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kk = k0 + wc * 128 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < g.Npad && kk < g.ldk) out[(long)n * g.ldk + kk] = acc[i][j][r] * u1 * u2;
-      }
-    }
-  if (want_colsum) {
-    float* cs = reinterpret_cast<float*>(smem_d);
-    if (!is_y) *reinterpret_cast<f4*>(cs + q * 256 + c4 * 4) = csum;
-    __syncthreads();
-    if (tid < 256 && n0 + tid < g.Npad) g.colsum[chunk * g.Npad + n0 + tid] = ((cs[tid] + cs[256 + tid]) + cs[512 + tid]) + cs[768 + tid];
-  }
-}
-
-template <int XK0, int YK0, int XK1, int YK1>
-static void launch_dw_hx_t(const DwGemm& g, int n0, int k0, cnr_stream s) {
-  const size_t lds = (size_t)2 * DH_BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_hx_kernel<XK0, YK0, XK1, YK1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  const int tn_ = (g.N - n0) < 256 ? (g.N - n0) : 256, tk_ = (g.K - k0) < 256 ? (g.K - k0) : 256;
-  TimingScope ts_("dw_gemm_hx", 1, 4224, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
-  hipLaunchKernelGGL((dw_gemm_hx_kernel<XK0, YK0, XK1, YK1>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
-}
-
-static void launch_dw_hx(const DwGemm& g, int n0, int k0, cnr_stream s) {
-  const int x0 = g.X[0].kind, y0 = g.Y[0].kind, x1 = g.npairs > 1 ? g.X[1].kind : -1, y1 = g.npairs > 1 ? g.Y[1].kind : -1;
-#define DH_CASE(A_, B_, C_, D_) if (x0 == A_ && y0 == B_ && x1 == C_ && y1 == D_) { launch_dw_hx_t<A_, B_, C_, D_>(g, n0, k0, s); return; }
-  DH_CASE(VK_DIRECT, VK_DIRECT, -1, -1)
-  DH_CASE(VK_DIRECT, VK_SOFTPLUS, -1, -1)
-  DH_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL, VK_DIRECT)
-  DH_CASE(VK_DIRECT, VK_SOFTPLUS, VK_SIGMUL_ROW, VK_DIRECT)
-#undef DH_CASE
-  launch_dw_hx_t<-1, -1, -1, -1>(g, n0, k0, s);
-}
-
-// G = 1 + min over points (both pairs) of log2(sx * sy), rows with a zero scale (all-zero rows) excluded.  *gexp must hold a large
-// value on entry (be_dw_scale fills it with 0x7f bytes).  min is order independent, so the atomic keeps results deterministic.
-__global__ void dw_scale_kernel(const float* sx0, const float* sy0, const float* sx1, const float* sy1, long P, int* gexp) {
-  int best = 0x7f7f7f7f;
-  for (long pt = (long)blockIdx.x * blockDim.x + threadIdx.x; pt < P; pt += (long)gridDim.x * blockDim.x) {
-    const float a = sx0[pt], b = sy0[pt];
-    if (a > 0.0f && b > 0.0f) { const int e = ilogbf(a) + ilogbf(b) + 1; best = e < best ? e : best; }
-    if (sx1) {
-      const float c = sx1[pt], d = sy1[pt];
-      if (c > 0.0f && d > 0.0f) { const int e = ilogbf(c) + ilogbf(d) + 1; best = e < best ? e : best; }
-    }
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(best, d); best = o < best ? o : best; }
-  if ((threadIdx.x & 63) == 0) atomicMin(gexp, best);
-}
-
-void be_dw_scale(const DwGemm& g, int* gexp, cnr_stream s) {
-  (void)hipMemsetAsync(gexp, 0x7f, sizeof(int), s);
-  TimingScope ts_("dw_scale", 2, 0, g.P, 0, 0, 0, s);
-  hipLaunchKernelGGL(dw_scale_kernel, dim3(512), dim3(256), 0, s, g.sx[0], g.sy[0], g.npairs > 1 ? g.sx[1] : nullptr,
-                     g.npairs > 1 ? g.sy[1] : nullptr, g.P, gexp);
-  CNR_LAUNCH_CHECK("dw_scale");
-}
-
-// ================================================================================================
-// weight-gradient strips with one very narrow side (<= 8 columns): the 3 / 6 extra input columns of the colour and
-// relight nets, the rgb / sdf output rows.  Pure HBM streams (<= 12 FLOP per loaded byte): no matrix cores, no LDS
-// staging.  One workgroup per point chunk, 16 waves, each wave walks its own points (slabs dealt round-robin as in
-// dw_gemm_bx); a lane owns 4 columns of the wide operand x all narrow columns in registers; the 8 waves are folded
-// through LDS in a fixed order.  NARROW_X: the narrow operand is X (rows of dW), otherwise Y (columns of dW).
-// ================================================================================================
-constexpr int SK_WAVES = 8;
-
-template <bool NARROW_X, bool NG2>
-__global__ __launch_bounds__(SK_WAVES * 64) void dw_skinny_kernel(const DwGemm g, int n0, int k0, int ncnt) {
-  constexpr int SK_UNROLL = NG2 ? 4 : 8;
-  extern __shared__ __attribute__((aligned(16))) float smem_k[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long chunk = blockIdx.x;
-  const int wide0 = NARROW_X ? k0 : n0, narrow0 = NARROW_X ? n0 : k0;
-  const int wide_lim = NARROW_X ? g.ldk : g.Npad;       // wide columns beyond the padded extent are neither read nor written
-  const int wcol = wide0 + lane * 4;
-  const bool wlive = wcol < wide_lim;
-  f4 acc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { acc[j].x = 0.f; acc[j].y = 0.f; acc[j].z = 0.f; acc[j].w = 0.f; }
-  f4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};       // column sums of the narrow X operand (bias gradient)
-  const bool want_colsum = NARROW_X && g.colsum != nullptr && k0 == 0;
-  // points of this workgroup: 16-point slabs chunk, chunk + nchunk, ...; wave w takes points w and w + 8 of each slab
-  const long total_slabs = (g.P + 15) / 16;
-  const long my_slabs = chunk < total_slabs ? (total_slabs - chunk + g.nchunk - 1) / g.nchunk : 0;
-  const long my_pts = my_slabs * (16 / SK_WAVES);       // per wave
-  const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-  for (int pair = 0; pair < g.npairs; ++pair) {
-    const View& Vn = NARROW_X ? g.X[pair] : g.Y[pair];
-    const View& Vw = NARROW_X ? g.Y[pair] : g.X[pair];
-    for (long i0 = 0; i0 < my_pts; i0 += SK_UNROLL) {
-      // all loads of the round are issued before any of the (interpreted) view math: one memory round trip per round
-      Raw4 wr[SK_UNROLL], nr0[SK_UNROLL], nr1[SK_UNROLL];
-      unsigned okmask = 0;
-#pragma unroll
-      for (int u = 0; u < SK_UNROLL; ++u) {
-        const long i = i0 + u;
-        const long pt = ((i >> 1) * g.nchunk + chunk) * 16 + wave + SK_WAVES * (i & 1);
-        const bool ok = i < my_pts && pt < g.P;
-        okmask |= ok ? (1u << u) : 0u;
-        const long ptc = ok ? pt : g.P - 1;
-        wr[u] = view_fetch4(Vw, ptc, wlive ? wcol : wide0);
-        nr0[u] = view_fetch4(Vn, ptc, narrow0);
-        if (NG2) nr1[u] = view_fetch4(Vn, ptc, narrow0 + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < SK_UNROLL; ++u) {
-        const bool ok = (okmask >> u) & 1;
-        const f4 w = (ok && wlive) ? view_finish4(Vw, wr[u], wcol) : z4;
-        const f4 a0 = ok ? view_finish4(Vn, nr0[u], narrow0) : z4;
-        f4 a1 = z4;
-        if (NG2 && ok) a1 = view_finish4(Vn, nr1[u], narrow0 + 4);
-#pragma unroll
-        for (int j = 0; j < (NG2 ? 8 : 4); ++j) {
-          const float nj = j < 4 ? a0[j & 3] : a1[j & 3];
-          acc[j].x += nj * w.x; acc[j].y += nj * w.y; acc[j].z += nj * w.z; acc[j].w += nj * w.w;
-        }
-        if (want_colsum && pair == 0) {
-          cs0.x += a0.x; cs0.y += a0.y; cs0.z += a0.z; cs0.w += a0.w;
-          cs1.x += a1.x; cs1.y += a1.y; cs1.z += a1.z; cs1.w += a1.w;
-        }
-      }
-    }
-  }
-  // fold the waves in a fixed order: LDS [wave][8 narrow][256 wide]
-  float* red = smem_k + (size_t)wave * 8 * 256 + lane * 4;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) *reinterpret_cast<f4*>(red + j * 256) = acc[j];
-  float* csr = smem_k + (size_t)SK_WAVES * 8 * 256;
-  if (want_colsum && lane == 0) {
-    *reinterpret_cast<f4*>(csr + wave * 8) = cs0;
-    *reinterpret_cast<f4*>(csr + wave * 8 + 4) = cs1;
-  }
-  __syncthreads();
-  float* out = g.partial + chunk * (long)g.Npad * g.ldk;
-  for (int e = tid; e < 8 * 256; e += SK_WAVES * 64) {
-    const int j = e >> 8, c = e & 255;
-    float sum = 0.f;
-#pragma unroll
-    for (int w = 0; w < SK_WAVES; ++w) sum += smem_k[(size_t)w * 8 * 256 + e];
-    const int n = NARROW_X ? narrow0 + j : wide0 + c, k = NARROW_X ? wide0 + c : narrow0 + j;
-    if (j < ncnt && n < g.Npad && k < g.ldk) out[(long)n * g.ldk + k] = sum;
-  }
-  if (want_colsum && tid < ncnt) {
-    float sum = 0.f;
-#pragma unroll
-    for (int w = 0; w < SK_WAVES; ++w) sum += csr[w * 8 + tid];
-    if (n0 + tid < g.Npad) g.colsum[chunk * g.Npad + n0 + tid] = sum;
-  }
-}
-
-template <bool NARROW_X, bool NG2>
-static void launch_dw_skinny_t(const DwGemm& g, int n0, int k0, int ncnt, cnr_stream s) {
-  const size_t lds = ((size_t)SK_WAVES * 8 * 256 + SK_WAVES * 8) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_skinny_kernel<NARROW_X, NG2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  const int wide = NARROW_X ? ((g.K - k0) < 256 ? (g.K - k0) : 256) : ((g.N - n0) < 256 ? (g.N - n0) : 256);
-  const int tn_ = NARROW_X ? ncnt : wide, tk_ = NARROW_X ? wide : ncnt;
-  TimingScope ts_("dw_skinny", 1, NARROW_X ? 1 : 2, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
-  hipLaunchKernelGGL((dw_skinny_kernel<NARROW_X, NG2>), dim3(g.nchunk), dim3(SK_WAVES * 64), lds, s, g, n0, k0, ncnt);
-}
-
-template <bool NARROW_X>
-static void launch_dw_skinny(const DwGemm& g, int n0, int k0, int ncnt, cnr_stream s) {
-  if (ncnt > 4) launch_dw_skinny_t<NARROW_X, true>(g, n0, k0, ncnt, s);
-  else launch_dw_skinny_t<NARROW_X, false>(g, n0, k0, ncnt, s);
-}
-
-void be_dw_gemm(const DwGemm& g, cnr_stream s) {
-  // tile the [Npad x ldk] output: 256x256 main tiles, 256x64 column tails, 32x256 row tails
-  static const bool dw_fp32 = getenv("CNR_DW_FP32") != nullptr;   // debugging aid: FP32-MFMA kernel for the main tiles too
-  static const bool dw_bf16 = getenv("CNR_DW_BF16") != nullptr;   // debugging aid: split-bf16 kernel even when row scales are available
-  for (int n0 = 0; n0 < g.N; n0 += 256) {
-    const int nrem = g.N - n0;
-    for (int k0 = 0; k0 < g.K;) {
-      const int krem = g.K - k0;
-      if (nrem > 32) {
-        if (krem > 64) {
-          // the gradient-chain pair of the top SDF layer is a unit vector at the sdf row: it adds nothing to other row tiles
-          DwGemm gm = g;
-          if (gm.npairs == 2 && gm.X[1].kind == VK_CONST_COL0) {
-            const int hot = gm.X[1].math_split == (1 << 30) ? 0 : gm.X[1].math_split;
-            if (hot < n0 || hot >= n0 + 256) gm.npairs = 1;
-          }
-          bool scaled = !dw_bf16 && gm.gexp != nullptr;
-          for (int i = 0; i < gm.npairs; ++i) scaled = scaled && gm.sx[i] != nullptr && gm.sy[i] != nullptr;
-          if (dw_fp32) launch_dw<4, 2, 2, 4>(g, n0, k0, s);
-          else if (scaled) launch_dw_hx(gm, n0, k0, s);
-          else launch_dw_bx(gm, n0, k0, s);
-          k0 += 256;
-        }
-        else if (krem <= 8 && !dw_fp32 && !(g.colsum != nullptr && k0 == 0) && (k0 & 3) == 0) { launch_dw_skinny<false>(g, n0, k0, krem, s); k0 += 64; }
-        else { launch_dw<8, 1, 1, 2>(g, n0, k0, s); k0 += 64; }
-      } else if (nrem <= 8 && !dw_fp32 && (n0 & 3) == 0) {
-        launch_dw_skinny<true>(g, n0, k0, nrem, s); k0 += 256;
-      } else {
-        launch_dw<1, 8, 1, 1>(g, n0, k0, s); k0 += 256;
-      }
-    }
-  }
-  CNR_LAUNCH_CHECK("dw_gemm");
 }
 
 }  // namespace cnr

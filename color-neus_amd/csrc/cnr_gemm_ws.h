@@ -1,0 +1,229 @@
+// Weight-stationary layer GEMM: kernel template and launcher (included by cnr_gemm_ws_a.hip / cnr_gemm_ws_b.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "cnr_backend.h"
+#include "cnr_hip_util.h"
+#include "cnr_gemm_int.h"
+
+namespace cnr {
+
+// ================================================================================================
+// weight-stationary layer GEMM (K <= 256, up to 256 output columns per launch)
+//
+// The whole layer lives in the REGISTER FILE of one CU: 8 waves x 32 output columns; each wave keeps its slice of W as two f16
+// planes in MFMA B-operand layout (2 planes x 16 k-blocks x 4 VGPRs = 128 VGPRs).  Points stream through in 32-row tiles: a tile is
+// fetched once, gets the fused prologue (cnr_views.h), is scaled by an exact power of two per row, split into f16 hi + lo
+// (11 + 11 significand bits) on its way into LDS and read by all 8 waves.  Each product is three v_mfma_f32_32x32x16_f16
+// (a1 w1 + a1 w2 + a2 w1; the dropped a2 w2 is < 2^-22), fp32 accumulation, and the epilogue undoes the row / column scales
+// (exact).  Measured (tools/probes/ws_probe.hip): max error 8.3e-7 vs float64 where the FP32 FMA chain of v_mfma_f32_32x32x2_f32 has
+// 1.1e-6 -- also with rows spanning 12 orders of magnitude -- at 3 x 32 = 96 MFMA cycles per k16 block instead of 8 x 64 = 512.
+// No weight traffic after the prologue, 16 accumulator registers, one barrier per 32 points.
+// ================================================================================================
+constexpr int WS_TP = 32;
+constexpr int WS_THREADS = 512;
+constexpr int WS_TLD = 36;
+
+__device__ __forceinline__ void ws_put4(const f4& v, float sc, unsigned char* dst, int aplane) {
+  f16x4 h1, h2;
+  float x;
+  x = v.x * sc; h1[0] = (_Float16)x; h2[0] = (_Float16)(x - (float)h1[0]);
+  x = v.y * sc; h1[1] = (_Float16)x; h2[1] = (_Float16)(x - (float)h1[1]);
+  x = v.z * sc; h1[2] = (_Float16)x; h2[2] = (_Float16)(x - (float)h1[2]);
+  x = v.w * sc; h1[3] = (_Float16)x; h2[3] = (_Float16)(x - (float)h1[3]);
+  *reinterpret_cast<f16x4*>(dst) = h1;
+  *reinterpret_cast<f16x4*>(dst + aplane) = h2;
+}
+
+// VK / EK >= 0 pin the view / epilogue kind at compile time: the interpreted switches of cnr_views.h fold away and each
+// instantiation only allocates the registers its own prologue and epilogue need (-1 = generic, interpreted at run time).
+// PLAIN promises an epilogue without tail fill and without a split point (most launches): that code folds away as well.
+// K17 admits a 17th k16 block (K up to 272: the layers whose input is a 256-wide hidden vector plus a few concatenated columns).
+template <int VK, int EK, bool PLAIN, bool K17 = false>
+__global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const LayerGemm g_in, int tiles_per_wg, int wrows) {
+  constexpr int NKB = K17 ? 17 : 16;
+  LayerGemm g = g_in;
+  if (VK >= 0) g.A.kind = VK;
+  if (EK >= 0) g.E.kind = EK;
+  if (PLAIN) { g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30; }
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long Pn = g.P_dev ? (long)*g.P_dev : g.P;
+  const long ntiles = (Pn + WS_TP - 1) / WS_TP;
+  const long t0 = (long)blockIdx.x * tiles_per_wg;
+  if (t0 >= ntiles) return;
+  long t1 = t0 + tiles_per_wg;
+  if (t1 > ntiles) t1 = ntiles;
+  const int nkb = (g.K + 15) >> 4;              // 1..NKB k16 blocks
+  const int kpad = nkb * 16;
+  const int ald = kpad * 2 + 16;                // bytes per LDS row of one plane (+16: conflict-free ds_read_b128)
+  const int aplane = WS_TP * ald;
+  const int abuf = 2 * aplane + 128;            // two planes + 32 row scales
+  float* T = reinterpret_cast<float*>(smem_b + 2 * abuf) + wave * (32 * WS_TLD);
+  const int c0 = g.col0 + wave * 32;            // this wave's first output column
+  const bool has_w = c0 < wrows;
+  const int ncols_live = g.E.n_out + (g.E.tail_src ? g.E.tail_n : 0);
+
+  // ---- resident weights (two f16 planes of this wave's 32 rows of W)
+  f16x8 w1[NKB], w2[NKB];
+  {
+    const unsigned short* wp = g.Wp + (long)(has_w ? c0 + (lane & 31) : 0) * g.ldw + (lane >> 5) * 8;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb < nkb) {
+        w1[kb] = *reinterpret_cast<const f16x8*>(wp + kb * 16);
+        w2[kb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 16);
+      }
+    }
+  }
+  f4 wsc = {1.f, 1.f, 1.f, 1.f};               // inverse column scales of the 4 columns this lane finishes in the epilogue
+  if (has_w) wsc = *reinterpret_cast<const f4*>(g.wscale + c0 + (lane & 7) * 4);
+  const int ecol = c0 + (lane & 7) * 4;         // ... and their epilogue path / bias (fixed per lane for the whole launch)
+  const bool efast = epi_fast4(g.E, ecol);
+  f4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (efast) bias4 = epi_bias4(g.E, ecol);
+
+  // ---- staging map: 16 threads per row, 4 consecutive columns each, up to 4 passes of 64 columns
+  const int srow = tid >> 4, scol = (tid & 15) * 4;
+  const bool pv0 = scol < kpad, pv1 = 64 + scol < kpad, pv2 = 128 + scol < kpad, pv3 = 192 + scol < kpad;
+  const bool pv4 = K17 && 256 + scol < kpad;   // 17th block: 4 of the 16 threads of a row
+  Raw4 r0, r1, r2, r3, r4;
+  const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+  r0.a = z4; r0.b = z4; r1 = r0; r2 = r0; r3 = r0; r4 = r0;
+#define WS_FETCH_TILE(tile_)                                                      \
+  {                                                                               \
+    long row_ = (tile_) * WS_TP + srow; if (row_ >= Pn) row_ = Pn - 1;            \
+    if (pv0) r0 = view_fetch4(g.A, row_, scol);                                   \
+    if (pv1) r1 = view_fetch4(g.A, row_, 64 + scol);                              \
+    if (pv2) r2 = view_fetch4(g.A, row_, 128 + scol);                             \
+    if (pv3) r3 = view_fetch4(g.A, row_, 192 + scol);                             \
+    if (K17 && pv4) r4 = view_fetch4(g.A, row_, 256 + scol);                      \
+  }
+#define WS_PUT_TILE(buf_, tile_)                                                  \
+  {                                                                               \
+    const f4 v0 = pv0 ? view_finish4(g.A, r0, scol) : z4;                         \
+    const f4 v1 = pv1 ? view_finish4(g.A, r1, 64 + scol) : z4;                    \
+    const f4 v2 = pv2 ? view_finish4(g.A, r2, 128 + scol) : z4;                   \
+    const f4 v3 = pv3 ? view_finish4(g.A, r3, 192 + scol) : z4;                   \
+    const f4 v4 = (K17 && pv4) ? view_finish4(g.A, r4, 256 + scol) : z4;          \
+    float mx = fmaxf(fmaxf(fmaxf(ws_absmax4(v0), ws_absmax4(v1)), fmaxf(ws_absmax4(v2), ws_absmax4(v3))), ws_absmax4(v4)); \
+    _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16)); \
+    float sc = 1.0f;                                                              \
+    if (mx > 0.0f && mx < 3.0e38f) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); } /* 2^e_ clamp: subnormal rows must not overflow the scale */ \
+    unsigned char* dst = smem_b + (buf_) * abuf + srow * ald + scol * 2;          \
+    if (pv0) ws_put4(v0, sc, dst, aplane);                                        \
+    if (pv1) ws_put4(v1, sc, dst + 128, aplane);                                  \
+    if (pv2) ws_put4(v2, sc, dst + 256, aplane);                                  \
+    if (pv3) ws_put4(v3, sc, dst + 384, aplane);                                  \
+    if (K17 && pv4) ws_put4(v4, sc, dst + 512, aplane);                           \
+    if ((tid & 15) == 0) {                                                        \
+      reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
+      const long prow_ = (tile_) * WS_TP + srow;                                  \
+      if (g.rs_out && prow_ < Pn) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : 0.0f; /* 0 marks an all-zero row */ \
+    }                                                                             \
+  }
+#define WS_MFMA(kb_)                                                                               \
+  if ((kb_) < nkb) {                                                                               \
+    const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + (kb_) * 32);                             \
+    const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + aplane + (kb_) * 32);                    \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb_], acc, 0, 0, 0);                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb_], acc, 0, 0, 0);                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb_], acc, 0, 0, 0);                       \
+  }
+
+  // Waves 0..3 (rows 0..15 of a tile) and waves 4..7 (rows 16..31) share the SIMDs pairwise and run half an iteration out of
+  // phase: the late group converts + stores its half of tile t+1 (fetched one iteration earlier) and fetches tile t+2 BEFORE
+  // its MFMAs of tile t, the early group fetches tile t+1 before and stores it after -- so one wave of each SIMD is in the
+  // matrix pipe while the other does prologue math / LDS stores / epilogue.  One barrier per tile.
+  const bool late = wave >= 4;
+  WS_FETCH_TILE(t0)
+  WS_PUT_TILE(0, t0)
+  if (late && t0 + 1 < t1) WS_FETCH_TILE(t0 + 1)
+  __syncthreads();
+
+  for (long t = t0; t < t1; ++t) {
+    const int buf = (int)((t - t0) & 1);
+    const bool more = t + 1 < t1;
+    if (!late) {
+      if (more) WS_FETCH_TILE(t + 1)
+    } else if (more) {
+      WS_PUT_TILE(buf ^ 1, t + 1)
+      if (t + 2 < t1) WS_FETCH_TILE(t + 2)
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    const unsigned char* Ab = smem_b + buf * abuf + (lane & 31) * ald + (lane >> 5) * 16;
+    if (has_w) {
+      WS_MFMA(0) WS_MFMA(1) WS_MFMA(2) WS_MFMA(3) WS_MFMA(4) WS_MFMA(5) WS_MFMA(6) WS_MFMA(7)
+      WS_MFMA(8) WS_MFMA(9) WS_MFMA(10) WS_MFMA(11) WS_MFMA(12) WS_MFMA(13) WS_MFMA(14) WS_MFMA(15)
+      if (K17) { WS_MFMA(NKB - 1) }
+    }
+    // epilogue of this 32 x 32 tile: undo the exact row / column scales, then the fused epilogue on 4 columns per lane.
+    // The side inputs of all four row groups are requested first: one memory round trip per tile, and no load has to
+    // wait behind the stores of the previous row group.
+    if (c0 < ncols_live) {
+      const float* rs = reinterpret_cast<const float*>(smem_b + buf * abuf + 2 * aplane);
+      const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * WS_TLD + cl] = acc[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      constexpr int EG = (EK == EK_SWEEP || EK == EK_VBACK) ? 2 : 4;   // row groups whose side inputs are in flight together (register budget)
+#pragma unroll
+      for (int i0 = 0; i0 < 4; i0 += EG) {
+        EpiRaw4 er[EG];
+#pragma unroll
+        for (int i = 0; i < EG; ++i) {
+          long row = t * WS_TP + (lane >> 3) + 8 * (i0 + i);
+          if (row >= Pn) row = Pn - 1;
+          if (efast) er[i] = epi_fetch4(g.E, row, ecol);
+        }
+#pragma unroll
+        for (int i = 0; i < EG; ++i) {
+          const int rr = (lane >> 3) + 8 * (i0 + i), cc = (lane & 7) * 4;
+          const long row = t * WS_TP + rr;
+          const float rsc = rs[rr];
+          f4 v = *reinterpret_cast<const f4*>(T + rr * WS_TLD + cc);
+          v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
+          if (row < Pn) {
+            if (efast) epi_finish4(g.E, row, ecol, v, bias4, er[i]);
+            else epi_apply4(g.E, row, ecol, v);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!late && more) WS_PUT_TILE(buf ^ 1, t + 1)
+    __syncthreads();
+  }
+#undef WS_FETCH_TILE
+#undef WS_PUT_TILE
+#undef WS_MFMA
+}
+
+template <int VK, int EK, bool PLAIN, bool K17 = false>
+static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
+  const int nkb = (g.K + 15) / 16;
+  const int abuf = 2 * WS_TP * (nkb * 32 + 16) + 128;
+  const size_t lds = (size_t)2 * abuf + (size_t)8 * 32 * WS_TLD * sizeof(float);
+  const long ntiles = (g.P + WS_TP - 1) / WS_TP;
+  if (ntiles == 0) return;
+  static const int ws_wgs = getenv("CNR_WS_WGS") ? atoi(getenv("CNR_WS_WGS")) : 256;       // tuning knobs (defaults measured on MI355X)
+  static const int ws_mintpw = getenv("CNR_WS_MINTPW") ? atoi(getenv("CNR_WS_MINTPW")) : 8;
+  long tpw = (ntiles + ws_wgs - 1) / ws_wgs;   // one workgroup per CU: the weights are loaded once per CU (measured best of 256 / 512 / 768 / 1024)
+  if (tpw < ws_mintpw) tpw = ws_mintpw;
+  const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN, K17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
+  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN, K17>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
+}
+
+}  // namespace cnr
