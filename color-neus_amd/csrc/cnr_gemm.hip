@@ -43,7 +43,7 @@ __global__ void row_scale_kernel(const LayerGemm g) {
   const int kpad = ((g.K + 15) >> 4) * 16;
   float mx = 0.0f;
   for (int c = 0; c < kpad; c += 4) mx = fmaxf(mx, ws_absmax4(view_eval4(g.A, row, c)));
-  float sc = 0.0f;
+  float sc = mx == 0.0f ? 0.0f : __builtin_nanf("");   // 0: all-zero row, NaN: non-finite row
   if (mx > 0.0f && mx < 3.0e38f) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); }
   g.rs_out[row] = sc;
 }

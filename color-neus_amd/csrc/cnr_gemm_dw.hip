@@ -462,7 +462,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, i
     }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
       float f_ = rsx[i];                                                                   \
-      if (is_y) f_ = f_ > 0.0f ? ldexpf(1.0f / f_, G) : 0.0f;                              \
+      if (is_y) f_ = f_ > 0.0f ? ldexpf(1.0f / f_, G) : (f_ == 0.0f ? 0.0f : f_);          \
       v_[i].x *= f_; v_[i].y *= f_; v_[i].z *= f_; v_[i].w *= f_;                          \
     }                                                                                      \
     unsigned char* d_ = sdst + (buf_) * DH_BUF;                                            \
@@ -567,25 +567,41 @@ static void launch_dw_hx(const DwGemm& g, int n0, int k0, cnr_stream s) {
 
 // G = 1 + min over points (both pairs) of log2(sx * sy), rows with a zero scale (all-zero rows) excluded.  *gexp must hold a large
 // value on entry (be_dw_scale fills it with 0x7f bytes).  min is order independent, so the atomic keeps results deterministic.
+__device__ __forceinline__ int dw_scale_exp4(const f4& a, const f4& b, int best) {
+  // the scales are powers of two (or 0): exponent = biased exponent field - 127
+  const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ea = (int)((__float_as_uint(av[i]) >> 23) & 0xff), eb = (int)((__float_as_uint(bv[i]) >> 23) & 0xff);
+    const int e = ea + eb - 254 + 1;
+    if (av[i] > 0.0f && bv[i] > 0.0f && e < best) best = e;
+  }
+  return best;
+}
 __global__ void dw_scale_kernel(const float* sx0, const float* sy0, const float* sx1, const float* sy1, long P, int* gexp) {
   int best = 0x7f7f7f7f;
-  for (long pt = (long)blockIdx.x * blockDim.x + threadIdx.x; pt < P; pt += (long)gridDim.x * blockDim.x) {
-    const float a = sx0[pt], b = sy0[pt];
-    if (a > 0.0f && b > 0.0f) { const int e = ilogbf(a) + ilogbf(b) + 1; best = e < best ? e : best; }
-    if (sx1) {
-      const float c = sx1[pt], d = sy1[pt];
-      if (c > 0.0f && d > 0.0f) { const int e = ilogbf(c) + ilogbf(d) + 1; best = e < best ? e : best; }
-    }
+  const long P4 = P >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P4; i += (long)gridDim.x * blockDim.x) {
+    best = dw_scale_exp4(reinterpret_cast<const f4*>(sx0)[i], reinterpret_cast<const f4*>(sy0)[i], best);
+    if (sx1) best = dw_scale_exp4(reinterpret_cast<const f4*>(sx1)[i], reinterpret_cast<const f4*>(sy1)[i], best);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (P & 3)) {   // last 1..3 points
+    const long pt = (P4 << 2) + threadIdx.x;
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    f4 a = z, b = z;
+    a.x = sx0[pt]; b.x = sy0[pt];
+    best = dw_scale_exp4(a, b, best);
+    if (sx1) { a.x = sx1[pt]; b.x = sy1[pt]; best = dw_scale_exp4(a, b, best); }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(best, d); best = o < best ? o : best; }
-  if ((threadIdx.x & 63) == 0) atomicMin(gexp, best);
+  if ((threadIdx.x & 63) == 0 && best != 0x7f7f7f7f) atomicMin(gexp, best);
 }
 
 void be_dw_scale(const DwGemm& g, int* gexp, cnr_stream s) {
   (void)hipMemsetAsync(gexp, 0x7f, sizeof(int), s);
   TimingScope ts_("dw_scale", 2, 0, g.P, 0, 0, 0, s);
-  hipLaunchKernelGGL(dw_scale_kernel, dim3(512), dim3(256), 0, s, g.sx[0], g.sy[0], g.npairs > 1 ? g.sx[1] : nullptr,
+  hipLaunchKernelGGL(dw_scale_kernel, dim3(256), dim3(256), 0, s, g.sx[0], g.sy[0], g.npairs > 1 ? g.sx[1] : nullptr,
                      g.npairs > 1 ? g.sy[1] : nullptr, g.P, gexp);
   CNR_LAUNCH_CHECK("dw_scale");
 }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     if ((tid & 15) == 0) {                                                        \
       reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
       const long prow_ = (tile_) * WS_TP + srow;                                  \
-      if (g.rs_out && prow_ < Pn) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : 0.0f; /* 0 marks an all-zero row */ \
+      if (g.rs_out && prow_ < Pn) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); /* 0: all-zero row, NaN: non-finite row (must keep poisoning the weight gradient) */ \
     }                                                                             \
   }
 #define WS_MFMA(kb_)                                                                               \

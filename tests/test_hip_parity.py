@@ -96,6 +96,66 @@ def test_against_oracle_larger_batch():
     assert not bad, bad
 
 
+def _oracle_batch(R, seed):
+    from oracle import colorneus_oracle as O
+    ocfg = O.dtu_config()
+    P = O.init_params(ocfg, seed=5, trained_like=True)
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(R, 3, generator=g); o = o / o.norm(dim=-1, keepdim=True) * 2.7
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g) * 0.3 - o, dim=-1)
+    near, far = O.near_far_from_sphere(o, d)
+    t_rand = torch.rand(R, 1, generator=g)
+    gt = torch.rand(R, 3, generator=g)
+    mask = (torch.rand(R, generator=g) > 0.3).float()
+    return O, ocfg, P, o, d, near, far, t_rand, gt, mask
+
+
+def test_parameter_gradients_against_float64_oracle_larger_batch():
+    """All parameter gradients of one training loss on 160 rays x 128 samples (DTU-size network, inv_s = 665) against the
+    oracle evaluated in float64 at the same z: covers the split-f16 weight-gradient tiles, their per-point scales and the
+    skinny strips on an input that is not one of the golden fixtures."""
+    import color_neus_amd as cn
+    O, ocfg, P, o, d, near, far, t_rand, gt, mask = _oracle_batch(160, seed=21)
+    z32 = O.sample_z(P, ocfg, o, d, near, far, t_rand)
+    P64 = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    oo = O.render(P64, ocfg, o.double(), d.double(), near.double(), far.double(), z_vals=z32.double())
+    l64, _ = O.compute_loss(oo, gt.double(), mask.double())
+    l64.backward()
+    r = N.make_renderer(ocfg, P, None, DEV)
+    out = r(o.to(DEV), d.to(DEV), near.to(DEV), far.to(DEV), z_vals=z32.to(DEV))
+    loss, _ = cn.compute_loss(out, gt.to(DEV), mask.to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(l64.detach())) < 2e-4 * abs(float(l64.detach()))
+    got = dict(r.named_parameters())
+    ref = {k: v.grad for k, v in P64.items()}
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    bad = []
+    for k, gr in ref.items():
+        name = k if k in got else "renderer." + k
+        err = float((got[name].grad.detach().cpu().double() - gr).abs().max())
+        lim = G.grad_tolerance(float(gr.abs().max()), gmax, 3e-4)   # fp32 vs float64 of the same algorithm (the reference's own spread is 4.5e-4)
+        if not err <= lim:
+            bad.append((k, err, lim))
+    assert not bad, bad
+
+
+def test_non_finite_input_poisons_the_weight_gradients():
+    """A NaN ray must not be dropped silently by the per-point scaling of the weight-gradient GEMM."""
+    import color_neus_amd as cn
+    O, ocfg, P, o, d, near, far, t_rand, gt, mask = _oracle_batch(64, seed=3)
+    o[5, 1] = float("nan")
+    r = N.make_renderer(ocfg, P, None, DEV)
+    z = torch.linspace(0.5, 4.0, ocfg.n_samples + ocfg.n_importance).repeat(64, 1)
+    out = r(o.to(DEV), d.to(DEV), near.to(DEV), far.to(DEV), z_vals=z.to(DEV))
+    loss, _ = cn.compute_loss(out, gt.to(DEV), mask.to(DEV))
+    loss.backward()
+    assert not bool(torch.isfinite(loss.detach()))
+    # (the ReLU stacks clamp NaN to 0 like fmaxf does, so only the SDF network -- softplus -- is required to carry the poison)
+    finite = [n for n, p in r.named_parameters() if "sdf_network" in n and p.grad is not None and p.grad.numel() > 1024
+              and bool(torch.isfinite(p.grad).all())]
+    assert not finite, finite
+
+
 def test_sdf_grid_and_vertex_colour():
     fx = G.load("functions")
     from oracle import colorneus_oracle as O
