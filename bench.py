@@ -51,8 +51,11 @@ def parse():
 def clip_per_parameter_(params, max_norm=1.0):
     """clip_gradient (lib/utils/net_utils.py:174-184): each parameter tensor's L2 norm clipped separately."""
     grads = [p.grad for p in params if p.grad is not None]
-    norms = torch._foreach_norm(grads)
-    coefs = [torch.clamp(max_norm / (n + 1e-6), max=1.0) for n in norms]
+    coefs = torch._foreach_norm(grads)                 # 5 multi-tensor launches instead of ~170 scalar ones
+    torch._foreach_add_(coefs, 1e-6)
+    torch._foreach_reciprocal_(coefs)
+    torch._foreach_mul_(coefs, max_norm)
+    torch._foreach_clamp_max_(coefs, 1.0)
     torch._foreach_mul_(grads, coefs)
 
 
