@@ -176,6 +176,8 @@ void be_variance_finish(const VarianceFinish& p, cnr_stream s);
 void be_pbar_finish(const PbarFinish& p, cnr_stream s);
 void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s);
 void be_memset_zero(void* p, size_t bytes, cnr_stream s);
+// p[row][c] = 0 for c in [c0, c1), row < rows: zero the pad columns a GEMM reads without touching the rest of a wide buffer
+void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream s);
 void be_grid_points(float* pts /*unused*/, cnr_stream s);
 struct KernelTiming { char name[32]; int kind; int nt; long P; int N, K, pairs; float ms; double bytes; };
 void be_timing_enable(int on);

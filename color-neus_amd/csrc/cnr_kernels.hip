@@ -80,6 +80,18 @@ void be_memset_zero(void* p, size_t bytes, cnr_stream s) {
   if (e != hipSuccess && g_first_error == hipSuccess) { g_first_error = e; g_first_error_where = "memset"; }
 }
 
+__global__ void zero_cols_kernel(float* p, int ld, int c0, int c1, long rows) {
+  const int w = c1 - c0;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * w) p[(i / w) * ld + c0 + (int)(i % w)] = 0.0f;
+}
+void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream s) {
+  if (c1 <= c0 || rows <= 0) return;
+  const long n = rows * (c1 - c0);
+  hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, ld, c0, c1, rows);
+  CNR_LAUNCH_CHECK("zero_cols");
+}
+
 // ================================================================================================
 // point-wise kernels
 // ================================================================================================

@@ -18,6 +18,9 @@ void be_timing_enable(int) {}
 int be_timing_collect(KernelTiming*, int) { return 0; }
 int be_check_last_error(char*, size_t) { return 0; }
 void be_memset_zero(void* p, size_t bytes, cnr_stream) { memset(p, 0, bytes); }
+void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream) {
+  for (long r = 0; r < rows; ++r) for (int c = c0; c < c1; ++c) p[r * ld + c] = 0.0f;
+}
 void be_dw_scale(const DwGemm&, int*, cnr_stream) {}   // the emulation accumulates in plain fp32: no operand scaling
 void be_grid_points(float*, cnr_stream) {}
 

@@ -336,7 +336,7 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   for (int l = 0; l + 1 < m.NC; ++l) b.DC[l] = a.f((size_t)P * m.Hc);
   b.VB.resize(m.L); b.Z2.resize(m.L);
   for (int l = 0; l < m.L; ++l) { b.VB[l] = a.f((size_t)P * m.Hs); b.Z2[l] = a.f((size_t)P * m.Hs); }
-  long nch = P / 512;
+  long nch = P / 128;   // one workgroup per CU as soon as every chunk has a few 16-point slabs
   if (nch < 1) nch = 1;
   if (nch > 256) nch = 256;
   b.nchunk = (int)nch;
@@ -581,7 +581,7 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   be_fine_setup(fs, s);
   sdf_chain(m, P, x.E, x.Z.data(), x.sdf, x.featx, x.ldfx, 1.0f / scale, s, x.rsY.data());
   for (int l = 1; l < m.L; ++l)   // V[l-1] feeds a GEMM over round_up(n,16) columns: its unwritten pad columns must be finite
-    if (m.skip(l) && x.V[l - 1]) be_memset_zero(x.V[l - 1], (size_t)P * m.Hs * sizeof(float), s);
+    if (m.skip(l) && x.V[l - 1]) be_zero_cols(x.V[l - 1], m.Hs, m.sdf[l - 1].n, round_up(m.sdf[l - 1].n, 16), P, s);
   sdf_grad_chain(m, P, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s, x.rsX1.data());
   GradFinish gf;
   gf.featx = x.featx; gf.ldfx = x.ldfx; gf.F = m.F;
@@ -682,7 +682,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   const bool skipnet = has_skip(m);
 
   // ---- 1. compositor backward
-  be_memset_zero(b.ZTOP, (size_t)P * x.ldztop * sizeof(float), s);
+  be_zero_cols(b.ZTOP, x.ldztop, m.F + 1, x.ldztop, P, s);   // pad columns of [feat cotangent | sdf cotangent | 0]: every other column is written below
   CompositeBwd cb;
   cb.o = in->rays_o; cb.d = in->rays_d; cb.z = out->z_vals; cb.R = R; cb.M = m.M; cb.sample_dist = 2.0f / (float)m.S;
   cb.sdf = x.sdf; cb.g = out->gradients; cb.color = m.has_relight ? x.relit : x.gcol; cb.ldcolor = 4;
