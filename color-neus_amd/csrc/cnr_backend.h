@@ -156,6 +156,10 @@ void be_prep_weight(const PrepWeight& p, cnr_stream s);
 // fp32 matrix [rows][ld] -> two f16 planes of the row-scaled matrix (x * 2^e = hi + lo, 22 significand bits) + 1/2^e per row,
 // for the weight-stationary f16-split GEMM (cnr_gemm.hip)
 void be_split_planes(const float* src, int rows, int ld, unsigned short* planes, float* inv_scale, cnr_stream s);
+// all layers of a model in two launches (the per-layer launches are latency-bound: 57 launches of a few microseconds each)
+struct SplitJob { const float* src; int rows; int ld; unsigned short* planes; float* inv_scale; };
+void be_prep_weights(const PrepWeight* p, int count, cnr_stream s);
+void be_split_planes_many(const SplitJob* jobs, int count, cnr_stream s);
 void be_finish_weight(const FinishWeight& p, cnr_stream s);
 void be_embed_z(const EmbedZ& p, cnr_stream s);
 void be_embed_pts(const EmbedPts& p, cnr_stream s);

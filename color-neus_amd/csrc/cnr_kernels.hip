@@ -283,9 +283,8 @@ __device__ __forceinline__ double block_sum_256d(double x, double* sh4) {
 }
 
 // effective weights: weight-norm, column permutation, zero padding, transpose copy.  One block per padded row.
-__global__ __launch_bounds__(256) void prep_weight_kernel(const PrepWeight p) {
-  __shared__ double redd[4];
-  const int n = blockIdx.x, tid = threadIdx.x;     // internal row
+__device__ __forceinline__ void prep_weight_row(const PrepWeight& p, const int n, double* redd) {
+  const int tid = threadIdx.x;                     // n: internal row
   const bool real = n < p.n;
   const int nr = real ? (n + p.row_rot) % p.n : 0;  // reference row
   float scale = 1.0f;
@@ -309,11 +308,23 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(const PrepWeight p) {
   }
   if (tid == 0) p.bias[n] = real && p.b ? p.b[nr] : 0.0f;
 }
+__global__ __launch_bounds__(256) void prep_weight_kernel(const PrepWeight p) {
+  __shared__ double redd[4];
+  prep_weight_row(p, blockIdx.x, redd);
+}
+constexpr int kPrepBatch = 24;
+struct PrepBatch { int count; int row_start[kPrepBatch + 1]; PrepWeight p[kPrepBatch]; };
+static_assert(sizeof(PrepBatch) <= 4096, "kernel argument block");
+__global__ __launch_bounds__(256) void prep_weight_batch_kernel(const PrepBatch b) {
+  __shared__ double redd[4];
+  int i = 0;
+  while (i + 1 < b.count && (int)blockIdx.x >= b.row_start[i + 1]) ++i;
+  prep_weight_row(b.p[i], (int)blockIdx.x - b.row_start[i], redd);
+}
 
 // fp32 matrix -> two f16 planes of the row-scaled matrix: x * 2^e = hi + lo with e chosen per row so that max|x| * 2^e is in
 // [2^13, 2^14) (exact scaling; 11 + 11 significand bits), plus 1 / 2^e per row.  One 64-thread block per row.
-__global__ __launch_bounds__(64) void split_planes_kernel(const float* src, int ld, unsigned short* planes, long plane_stride, float* inv_scale) {
-  const int r = blockIdx.x;
+__device__ __forceinline__ void split_planes_row(const float* src, int ld, unsigned short* planes, long plane_stride, float* inv_scale, const int r) {
   const float* row = src + (long)r * ld;
   float mx = 0.0f;
   for (int k = threadIdx.x; k < ld; k += 64) mx = fmaxf(mx, fabsf(row[k]));
@@ -329,6 +340,42 @@ __global__ __launch_bounds__(64) void split_planes_kernel(const float* src, int 
     planes[plane_stride + (long)r * ld + k] = __builtin_bit_cast(unsigned short, h2);
   }
   if (threadIdx.x == 0) inv_scale[r] = 1.0f / sc;
+}
+__global__ __launch_bounds__(64) void split_planes_kernel(const float* src, int ld, unsigned short* planes, long plane_stride, float* inv_scale) {
+  split_planes_row(src, ld, planes, plane_stride, inv_scale, blockIdx.x);
+}
+constexpr int kSplitBatch = 2 * kPrepBatch;
+struct SplitBatch { int count; int row_start[kSplitBatch + 1]; SplitJob j[kSplitBatch]; };
+static_assert(sizeof(SplitBatch) <= 4096, "kernel argument block");
+__global__ __launch_bounds__(64) void split_planes_batch_kernel(const SplitBatch b) {
+  int i = 0;
+  while (i + 1 < b.count && (int)blockIdx.x >= b.row_start[i + 1]) ++i;
+  const SplitJob& j = b.j[i];
+  split_planes_row(j.src, j.ld, j.planes, (long)j.rows * j.ld, j.inv_scale, (int)blockIdx.x - b.row_start[i]);
+}
+void be_split_planes_many(const SplitJob* jobs, int count, cnr_stream s) {
+  for (int i0 = 0; i0 < count; i0 += kSplitBatch) {
+    SplitBatch b;
+    b.count = count - i0 < kSplitBatch ? count - i0 : kSplitBatch;
+    int rows = 0;
+    for (int i = 0; i < b.count; ++i) { b.row_start[i] = rows; b.j[i] = jobs[i0 + i]; rows += jobs[i0 + i].rows; }
+    b.row_start[b.count] = rows;
+    TimingScope ts_("split_planes", 2, 0, rows, 0, 0, 0, s);
+    hipLaunchKernelGGL(split_planes_batch_kernel, dim3(rows), dim3(64), 0, s, b);
+  }
+  CNR_LAUNCH_CHECK("split_planes");
+}
+void be_prep_weights(const PrepWeight* p, int count, cnr_stream s) {
+  for (int i0 = 0; i0 < count; i0 += kPrepBatch) {
+    PrepBatch b;
+    b.count = count - i0 < kPrepBatch ? count - i0 : kPrepBatch;
+    int rows = 0;
+    for (int i = 0; i < b.count; ++i) { b.row_start[i] = rows; b.p[i] = p[i0 + i]; rows += p[i0 + i].npad; }
+    b.row_start[b.count] = rows;
+    TimingScope ts_("prep_weight", 2, 0, rows, 0, 0, 0, s);
+    hipLaunchKernelGGL(prep_weight_batch_kernel, dim3(rows), dim3(256), 0, s, b);
+  }
+  CNR_LAUNCH_CHECK("prep_weight");
 }
 void be_split_planes(const float* src, int rows, int ld, unsigned short* planes, float* inv_scale, cnr_stream s) {
   TimingScope ts_("split_planes", 2, 0, rows, 0, 0, 0, s);

@@ -359,6 +359,8 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
 
 // ------------------------------------------------------------------------------------------------
 static void prep_all(Model& m, const float* const* params, cnr_stream s) {
+  std::vector<PrepWeight> pw;
+  std::vector<SplitJob> sj;
   auto prep = [&](Lin& q) {
     PrepWeight p;
     p.g = q.p_g >= 0 ? params[q.p_g] : nullptr;
@@ -370,13 +372,15 @@ static void prep_all(Model& m, const float* const* params, cnr_stream s) {
     p.W = q.W; p.ldw = q.ldw; p.npad = q.npad;
     p.Wt = q.Wt; p.ldwt = q.ldwt; p.kpad = q.kpad;
     p.bias = q.bias; p.row_rot = q.row_rot;
-    be_prep_weight(p, s);
-    be_split_planes(q.W, q.npad, q.ldw, q.Wp, q.Wps, s);
-    be_split_planes(q.Wt, q.kpad, q.ldwt, q.Wtp, q.Wtps, s);
+    pw.push_back(p);
+    sj.push_back(SplitJob{q.W, q.npad, q.ldw, q.Wp, q.Wps});
+    sj.push_back(SplitJob{q.Wt, q.kpad, q.ldwt, q.Wtp, q.Wtps});
   };
   for (auto& q : m.sdf) prep(q);
   for (auto& q : m.col) prep(q);
   for (auto& q : m.rel) prep(q);
+  be_prep_weights(pw.data(), (int)pw.size(), s);            // effective weights of every layer: one launch
+  be_split_planes_many(sj.data(), (int)sj.size(), s);       // their f16 planes (W and W^T): one launch
 }
 
 // forward-input view of SDF layer l (value path): e, softplus(z_{l-1}) or the skip concat / sqrt(2)
