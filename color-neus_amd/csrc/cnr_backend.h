@@ -159,6 +159,7 @@ void be_split_planes(const float* src, int rows, int ld, unsigned short* planes,
 // all layers of a model in two launches (the per-layer launches are latency-bound: 57 launches of a few microseconds each)
 struct SplitJob { const float* src; int rows; int ld; unsigned short* planes; float* inv_scale; };
 void be_prep_weights(const PrepWeight* p, int count, cnr_stream s);
+void be_finish_weights(const FinishWeight* f, int count, cnr_stream s);   // every layer keeps its own partial buffer until this launch
 void be_split_planes_many(const SplitJob* jobs, int count, cnr_stream s);
 void be_finish_weight(const FinishWeight& p, cnr_stream s);
 void be_embed_z(const EmbedZ& p, cnr_stream s);

@@ -390,11 +390,8 @@ void be_prep_weight(const PrepWeight& p, cnr_stream s) {
 }
 
 // reduce dW partials, undo the column permutation, weight-norm backward.  One block per output row.
-__global__ __launch_bounds__(256) void finish_weight_kernel(const FinishWeight p) {
-  __shared__ float red[4];
-  __shared__ double redd[4];
-  __shared__ float dwi[512];
-  const int n = blockIdx.x, tid = threadIdx.x;       // internal row
+__device__ __forceinline__ void finish_weight_row(const FinishWeight& p, const int n, float* red, double* redd, float* dwi) {
+  const int tid = threadIdx.x;                        // n: internal row
   const int nr = (n + p.row_rot) % p.n;               // reference row
   for (int j = tid; j < p.ldk; j += 256) {
     // fixed-order reduction over the chunks, 8 independent loads in flight (same summation order as a plain loop)
@@ -449,6 +446,35 @@ __global__ __launch_bounds__(256) void finish_weight_kernel(const FinishWeight p
     s = block_sum_256(s, red);
     if (tid == 0) p.db[nr] = s;
   }
+}
+__global__ __launch_bounds__(256) void finish_weight_kernel(const FinishWeight p) {
+  __shared__ float red[4];
+  __shared__ double redd[4];
+  __shared__ float dwi[512];
+  finish_weight_row(p, blockIdx.x, red, redd, dwi);
+}
+constexpr int kFinishBatch = 24;
+struct FinishBatch { int count; int row_start[kFinishBatch + 1]; FinishWeight f[kFinishBatch]; };
+static_assert(sizeof(FinishBatch) <= 4096, "kernel argument block");
+__global__ __launch_bounds__(256) void finish_weight_batch_kernel(const FinishBatch b) {
+  __shared__ float red[4];
+  __shared__ double redd[4];
+  __shared__ float dwi[512];
+  int i = 0;
+  while (i + 1 < b.count && (int)blockIdx.x >= b.row_start[i + 1]) ++i;
+  finish_weight_row(b.f[i], (int)blockIdx.x - b.row_start[i], red, redd, dwi);
+}
+void be_finish_weights(const FinishWeight* f, int count, cnr_stream s) {
+  for (int i0 = 0; i0 < count; i0 += kFinishBatch) {
+    FinishBatch b;
+    b.count = count - i0 < kFinishBatch ? count - i0 : kFinishBatch;
+    int rows = 0;
+    for (int i = 0; i < b.count; ++i) { b.row_start[i] = rows; b.f[i] = f[i0 + i]; rows += f[i0 + i].n; }
+    b.row_start[b.count] = rows;
+    TimingScope ts_("finish_weight", 2, 0, rows, 0, 0, 0, s);
+    hipLaunchKernelGGL(finish_weight_batch_kernel, dim3(rows), dim3(256), 0, s, b);
+  }
+  CNR_LAUNCH_CHECK("finish_weight");
 }
 void be_finish_weight(const FinishWeight& p, cnr_stream s) {
   TimingScope ts_("finish_weight", 2, 0, p.n, 0, 0, 0, s);

@@ -16,6 +16,7 @@ const char* be_name() { return "cpu-emu"; }
 void be_split_planes(const float*, int, int, unsigned short*, float*, cnr_stream) {}
 void be_split_planes_many(const SplitJob*, int, cnr_stream) {}
 void be_prep_weights(const PrepWeight* p, int count, cnr_stream s) { for (int i = 0; i < count; ++i) be_prep_weight(p[i], s); }
+void be_finish_weights(const FinishWeight* f, int count, cnr_stream s) { for (int i = 0; i < count; ++i) be_finish_weight(f[i], s); }
 void be_timing_enable(int) {}
 int be_timing_collect(KernelTiming*, int) { return 0; }
 int be_check_last_error(char*, size_t) { return 0; }

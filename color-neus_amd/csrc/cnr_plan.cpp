@@ -308,9 +308,10 @@ struct Bwd {   // backward scratch
   std::vector<float*> rsX0, rsY1;   // row scales of the SDF cotangents z-bar_l (value pair) and q-bar_l (gradient-chain pair)
   float* rsD;                       // row scales of the colour / relight cotangent consumed right after its layer GEMM
   int* gexp;                        // common exponent of the current split-f16 weight-gradient GEMM
-  float *partial, *colsum;
+  float* partial;                     // pool of per-layer weight-gradient partial sums
+  size_t partial_floats, partial_off;
+  std::vector<FinishWeight> pending;  // reductions queued by run_dw, issued as one launch by flush_dw
   int nchunk; long chunk_pts;
-  size_t partial_floats;
 };
 
 static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
@@ -341,14 +342,16 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   if (nch > 256) nch = 256;
   b.nchunk = (int)nch;
   b.chunk_pts = round_up((int)((P + nch - 1) / nch), 16);
-  size_t mx = 0;
-  auto upd = [&](const Lin& q) { size_t s = (size_t)q.npad * q.ldw; if (s > mx) mx = s; };
+  // every layer keeps its own [nchunk][npad][ldw] partial sums (+ bias column sums) until one batched reduction at the end
+  size_t tot = 0;
+  auto upd = [&](const Lin& q) { tot += round_up_sz((size_t)b.nchunk * q.npad * q.ldw, 64) + round_up_sz((size_t)b.nchunk * q.npad, 64); };
   for (auto& q : m.sdf) upd(q);
   for (auto& q : m.col) upd(q);
   for (auto& q : m.rel) upd(q);
-  b.partial_floats = mx;
-  b.partial = a.f((size_t)b.nchunk * mx);
-  b.colsum = a.f((size_t)b.nchunk * 320);
+  b.partial_floats = tot;
+  b.partial = a.f(tot);
+  b.partial_off = 0;
+  b.pending.clear();
   b.rsX0.assign(m.L + 1, nullptr); b.rsY1.assign(m.L + 1, nullptr);
   for (int l = 1; l <= m.L; ++l) b.rsX0[l] = a.f(P);
   for (int l = 1; l < m.L; ++l) b.rsY1[l] = a.f(P);
@@ -637,10 +640,14 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
 }
 
 // ------------------------------------------------------------------------------------------------
-static void run_dw(const Model& m, const Lin& q, DwGemm& g, const Bwd& b, const float* const* params, float* const* dparams,
+static void run_dw(const Model& m, const Lin& q, DwGemm& g, Bwd& b, const float* const* params, float* const* dparams,
                    bool with_bias, cnr_stream s) {
+  float* part = b.partial + b.partial_off;
+  b.partial_off += round_up_sz((size_t)b.nchunk * q.npad * q.ldw, 64);
+  float* csum = b.partial + b.partial_off;
+  b.partial_off += round_up_sz((size_t)b.nchunk * q.npad, 64);
   g.N = q.n; g.K = q.k_int; g.nchunk = b.nchunk; g.chunk_pts = b.chunk_pts;
-  g.partial = b.partial; g.Npad = q.npad; g.ldk = q.ldw; g.colsum = with_bias ? b.colsum : nullptr;
+  g.partial = part; g.Npad = q.npad; g.ldk = q.ldw; g.colsum = with_bias ? csum : nullptr;
   // split-f16 tiles need the row scales of every operand of the 256 x 256 tiles (the top SDF layer's unit-vector pair is dropped there)
   const int need = (g.npairs == 2 && g.X[1].kind == VK_CONST_COL0) ? 1 : g.npairs;
   bool scaled = q.n > 32 && q.k_int > 64;
@@ -653,13 +660,18 @@ static void run_dw(const Model& m, const Lin& q, DwGemm& g, const Bwd& b, const 
   }
   be_dw_gemm(g, s);
   FinishWeight f;
-  f.partial = b.partial; f.nchunk = b.nchunk; f.npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? b.colsum : nullptr;
+  f.partial = part; f.nchunk = b.nchunk; f.npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? csum : nullptr;
   f.g = q.p_g >= 0 ? params[q.p_g] : nullptr; f.v = params[q.p_v];
   f.n = q.n; f.k_ref = q.k_ref; f.nseg = q.nseg;
   for (int i = 0; i < q.nseg; ++i) f.seg[i] = q.seg[i];
   f.dg = q.p_g >= 0 ? dparams[q.p_g] : nullptr; f.dv = dparams[q.p_v]; f.db = dparams[q.p_b]; f.row_rot = q.row_rot;
-  be_finish_weight(f, s);
+  b.pending.push_back(f);
   (void)m;
+}
+
+static void flush_dw(Bwd& b, cnr_stream s) {
+  if (!b.pending.empty()) be_finish_weights(b.pending.data(), (int)b.pending.size(), s);
+  b.pending.clear();
 }
 
 static int render_backward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
@@ -832,6 +844,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     if (l < m.L) { d.sx[1] = x.rsX1[l]; d.sy[1] = b.rsY1[l]; }
     run_dw(m, q, d, b, params, dP, true, s);
   }
+  flush_dw(b, s);   // all 19 partial-sum reductions + weight-norm backward in one launch
   // ---- 8. d rays (camera refinement configs)
   if (rays_grad) {
     PbarFinish pf;
