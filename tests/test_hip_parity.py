@@ -3,6 +3,10 @@
 Everything goes through the product route: nn.Module -> autograd.Function -> ctypes -> C ABI -> HIP kernels.
 Gates: G1 sampler z (atol 1e-3), G2 render_core at golden z (rel 1e-4: 12 outputs, all parameter grads,
 d rays), G3 end-to-end in the init regime (rel 1e-4)."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -117,6 +121,18 @@ def test_results_do_not_depend_on_scratch_contents():
             assert torch.equal(ref[2][k], got[2][k]), k
     for k in ref[4]:
         assert torch.equal(ref[4][k], got[4][k]), k
+
+
+@pytest.mark.parametrize("switch", ["CNR_DISABLE_WS", "CNR_WS_GENERIC", "CNR_DW_BF16", "CNR_DW_FP32"])
+def test_fallback_kernels_keep_parity(switch):
+    """The debugging switches select the fallback kernels (FP32-MFMA layer GEMM, interpreted weight-stationary kernel, split-bf16 and
+    FP32-MFMA weight-gradient tiles).  They are read once per process, so the G2 gate runs in a child process."""
+    env = dict(os.environ, **{switch: "1"})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_g2_render_core_forward_backward and sharp and det"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def _oracle_batch(R, seed):
