@@ -56,6 +56,24 @@ CNR_HD float fast_rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // nn.Softplus(beta=100, threshold=20)                                      (reference fields.py:77)
 // log1p(exp(t))/100 == max(z,0) + log(1 + exp(-|t|))/100 for every t; above the threshold the reference returns z
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CNR_CPU_EMU)
+// Device versions: straight-line code on the raw v_exp_f32 (2^x) / v_log_f32 (log2) / v_rcp_f32 units -- no range-reduction or
+// denormal fix-ups (the arguments are in (0,1] and [1,2]) and no branches: above the threshold exp(-t) < 2^-24, so 1 + e rounds to 1
+// and the log term / the sigmoid complement vanish exactly, which is the reference's threshold behaviour.
+CNR_HD float softplus100(float z) {
+  const float e = __builtin_amdgcn_exp2f(fabsf(z) * -144.26950408889634f);            // exp(-|100 z|)
+  return fmaxf(z, 0.0f) + __builtin_amdgcn_logf(1.0f + e) * 0.0069314718055994531f;  // log2(1 + e) * ln2 / 100
+}
+// d softplus / dz = sigmoid(100 z) (1 above the threshold)
+CNR_HD float softplus100_d1(float z) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -144.26950408889634f));
+}
+// d2 softplus / dz2 = 100 s (1-s) (0 above the threshold)
+CNR_HD float softplus100_d2(float z) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -144.26950408889634f));
+  return 100.0f * s * (1.0f - s);
+}
+#else
 CNR_HD float softplus100(float z) {
   float t = 100.0f * z;
   if (t > 20.0f) return z;
@@ -73,6 +91,7 @@ CNR_HD float softplus100_d2(float z) {
   float s = fast_rcp_(1.0f + fast_exp_(-t));
   return 100.0f * s * (1.0f - s);
 }
+#endif
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }

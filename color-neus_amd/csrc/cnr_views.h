@@ -41,10 +41,20 @@ CNR_HD Raw4 view_fetch4(const View& v, long row, int col) {
   return r;
 }
 
+// exact two-way select without a branch (the compiler otherwise wraps every element of a prologue in an exec-mask branch)
+CNR_HD float select_f32(bool c, float x, float y) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CNR_CPU_EMU)
+  const unsigned m = c ? 0xffffffffu : 0u;
+  return __uint_as_float((__float_as_uint(x) & m) | (__float_as_uint(y) & ~m));
+#else
+  return c ? x : y;
+#endif
+}
+
 CNR_HD float view_math1(const View& v, float a, float b, int col) {
   switch (v.kind) {
     case VK_DIRECT: return a;
-    case VK_SOFTPLUS: return col < v.math_split ? softplus100(a) : a;
+    case VK_SOFTPLUS: return select_f32(col < v.math_split, softplus100(a), a);
     case VK_SIGMUL:
     case VK_SIGMUL_ROW: return softplus100_d1(a) * b;
     default: return col == (v.math_split == (1 << 30) ? 0 : v.math_split) ? 1.0f : 0.0f;
