@@ -41,7 +41,9 @@ __device__ __forceinline__ void ws_put4(const f4& v, float sc, unsigned char* ds
 // instantiation only allocates the registers its own prologue and epilogue need (-1 = generic, interpreted at run time).
 // PLAIN promises an epilogue without tail fill and without a split point (most launches): that code folds away as well.
 // K17 admits a 17th k16 block (K up to 272: the layers whose input is a 256-wide hidden vector plus a few concatenated columns).
-template <int VK, int EK, bool PLAIN, bool K17 = false>
+// FULLK promises K > (NKB - 1) * 16, i.e. every k16 block is live: the per-block guards fold away and the LDS fragment reads of the
+// next block can be scheduled across the MFMAs of the current one.
+template <int VK, int EK, bool PLAIN, bool K17 = false, bool FULLK = false>
 __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const LayerGemm g_in, int tiles_per_wg, int wrows) {
   constexpr int NKB = K17 ? 17 : 16;
   LayerGemm g = g_in;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   if (t0 >= ntiles) return;
   long t1 = t0 + tiles_per_wg;
   if (t1 > ntiles) t1 = ntiles;
-  const int nkb = (g.K + 15) >> 4;              // 1..NKB k16 blocks
+  const int nkb = FULLK ? NKB : (g.K + 15) >> 4;   // 1..NKB k16 blocks
   const int kpad = nkb * 16;
   const int ald = kpad * 2 + 16;                // bytes per LDS row of one plane (+16: conflict-free ds_read_b128)
   const int aplane = WS_TP * ald;
@@ -205,8 +207,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
 #undef WS_MFMA
 }
 
-template <int VK, int EK, bool PLAIN, bool K17 = false>
-static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
+template <int VK, int EK, bool PLAIN, bool K17, bool FULLK>
+static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
   const int nkb = (g.K + 15) / 16;
   const int abuf = 2 * WS_TP * (nkb * 32 + 16) + 128;
   const size_t lds = (size_t)2 * abuf + (size_t)8 * 32 * WS_TLD * sizeof(float);
@@ -219,11 +221,18 @@ static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN, K17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN, K17, FULLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
-  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN, K17>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
+  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN, K17, FULLK>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
+}
+
+template <int VK, int EK, bool PLAIN, bool K17 = false>
+static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
+  const int nkb = (g.K + 15) / 16;
+  if (nkb == (K17 ? 17 : 16)) launch_ws_tk<VK, EK, PLAIN, K17, true>(g, wrows, s);
+  else launch_ws_tk<VK, EK, PLAIN, K17, false>(g, wrows, s);
 }
 
 }  // namespace cnr
