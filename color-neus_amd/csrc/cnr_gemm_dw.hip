@@ -389,6 +389,14 @@ static void launch_dw_bx(const DwGemm& g, int n0, int k0, cnr_stream s) {
 constexpr int DH_OPER = 2 * DX_PLANE;
 constexpr int DH_BUF = 2 * DH_OPER;
 
+// 2^G / sx for a power-of-two sx > 0 by exponent arithmetic (0 stays 0, NaN stays NaN, underflow flushes to 0)
+__device__ __forceinline__ float dh_yscale(float sx, int G) {
+  const unsigned bits = __float_as_uint(sx);
+  const int field = G - (int)((bits >> 23) & 0xff) + 254;      // biased exponent of 2^(G - log2 sx)
+  const float r = __uint_as_float((unsigned)(field < 1 ? 0 : (field > 254 ? 254 : field)) << 23);
+  return sx > 0.0f ? (field < 1 ? 0.0f : r) : sx;
+}
+
 template <int XK0, int YK0, int XK1, int YK1>
 __global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, int n0, int k0) {
   DwGemm g = g_in;
@@ -437,9 +445,10 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, i
     ra[i] = q_.a; rb[i] = q_.b;                                                            \
     rsx[i] = sxp_[pt];                                                                     \
   }
+  constexpr bool kOnePair = XK0 >= 0 && XK1 < 0;   // specialised single-pair instantiation: the pair index folds to 0
 #define DH_LOAD_SLAB(s_)                                                                   \
   {                                                                                        \
-    const int pair_ = (s_) / nslab_pair;                                                   \
+    const int pair_ = kOnePair ? 0 : (s_) / nslab_pair;                                    \
     staged_pair = pair_;                                                                   \
     const long pbase_ = ((long)((s_) - pair_ * nslab_pair) * g.nchunk + chunk) * 16 + q * 4; \
     const float* sxp_ = pair_ == 0 ? g.sx[0] : g.sx[1];                                    \
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, i
     }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
       float f_ = rsx[i];                                                                   \
-      if (is_y) f_ = f_ > 0.0f ? ldexpf(1.0f / f_, G) : (f_ == 0.0f ? 0.0f : f_);          \
+      if (is_y) f_ = dh_yscale(f_, G);                                                      \
       v_[i].x *= f_; v_[i].y *= f_; v_[i].z *= f_; v_[i].w *= f_;                          \
     }                                                                                      \
     unsigned char* d_ = sdst + (buf_) * DH_BUF;                                            \
