@@ -624,8 +624,18 @@ void be_dw_scale(const DwGemm& g, int* gexp, cnr_stream s) {
 // ================================================================================================
 constexpr int SK_WAVES = 8;
 
-template <bool NARROW_X, bool NG2>
-__global__ __launch_bounds__(SK_WAVES * 64) void dw_skinny_kernel(const DwGemm g, int n0, int k0, int ncnt) {
+// KINDS: 0 = interpreted views; 1 = every view VK_DIRECT with scale 1 (4 of the 5 strips of a step); 2 = the sdf row of the top
+// SDF layer (zbar x softplus(z) + unit vector x qbar).  With the kinds pinned the interpreted prologue folds away.
+template <bool NARROW_X, bool NG2, int KINDS>
+__global__ __launch_bounds__(SK_WAVES * 64) void dw_skinny_kernel(const DwGemm g_in, int n0, int k0, int ncnt) {
+  DwGemm g = g_in;
+  if (KINDS == 1) {
+    g.X[0].kind = VK_DIRECT; g.Y[0].kind = VK_DIRECT; g.X[1].kind = VK_DIRECT; g.Y[1].kind = VK_DIRECT;
+    g.X[0].scale = 1.0f; g.Y[0].scale = 1.0f; g.X[1].scale = 1.0f; g.Y[1].scale = 1.0f;
+  } else if (KINDS == 2) {
+    g.X[0].kind = VK_DIRECT; g.Y[0].kind = VK_SOFTPLUS; g.X[1].kind = VK_CONST_COL0; g.Y[1].kind = VK_DIRECT;
+    g.X[0].scale = 1.0f; g.Y[1].scale = 1.0f;
+  }
   constexpr int SK_UNROLL = NG2 ? 4 : 8;
   extern __shared__ __attribute__((aligned(16))) float smem_k[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -645,8 +655,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void dw_skinny_kernel(const DwGemm g
   const long my_pts = my_slabs * (16 / SK_WAVES);       // per wave
   const f4 z4 = {0.f, 0.f, 0.f, 0.f};
   for (int pair = 0; pair < g.npairs; ++pair) {
-    const View& Vn = NARROW_X ? g.X[pair] : g.Y[pair];
-    const View& Vw = NARROW_X ? g.Y[pair] : g.X[pair];
+    const View& Vn = NARROW_X ? (pair == 0 ? g.X[0] : g.X[1]) : (pair == 0 ? g.Y[0] : g.Y[1]);
+    const View& Vw = NARROW_X ? (pair == 0 ? g.Y[0] : g.Y[1]) : (pair == 0 ? g.X[0] : g.X[1]);
     for (long i0 = 0; i0 < my_pts; i0 += SK_UNROLL) {
       // all loads of the round are issued before any of the (interpreted) view math: one memory round trip per round
       Raw4 wr[SK_UNROLL], nr0[SK_UNROLL], nr1[SK_UNROLL];
@@ -708,18 +718,29 @@ __global__ __launch_bounds__(SK_WAVES * 64) void dw_skinny_kernel(const DwGemm g
   }
 }
 
-template <bool NARROW_X, bool NG2>
-static void launch_dw_skinny_t(const DwGemm& g, int n0, int k0, int ncnt, cnr_stream s) {
+template <bool NARROW_X, bool NG2, int KINDS>
+static void launch_dw_skinny_td(const DwGemm& g, int n0, int k0, int ncnt, cnr_stream s) {
   const size_t lds = ((size_t)SK_WAVES * 8 * 256 + SK_WAVES * 8) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_skinny_kernel<NARROW_X, NG2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_skinny_kernel<NARROW_X, NG2, KINDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int wide = NARROW_X ? ((g.K - k0) < 256 ? (g.K - k0) : 256) : ((g.N - n0) < 256 ? (g.N - n0) : 256);
   const int tn_ = NARROW_X ? ncnt : wide, tk_ = NARROW_X ? wide : ncnt;
   TimingScope ts_("dw_skinny", 1, NARROW_X ? 1 : 2, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
-  hipLaunchKernelGGL((dw_skinny_kernel<NARROW_X, NG2>), dim3(g.nchunk), dim3(SK_WAVES * 64), lds, s, g, n0, k0, ncnt);
+  hipLaunchKernelGGL((dw_skinny_kernel<NARROW_X, NG2, KINDS>), dim3(g.nchunk), dim3(SK_WAVES * 64), lds, s, g, n0, k0, ncnt);
+}
+
+template <bool NARROW_X, bool NG2>
+static void launch_dw_skinny_t(const DwGemm& g, int n0, int k0, int ncnt, cnr_stream s) {
+  bool direct = true;
+  for (int i = 0; i < g.npairs; ++i) direct = direct && g.X[i].kind == VK_DIRECT && g.Y[i].kind == VK_DIRECT && g.X[i].scale == 1.0f && g.Y[i].scale == 1.0f;
+  const bool sdf_row = NARROW_X && g.npairs == 2 && g.X[0].kind == VK_DIRECT && g.X[0].scale == 1.0f && g.Y[0].kind == VK_SOFTPLUS &&
+                       g.X[1].kind == VK_CONST_COL0 && g.Y[1].kind == VK_DIRECT && g.Y[1].scale == 1.0f;
+  if (direct) launch_dw_skinny_td<NARROW_X, NG2, 1>(g, n0, k0, ncnt, s);
+  else if (sdf_row) launch_dw_skinny_td<NARROW_X, NG2, 2>(g, n0, k0, ncnt, s);
+  else launch_dw_skinny_td<NARROW_X, NG2, 0>(g, n0, k0, ncnt, s);
 }
 
 template <bool NARROW_X>
