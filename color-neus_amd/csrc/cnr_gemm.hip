@@ -22,6 +22,16 @@
 namespace cnr {
 
 static void dispatch_layer_gemm(const LayerGemm& g, int nt, cnr_stream s) {
+  // the narrow launches of the render plan (sdf / rgb / embedding-cotangent columns) with their kinds pinned at compile time
+  const int vk = g.A.kind, ek = g.E.kind;
+#define LG_CASE(V_, E_)                                                              \
+  if (vk == V_ && ek == E_ && nt <= 2) {                                              \
+    if (nt == 1) launch_layer_gemm<1, V_, E_>(g, s); else launch_layer_gemm<2, V_, E_>(g, s); \
+    return;                                                                           \
+  }
+  LG_CASE(VK_SOFTPLUS, EK_STORE) LG_CASE(VK_SIGMUL, EK_STORE) LG_CASE(VK_DIRECT, EK_STORE) LG_CASE(VK_DIRECT, EK_SIGMOID)
+  LG_CASE(VK_DIRECT, EK_RELIGHT_TOP) LG_CASE(VK_DIRECT, EK_RELU_MASK) LG_CASE(VK_DIRECT, EK_SPLIT)
+#undef LG_CASE
   switch (nt) {
     case 1: launch_layer_gemm<1>(g, s); break;
     case 2: launch_layer_gemm<2>(g, s); break;

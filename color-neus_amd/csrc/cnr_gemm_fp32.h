@@ -45,7 +45,8 @@ __device__ __forceinline__ void lg_epilogue_tiles(const f32x16 (&acc)[NT], const
   }
 }
 
-template <int NT>
+// VK / EK >= 0 pin the view / epilogue kind at compile time (used for the narrow launches of the render plan)
+template <int NT, int VK = -1, int EK = -1>
 __global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                            // [2][128][LG_LD]
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
   long arow0 = row0 + ar0, arow1 = row0 + ar1;
   if (arow0 >= Pn) arow0 = Pn - 1;             // clamp: rows beyond P are computed on valid data and dropped in the epilogue
   if (arow1 >= Pn) arow1 = Pn - 1;
-  const View A = g.A;
+  View A = g.A;
+  if (VK >= 0) A.kind = VK;
   const bool has_b = A.kind == VK_SIGMUL || A.kind == VK_SIGMUL_ROW;
   const float* a0p = A.a + arow0 * A.lda + ac4;
   const float* a1p = A.a + arow1 * A.lda + ac4;
@@ -135,23 +137,24 @@ __global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
 
   // ---- epilogue: transpose each 32x32 accumulator tile through a wave-private LDS tile, then 4 columns per lane
   float* T = smem + wave * (32 * LG_TLD);
-  const Epi e = g.E;
+  Epi e = g.E;
+  if (EK >= 0) e.kind = EK;
   const int ncols_live = e.n_out + (e.tail_src ? e.tail_n : 0);
   lg_epilogue_tiles<NT, 0>(acc, e, T, row0 + wave * 32, Pn, lane, ncols_live, g.col0);
 }
 
-template <int NT>
+template <int NT, int VK = -1, int EK = -1>
 void launch_layer_gemm(const LayerGemm& g, cnr_stream s) {
   const size_t lds = (size_t)(2 * LG_BM * LG_LD + 2 * NT * 32 * LG_LD) * sizeof(float);
   const unsigned grid = (unsigned)((g.P + LG_BM - 1) / LG_BM);
   if (grid == 0) return;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_kernel<NT, VK, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   TimingScope ts_("layer_gemm", 0, NT, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
-  hipLaunchKernelGGL(layer_gemm_kernel<NT>, dim3(grid), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((layer_gemm_kernel<NT, VK, EK>), dim3(grid), dim3(256), lds, s, g);
 }
 
 
