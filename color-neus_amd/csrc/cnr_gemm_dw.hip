@@ -16,7 +16,7 @@ namespace cnr {
 // points per slab: 16 for the square tile; the skinny tail tiles are latency-bound streams, so they take as many as LDS holds
 constexpr int dw_bp(int tn, int tk) { return tn + tk <= 288 ? 64 : (tn + tk <= 320 ? 48 : 16); }
 
-template <int WR, int WC, int MT, int KT>
+template <int WR, int WC, int MT, int KT, int KINDS = 0>
 __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, int k0) {
   constexpr int TN = WR * MT * 32, TK = WC * KT * 32;
   constexpr int DW_BP = dw_bp(TN, TK);
@@ -48,13 +48,13 @@ __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, in
   float csum = 0.0f;
   const bool want_colsum = g.colsum != nullptr && k0 == 0;
 
-#define DW_LOAD_SLAB(s_)                                                                                  \
+  // local views with the kinds pinned for the specialised instantiations (KINDS: 0 interpreted, 1 single pair all-direct, 2 SDF layer 0)
+  View vX0 = g.X[0], vY0 = g.Y[0], vX1 = g.X[1], vY1 = g.Y[1];
+  if (KINDS == 1) { vX0.kind = VK_DIRECT; vY0.kind = VK_DIRECT; vX0.scale = 1.0f; vY0.scale = 1.0f; }
+  if (KINDS == 2) { vX0.kind = VK_DIRECT; vY0.kind = VK_DIRECT; vX1.kind = VK_SIGMUL; vY1.kind = VK_DIRECT;
+                    vX0.scale = 1.0f; vY0.scale = 1.0f; vX1.scale = 1.0f; vY1.scale = 1.0f; }
+#define DW_FETCH_(X_, Y_)                                                                                 \
   {                                                                                                       \
-    const int pair_ = (s_) / nslab_pair;                                                                  \
-    staged_pair = pair_;                                                                                  \
-    const long pbase_ = p_begin + (long)((s_) - pair_ * nslab_pair) * DW_BP;                              \
-    const View& X_ = g.X[pair_];                                                                          \
-    const View& Y_ = g.Y[pair_];                                                                          \
     _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
       const int idx = tid + i * 512;                                                                      \
       if (NX_EXACT || idx < DW_BP * TN / 4) {                                                             \
@@ -78,14 +78,20 @@ __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, in
       }                                                                                                   \
     }                                                                                                     \
   }
-#define DW_STORE_SLAB(buf_)                                                                               \
+#define DW_LOAD_SLAB(s_)                                                                                  \
   {                                                                                                       \
-    const f4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                                  \
+    const int pair_ = KINDS == 1 ? 0 : (s_) / nslab_pair;                                                 \
+    staged_pair = pair_;                                                                                  \
+    const long pbase_ = p_begin + (long)((s_) - pair_ * nslab_pair) * DW_BP;                              \
+    if (pair_ == 0) DW_FETCH_(vX0, vY0) else DW_FETCH_(vX1, vY1)                                          \
+  }
+#define DW_FINISH_(X_, Y_, buf_)                                                                          \
+  {                                                                                                       \
     _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                                      \
       const int idx = tid + i * 512;                                                                      \
       if (NX_EXACT || idx < DW_BP * TN / 4) {                                                             \
         Raw4 q_; q_.a = rxa[i]; q_.b = rxb[i];                                                            \
-        const f4 v_ = view_finish4(g.X[staged_pair], q_, n0 + (idx % (TN / 4)) * 4);                      \
+        const f4 v_ = view_finish4(X_, q_, n0 + (idx % (TN / 4)) * 4);                                    \
         *reinterpret_cast<f4*>(Xs + (buf_) * DW_BP * TN + idx * 4) = okx[i] ? v_ : z4_;                   \
       }                                                                                                   \
     }                                                                                                     \
@@ -93,10 +99,15 @@ __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, in
       const int idx = tid + i * 512;                                                                      \
       if (NY_EXACT || idx < DW_BP * TK / 4) {                                                             \
         Raw4 q_; q_.a = rya[i]; q_.b = ryb[i];                                                            \
-        const f4 v_ = view_finish4(g.Y[staged_pair], q_, k0 + (idx % (TK / 4)) * 4);                      \
+        const f4 v_ = view_finish4(Y_, q_, k0 + (idx % (TK / 4)) * 4);                                    \
         *reinterpret_cast<f4*>(Ys + (buf_) * DW_BP * TK + idx * 4) = oky[i] ? v_ : z4_;                   \
       }                                                                                                   \
     }                                                                                                     \
+  }
+#define DW_STORE_SLAB(buf_)                                                                               \
+  {                                                                                                       \
+    const f4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                                  \
+    if (staged_pair == 0) DW_FINISH_(vX0, vY0, buf_) else DW_FINISH_(vX1, vY1, buf_)                      \
   }
 
   if (nslab > 0) {
@@ -131,6 +142,8 @@ __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, in
   }
 #undef DW_LOAD_SLAB
 #undef DW_STORE_SLAB
+#undef DW_FETCH_
+#undef DW_FINISH_
 
   float* out = g.partial + chunk * (long)g.Npad * g.ldk;
 #pragma unroll
@@ -147,19 +160,19 @@ __global__ __launch_bounds__(512) void dw_gemm_kernel(const DwGemm g, int n0, in
   if (want_colsum && tid < TN && n0 + tid < g.Npad) g.colsum[chunk * g.Npad + n0 + tid] = csum;
 }
 
-template <int WR, int WC, int MT, int KT>
+template <int WR, int WC, int MT, int KT, int KINDS = 0>
 static void launch_dw(const DwGemm& g, int n0, int k0, cnr_stream s) {
   constexpr int TN = WR * MT * 32, TK = WC * KT * 32;
   constexpr int DW_BP = dw_bp(TN, TK);
   const size_t lds = (size_t)(2 * DW_BP * (TN + TK)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_kernel<WR, WC, MT, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_kernel<WR, WC, MT, KT, KINDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int tn_ = (g.N - n0) < TN ? (g.N - n0) : TN, tk_ = (g.K - k0) < TK ? (g.K - k0) : TK;
   TimingScope ts_("dw_gemm", 1, WR * 1000 + WC * 100 + MT * 10 + KT, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
-  hipLaunchKernelGGL((dw_gemm_kernel<WR, WC, MT, KT>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
+  hipLaunchKernelGGL((dw_gemm_kernel<WR, WC, MT, KT, KINDS>), dim3(g.nchunk), dim3(512), lds, s, g, n0, k0);
 }
 
 // ================================================================================================
@@ -773,7 +786,14 @@ void be_dw_gemm(const DwGemm& g, cnr_stream s) {
           k0 += 256;
         }
         else if (krem <= 8 && !dw_fp32 && !(g.colsum != nullptr && k0 == 0) && (k0 & 3) == 0) { launch_dw_skinny<false>(g, n0, k0, krem, s); k0 += 64; }
-        else { launch_dw<8, 1, 1, 2>(g, n0, k0, s); k0 += 64; }
+        else {   // 9..64-column strips (embedding inputs): FP32-MFMA tile, view kinds pinned for the two shapes of the plan
+          const bool d0 = g.X[0].kind == VK_DIRECT && g.Y[0].kind == VK_DIRECT && g.X[0].scale == 1.0f && g.Y[0].scale == 1.0f;
+          if (g.npairs == 1 && d0) launch_dw<8, 1, 1, 2, 1>(g, n0, k0, s);
+          else if (g.npairs == 2 && d0 && g.X[1].kind == VK_SIGMUL && g.Y[1].kind == VK_DIRECT && g.X[1].scale == 1.0f && g.Y[1].scale == 1.0f)
+            launch_dw<8, 1, 1, 2, 2>(g, n0, k0, s);
+          else launch_dw<8, 1, 1, 2>(g, n0, k0, s);
+          k0 += 64;
+        }
       } else if (nrem <= 8 && !dw_fp32 && (n0 & 3) == 0) {
         launch_dw_skinny<true>(g, n0, k0, nrem, s); k0 += 256;
       } else {
