@@ -267,6 +267,27 @@ class NeuSRenderer(nn.Module):
         named = dict(self.named_parameters())
         return [named[k] for k in self._order]
 
+    def _jitter_to_device(self, t_cpu, dev):
+        """H2D copy of the per-ray jitter without stalling the host: a plain .to(device) from pageable memory blocks until the
+        stream has drained, i.e. once per step.  Two pinned staging buffers are used alternately; an event per buffer guards reuse."""
+        if dev.type != "cuda":
+            return t_cpu.to(dev)
+        n = t_cpu.shape[0]
+        st = getattr(self, "_jit_stage", None)
+        if st is None or st["n"] != n or st["dev"] != dev:
+            st = {"n": n, "dev": dev, "i": 0, "buf": [torch.empty(n, 1, pin_memory=True) for _ in range(2)], "ev": [None, None]}
+            self._jit_stage = st
+        i = st["i"]
+        st["i"] = 1 - i
+        if st["ev"][i] is not None:
+            st["ev"][i].synchronize()          # the copy issued two calls ago
+        st["buf"][i].copy_(t_cpu)
+        out = st["buf"][i].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        st["ev"][i] = ev
+        return out
+
     # -- NeuS.forward (NeuS.py:294-408) -------------------------------------------------------------------------------
     def forward(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0, z_vals=None,
                 prune_eps=0.0, **kwargs):
@@ -281,7 +302,7 @@ class NeuSRenderer(nn.Module):
             perturb = perturb_overwrite
         t_rand = None
         if perturb > 0 and z_vals is None:
-            t_rand = torch.rand([n_rays, 1]).to(dev)   # CPU generator, exactly like NeuS.py:325
+            t_rand = self._jitter_to_device(torch.rand([n_rays, 1]), dev)   # CPU generator, exactly like NeuS.py:325
         bg = None
         if background_rgb is not None:
             bg = torch.as_tensor(background_rgb, dtype=torch.float32, device=dev).reshape(-1)[:3].contiguous()
