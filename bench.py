@@ -136,7 +136,10 @@ def main():
     result = {
         "metric": "rays/sec (fwd+bwd) at 128 samples/ray", "value": round(value, 1), "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "dtype_note": "fp32 tensors and fp32 accumulation; matrix products through error-free f16 hi/lo splits of the fp32 operands "
+                      "(3 MFMAs per product, exact power-of-two scaling), parity gate 1e-4 relative",
+        "data": "synthetic",
         "config": {"workload": "Color_NeuS_dtu.yml renderer block (SDF 8x256 + colour 4x256 + relight 4x256), synthetic 800x800 "
                                "view, %d rays/step/GPU x (64+64) samples, trained-like weights" % R,
                    "rays_per_step_per_gpu": R, "samples_per_ray": M, "parallelism": "ray-sharded dp%d" % world,
