@@ -215,7 +215,7 @@ static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
   const long ntiles = (g.P + WS_TP - 1) / WS_TP;
   if (ntiles == 0) return;
   static const int ws_wgs = getenv("CNR_WS_WGS") ? atoi(getenv("CNR_WS_WGS")) : 256;       // tuning knobs (defaults measured on MI355X)
-  static const int ws_mintpw = getenv("CNR_WS_MINTPW") ? atoi(getenv("CNR_WS_MINTPW")) : 8;
+  static const int ws_mintpw = getenv("CNR_WS_MINTPW") ? atoi(getenv("CNR_WS_MINTPW")) : 1;
   long tpw = (ntiles + ws_wgs - 1) / ws_wgs;   // one workgroup per CU: the weights are loaded once per CU (measured best of 256 / 512 / 768 / 1024)
   if (tpw < ws_mintpw) tpw = ws_mintpw;
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
