@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the CPU baseline (16 was the fastest of {8,16,32,64,128} on the 2x64-core bench host)")
+    ap.add_argument("--torch-loss", action="store_true", help="evaluate the loss with torch ops instead of the library's fused loss kernels")
     ap.add_argument("--torch-gpu-baseline", action="store_true", help="also time the plain-PyTorch restatement on the GPU")
     return ap.parse_args()
 
@@ -98,10 +99,13 @@ def main():
     def step(i):
         o, d, near, far, gt, mask = batch(i)
         out = renderer(o, d, near, far)
-        if world == 1:
-            loss, _ = cn.compute_loss(out, gt, mask)
-        else:
-            loss, _ = parallel.sharded_loss(out, gt, mask, n_rays_global=Rg, n_samples=M)
+        if args.torch_loss:    # the torch restatement of compute_loss (and its sharded counterpart)
+            if world == 1:
+                loss, _ = cn.compute_loss(out, gt, mask)
+            else:
+                loss, _ = parallel.sharded_loss(out, gt, mask, n_rays_global=Rg, n_samples=M)
+        else:                  # loss kernels of the render library; ray-sharded runs all-reduce 5 floats between their two phases
+            loss, _ = cn.compute_loss_fused(out, gt, mask, n_rays_global=Rg if world > 1 else None, library=lib)
         for p in params:
             p.grad = None
         loss.backward()
@@ -143,7 +147,7 @@ def main():
         "config": {"workload": "Color_NeuS_dtu.yml renderer block (SDF 8x256 + colour 4x256 + relight 4x256), synthetic 800x800 "
                                "view, %d rays/step/GPU x (64+64) samples, trained-like weights" % R,
                    "rays_per_step_per_gpu": R, "samples_per_ray": M, "parallelism": "ray-sharded dp%d" % world,
-                   "step": "fwd+loss+bwd" + ("" if args.no_optim else "+clip+adam") + ("+rccl-allreduce" if world > 1 else ""),
+                   "step": "fwd+" + ("torch-loss" if args.torch_loss else "fused-loss") + "+bwd" + ("" if args.no_optim else "+clip+adam") + ("+rccl-allreduce" if world > 1 else ""),
                    "final_loss": float(loss.detach())},
     }
 

@@ -44,6 +44,11 @@ class CnrKernelTiming(C.Structure):
                 ("K", C.c_int32), ("pairs", C.c_int32), ("ms", C.c_float), ("bytes", C.c_double)]
 
 
+class CnrLossConfig(C.Structure):
+    _fields_ = [("lambda_fine", C.c_float), ("lambda_eikonal", C.c_float), ("lambda_mask", C.c_float), ("lambda_relight", C.c_float),
+                ("rgb_l1", C.c_int32), ("include_mask", C.c_int32)]
+
+
 class CnrInGrads(C.Structure):
     _fields_ = [("d_params", C.POINTER(_FP)), ("d_rays_o", _FP), ("d_rays_d", _FP)]
 
@@ -69,7 +74,7 @@ def c_config(cfg) -> CnrConfig:
 EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_count", "cnr_param_info", "cnr_ctx_bytes",
            "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
-           "cnr_timing_enable", "cnr_timing_collect"]
+           "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_grads"]
 
 
 class RenderLibrary:
@@ -99,6 +104,10 @@ class RenderLibrary:
         L.cnr_sdf_grid.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32,
                                    _FP, _FP, C.c_size_t, _FP]
         L.cnr_vertex_color.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), _FP, C.c_int64, _FP, _FP, C.c_size_t, _FP]
+        L.cnr_loss_scratch_bytes.restype = C.c_size_t
+        L.cnr_loss_scratch_bytes.argtypes = [C.c_int64]
+        L.cnr_loss_sums.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_size_t, _FP]
+        L.cnr_loss_grads.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, _FP]
         L.cnr_timing_enable.argtypes = [C.c_int]
         L.cnr_timing_enable.restype = None
         L.cnr_timing_collect.argtypes = [C.POINTER(CnrKernelTiming), C.c_int]

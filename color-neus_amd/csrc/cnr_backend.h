@@ -181,6 +181,15 @@ void be_variance_finish(const VarianceFinish& p, cnr_stream s);
 void be_pbar_finish(const PbarFinish& p, cnr_stream s);
 void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s);
 void be_memset_zero(void* p, size_t bytes, cnr_stream s);
+
+// training loss (include/colorneus_render.h, cnr_loss_*): partial sums [nblk][4] -> sums[4]; gradients w.r.t. the renderer outputs
+struct LossArgs {
+  const float* color; const float* wsum; const float* drel; const float* gt; const float* mask;
+  long R; int M; int rgb_l1; int include_mask;
+};
+constexpr int kLossBlocks = 256;
+void be_loss_sums(const LossArgs& a, float* partial /* [kLossBlocks][4] */, float* sums /* [4] */, cnr_stream s);
+void be_loss_grads(const LossArgs& a, const float* coef, float* d_color, float* d_wsum, float* d_drel, cnr_stream s);
 // p[row][c] = 0 for c in [c0, c1), row < rows: zero the pad columns a GEMM reads without touching the rest of a wide buffer
 void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream s);
 void be_grid_points(float* pts /*unused*/, cnr_stream s);

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "cnr_backend.h"
+#include "cnr_loss.h"
 #include "cnr_bodies.h"
 #include "cnr_hip_util.h"
 
@@ -480,6 +481,59 @@ void be_finish_weight(const FinishWeight& p, cnr_stream s) {
   TimingScope ts_("finish_weight", 2, 0, p.n, 0, 0, 0, s);
   hipLaunchKernelGGL(finish_weight_kernel, dim3(p.n), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("finish_weight");
+}
+
+// ================================================================================================
+// training loss: block partial sums in a fixed order, then one block folds the partials; gradients are element-wise
+// ================================================================================================
+__global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs a, float* partial) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, nb = gridDim.x, b = blockIdx.x;
+  float s_rgb = 0.f, s_bce = 0.f, s_rel = 0.f;
+  const long n_rgb = a.R * 3;
+  for (long i = (long)b * 256 + tid; i < n_rgb; i += (long)nb * 256) s_rgb += loss_rgb_term(a.color[i], a.gt[i], a.rgb_l1);
+  if (a.mask)
+    for (long r = (long)b * 256 + tid; r < a.R; r += (long)nb * 256) s_bce += loss_bce_term(a.wsum[r], a.mask[r]);
+  if (a.drel) {
+    const long per_ray = (long)a.M * 3, n_rel = a.R * per_ray;
+    for (long i = (long)b * 256 + tid; i < n_rel; i += (long)nb * 256) {
+      const float m = (a.include_mask && a.mask) ? a.mask[i / per_ray] : 1.0f;
+      s_rel += a.drel[i] * m;
+    }
+  }
+  s_rgb = block_sum_256(s_rgb, red);
+  s_bce = block_sum_256(s_bce, red);
+  s_rel = block_sum_256(s_rel, red);
+  if (tid == 0) { partial[b * 4 + 0] = s_rgb; partial[b * 4 + 1] = s_bce; partial[b * 4 + 2] = s_rel; partial[b * 4 + 3] = 0.f; }
+}
+__global__ __launch_bounds__(256) void loss_fold_kernel(const float* partial, int nb, float* sums) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float v[3] = {0.f, 0.f, 0.f};
+  for (int b = tid; b < nb; b += 256) { v[0] += partial[b * 4]; v[1] += partial[b * 4 + 1]; v[2] += partial[b * 4 + 2]; }
+  for (int j = 0; j < 3; ++j) { const float s = block_sum_256(v[j], red); if (tid == 0) sums[j] = s; }
+  if (tid == 0) sums[3] = 0.f;
+}
+void be_loss_sums(const LossArgs& a, float* partial, float* sums, cnr_stream s) {
+  TimingScope ts_("loss_sums", 2, 0, a.R, 0, 0, 0, s);
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(kLossBlocks), dim3(256), 0, s, a, partial);
+  hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(256), 0, s, partial, kLossBlocks, sums);
+  CNR_LAUNCH_CHECK("loss_sums");
+}
+__global__ __launch_bounds__(256) void loss_grads_kernel(const LossArgs a, const float* coef, float* d_color, float* d_wsum, float* d_drel) {
+  const float c_rgb = coef[0], c_bce = coef[1], c_rel = coef[2];
+  const long n_rgb = a.R * 3, per_ray = (long)a.M * 3, n_rel = a.drel || d_drel ? a.R * per_ray : 0;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_rgb; i += stride) d_color[i] = c_rgb * loss_rgb_grad(a.color[i], a.gt[i], a.rgb_l1);
+  if (d_wsum)
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < a.R; r += stride) d_wsum[r] = a.mask ? c_bce * loss_bce_grad(a.wsum[r], a.mask[r]) : 0.0f;
+  if (d_drel)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_rel; i += stride) d_drel[i] = c_rel * ((a.include_mask && a.mask) ? a.mask[i / per_ray] : 1.0f);
+}
+void be_loss_grads(const LossArgs& a, const float* coef, float* d_color, float* d_wsum, float* d_drel, cnr_stream s) {
+  TimingScope ts_("loss_grads", 2, 0, a.R, 0, 0, 0, s);
+  hipLaunchKernelGGL(loss_grads_kernel, dim3(1024), dim3(256), 0, s, a, coef, d_color, d_wsum, d_drel);
+  CNR_LAUNCH_CHECK("loss_grads");
 }
 
 __global__ __launch_bounds__(256) void reduce_eik_kernel(const ReduceEik p) {

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "cnr_backend.h"
+#include "cnr_loss.h"
 #include "cnr_bodies.h"
 
 namespace cnr {
@@ -21,6 +22,25 @@ void be_timing_enable(int) {}
 int be_timing_collect(KernelTiming*, int) { return 0; }
 int be_check_last_error(char*, size_t) { return 0; }
 void be_memset_zero(void* p, size_t bytes, cnr_stream) { memset(p, 0, bytes); }
+void be_loss_sums(const LossArgs& a, float* partial, float* sums, cnr_stream) {
+  (void)partial;
+  double s_rgb = 0, s_bce = 0, s_rel = 0;   // (the emulation only has to agree with the oracle to test tolerance, not bitwise with the GPU)
+  for (long i = 0; i < a.R * 3; ++i) s_rgb += loss_rgb_term(a.color[i], a.gt[i], a.rgb_l1);
+  if (a.mask) for (long r = 0; r < a.R; ++r) s_bce += loss_bce_term(a.wsum[r], a.mask[r]);
+  if (a.drel) {
+    const long per_ray = (long)a.M * 3;
+    for (long i = 0; i < a.R * per_ray; ++i) s_rel += a.drel[i] * ((a.include_mask && a.mask) ? a.mask[i / per_ray] : 1.0f);
+  }
+  sums[0] = (float)s_rgb; sums[1] = (float)s_bce; sums[2] = (float)s_rel; sums[3] = 0.f;
+}
+void be_loss_grads(const LossArgs& a, const float* coef, float* d_color, float* d_wsum, float* d_drel, cnr_stream) {
+  for (long i = 0; i < a.R * 3; ++i) d_color[i] = coef[0] * loss_rgb_grad(a.color[i], a.gt[i], a.rgb_l1);
+  if (d_wsum) for (long r = 0; r < a.R; ++r) d_wsum[r] = a.mask ? coef[1] * loss_bce_grad(a.wsum[r], a.mask[r]) : 0.0f;
+  if (d_drel) {
+    const long per_ray = (long)a.M * 3;
+    for (long i = 0; i < a.R * per_ray; ++i) d_drel[i] = coef[2] * ((a.include_mask && a.mask) ? a.mask[i / per_ray] : 1.0f);
+  }
+}
 void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream) {
   for (long r = 0; r < rows; ++r) for (int c = c0; c < c1; ++c) p[r * ld + c] = 0.0f;
 }

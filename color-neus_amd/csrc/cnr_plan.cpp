@@ -999,6 +999,39 @@ int cnr_render_backward(const cnr_config* cfg, const float* const* params, const
 
 void cnr_timing_enable(int on) { be_timing_enable(on); }
 
+size_t cnr_loss_scratch_bytes(int64_t n_rays) { (void)n_rays; return (size_t)kLossBlocks * 4 * sizeof(float); }
+
+static int loss_args(const cnr_loss_config* cfg, const float* color, const float* wsum, const float* drel, const float* gt, const float* mask,
+                     int64_t n_rays, int32_t n_samples, LossArgs& a) {
+  if (!cfg || !color || !gt) return fail("null argument");
+  if (n_rays <= 0 || n_samples <= 0) return fail("n_rays and n_samples must be positive");
+  a.color = color; a.wsum = wsum; a.drel = drel; a.gt = gt; a.mask = mask; a.R = n_rays; a.M = n_samples;
+  a.rgb_l1 = cfg->rgb_l1; a.include_mask = cfg->include_mask;
+  return 0;
+}
+
+int cnr_loss_sums(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight, const float* rgb_gt,
+                  const float* mask, int64_t n_rays, int32_t n_samples, float* sums, void* scratch, size_t scratch_bytes, void* stream) {
+  LossArgs a;
+  if (loss_args(cfg, color_fine, weight_sum, delta_relight, rgb_gt, mask, n_rays, n_samples, a)) return -1;
+  if (!sums || !scratch) return fail("null argument");
+  if (mask && !weight_sum) return fail("weight_sum is required with a mask");
+  if (scratch_bytes < cnr_loss_scratch_bytes(n_rays)) return fail("loss scratch too small");
+  be_loss_sums(a, static_cast<float*>(scratch), sums, (cnr_stream)stream);
+  return check_backend("loss_sums");
+}
+
+int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* rgb_gt, const float* mask,
+                   int64_t n_rays, int32_t n_samples, const float* coef, float* d_color_fine, float* d_weight_sum, float* d_delta_relight,
+                   void* stream) {
+  LossArgs a;
+  if (loss_args(cfg, color_fine, weight_sum, nullptr, rgb_gt, mask, n_rays, n_samples, a)) return -1;
+  if (!coef || !d_color_fine) return fail("null argument");
+  if (d_weight_sum && mask && !weight_sum) return fail("weight_sum is required with a mask");
+  be_loss_grads(a, coef, d_color_fine, d_weight_sum, d_delta_relight, (cnr_stream)stream);
+  return check_backend("loss_grads");
+}
+
 int cnr_timing_collect(cnr_kernel_timing* out, int max_records) {
   static_assert(sizeof(cnr_kernel_timing) == sizeof(KernelTiming), "timing record layout");
   return be_timing_collect(reinterpret_cast<KernelTiming*>(out), max_records);

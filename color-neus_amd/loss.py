@@ -29,3 +29,120 @@ def compute_loss(render_dict, rgb_gt, mask=None, lambda_fine=1.0, lambda_eikonal
         loss_dict["relight_loss"] = relight_loss
     loss_dict["loss"] = loss
     return loss, loss_dict
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fused version: the same objective through two kernels of the render library (cnr_loss_sums /
+# cnr_loss_grads, include/colorneus_render.h) instead of ~25 element-wise / reduction launches and their autograd graph.
+# Ray-sharded runs pass n_rays_global (+ group): one 5-float all-reduce between the two phases reproduces the single-GPU
+# objective exactly (same construction as parallel.sharded_loss).
+# ---------------------------------------------------------------------------------------------------------------------
+import ctypes as _C
+
+
+def _p(t):
+    return _C.c_void_p(t.data_ptr()) if t is not None else _C.c_void_p(0)
+
+
+def _stream(t):
+    return _C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else _C.c_void_p(0)
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lib, lcfg, lambdas, n_rays_global, group, color, wsum, gerr, eik_sums, drel, gt, mask):
+        from ._lib import CnrLossConfig  # noqa: F401
+        lam_f, lam_e, lam_m, lam_r = lambdas
+        R = color.shape[0]
+        M = drel.shape[1] if drel is not None else 1
+        dev = color.device
+        color_c, gt_c = color.contiguous(), gt.contiguous()
+        wsum_c = wsum.reshape(-1).contiguous()
+        drel_c = drel.contiguous() if drel is not None else None
+        mask_c = mask.contiguous() if mask is not None else None
+        sums = torch.empty(4, dtype=torch.float32, device=dev)
+        nb = lib.lib.cnr_loss_scratch_bytes(R)
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        lib.check(lib.lib.cnr_loss_sums(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), _p(gt_c), _p(mask_c), R, M, _p(sums),
+                                        _p(scratch), nb, _stream(color_c)), "cnr_loss_sums")
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if (dist.is_initialized() and n_rays_global is not None) else 1
+        Rg = float(n_rays_global if n_rays_global is not None else R)
+        eik_factor = None
+        if world > 1:
+            stats = torch.cat([sums[:3], eik_sums.detach().reshape(-1)[:2].to(torch.float32)])
+            den_loc = stats[4].clone()
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+            eik = stats[3] / (stats[4] + 1e-5)
+            eik_factor = (den_loc + 1e-5) / (stats[4] + 1e-5)
+            tot = stats
+        else:
+            eik = gerr.detach()
+            tot = sums
+        rgb_loss = tot[0] / (Rg * 3.0)
+        loss = lam_f * rgb_loss + lam_e * eik
+        parts = [rgb_loss, eik]
+        mask_loss = relight_loss = None
+        if lam_m != 0 and mask is not None:
+            mask_loss = tot[1] / Rg
+            loss = loss + lam_m * mask_loss
+        mean_rel = None
+        if lam_r != 0 and drel is not None:
+            mean_rel = tot[2] / (Rg * M * 3.0)
+            relight_loss = mean_rel * mean_rel
+            loss = loss + lam_r * relight_loss
+        ctx.lib, ctx.lcfg, ctx.lambdas, ctx.Rg, ctx.M = lib, lcfg, lambdas, Rg, M
+        ctx.has = (mask is not None and lam_m != 0, drel is not None and lam_r != 0, eik_factor is not None)
+        ctx.shapes = (color.shape, wsum.shape, tuple(drel.shape) if drel is not None else None)
+        ctx.save_for_backward(color_c, wsum_c, gt_c, mask_c if mask_c is not None else torch.empty(0, device=dev),
+                              mean_rel if mean_rel is not None else torch.zeros((), device=dev),
+                              eik_factor if eik_factor is not None else torch.ones((), device=dev))
+        ctx.mark_non_differentiable(*[t for t in (rgb_loss, eik) if t is not None])
+        zero = torch.zeros((), device=dev)
+        return loss, rgb_loss, eik, (mask_loss if mask_loss is not None else zero), (relight_loss if relight_loss is not None else zero)
+
+    @staticmethod
+    def backward(ctx, g_loss, *_unused):
+        color_c, wsum_c, gt_c, mask_c, mean_rel, eik_factor = ctx.saved_tensors
+        lam_f, lam_e, lam_m, lam_r = ctx.lambdas
+        has_mask, has_rel, _ = ctx.has
+        lib, lcfg, Rg, M = ctx.lib, ctx.lcfg, ctx.Rg, ctx.M
+        dev = color_c.device
+        R = color_c.shape[0]
+        mask_t = mask_c if mask_c.numel() else None
+        # coefficients on the device from the (device-resident) upstream gradient: no host -> device copy, hence no host stall
+        g = g_loss.to(torch.float32)
+        c_rgb = lam_f * (1.0 if lcfg.rgb_l1 else 2.0) / (Rg * 3.0)
+        c_bce = (lam_m / Rg) if has_mask else 0.0
+        c_rel = (lam_r * 2.0 / (Rg * M * 3.0)) if has_rel else 0.0
+        coef = torch.stack([g * c_rgb, g * c_bce, g * c_rel * mean_rel, g * 0.0])
+        d_color = torch.empty_like(color_c)
+        d_wsum = torch.empty(R, dtype=torch.float32, device=dev)
+        d_drel = torch.empty(ctx.shapes[2], dtype=torch.float32, device=dev) if (has_rel and ctx.shapes[2] is not None) else None
+        lib.check(lib.lib.cnr_loss_grads(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(gt_c), _p(mask_t if has_mask or lcfg.include_mask else None),
+                                         R, M, _p(coef), _p(d_color), _p(d_wsum), _p(d_drel), _stream(color_c)), "cnr_loss_grads")
+        d_gerr = g_loss * lam_e * eik_factor
+        return (None, None, None, None, None, d_color.reshape(ctx.shapes[0]), d_wsum.reshape(ctx.shapes[1]), d_gerr, None, d_drel, None, None)
+
+
+def compute_loss_fused(render_dict, rgb_gt, mask=None, lambda_fine=1.0, lambda_eikonal=0.1, lambda_mask=0.1, lambda_relight=1.0,
+                       rgb_loss_type="mse", include_mask=True, n_rays_global=None, group=None, library=None):
+    """Same objective and return convention as compute_loss, evaluated by the render library's loss kernels.  With
+    ``n_rays_global`` (ray-sharded data parallel) the returned loss is the GLOBAL value on every rank and its backward yields the
+    rank-local gradients whose sum over ranks is the single-GPU gradient."""
+    from ._lib import CnrLossConfig, load_library
+    lib = library if library is not None else load_library()
+    lcfg = CnrLossConfig(lambda_fine, lambda_eikonal, lambda_mask, lambda_relight, 0 if rgb_loss_type == "mse" else 1, 1 if include_mask else 0)
+    drel = render_dict.get("delta_relight") if lambda_relight != 0 else None
+    eik_sums = render_dict.get("eik_sums")
+    if n_rays_global is not None and eik_sums is None:
+        raise ValueError("ray-sharded fused loss needs the renderer's eik_sums output")
+    loss, rgb_l, eik_l, mask_l, rel_l = _FusedLoss.apply(lib, lcfg, (lambda_fine, lambda_eikonal, lambda_mask, lambda_relight), n_rays_global,
+                                                       group, render_dict["color_fine"], render_dict["weight_sum"],
+                                                       render_dict["gradient_error"], eik_sums, drel, rgb_gt, mask)
+    loss_dict = {"rgb_fine_loss": rgb_l, "eikonal_loss": eik_l, "loss": loss}
+    if lambda_mask != 0 and mask is not None:
+        loss_dict["mask_loss"] = mask_l
+    if drel is not None:
+        loss_dict["relight_loss"] = rel_l
+    return loss, loss_dict

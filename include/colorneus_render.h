@@ -102,6 +102,27 @@ typedef struct cnr_kernel_timing {
 void cnr_timing_enable(int on);
 int cnr_timing_collect(cnr_kernel_timing* out, int max_records);
 
+/* ---- loss of the training step (replaces NeuS_Trainer.compute_loss, NeuS_Trainer.py:129-171, the consumer right after the path) ----
+ * loss = lambda_fine * mean((color_fine - rgb_gt)^2 or |.|) + lambda_eikonal * gradient_error
+ *      + lambda_mask * BCE(clip(weight_sum, 1e-3, 1 - 1e-3), mask) + lambda_relight * mean(delta_relight * mask)^2
+ * Two phases so that a ray-sharded run can all-reduce the three sums in between:
+ *   cnr_loss_sums : sums[0] = sum of squared (or absolute) colour errors, sums[1] = sum of the BCE terms, sums[2] = sum of
+ *                   delta_relight (* mask); fixed-order reductions.
+ *   cnr_loss_grads: d_color_fine = coef[0] * (c - gt) (or sign), d_weight_sum = coef[1] * dBCE/dws, d_delta_relight = coef[2] (* mask);
+ *                   the caller folds lambda, 1/N and the upstream gradient into the three device-side coefficients. */
+typedef struct cnr_loss_config {
+  float lambda_fine, lambda_eikonal, lambda_mask, lambda_relight;
+  int32_t rgb_l1;        /* 0: MSE (RGB_LOSS_TYPE "mse"), 1: L1 */
+  int32_t include_mask;  /* relight term uses delta_relight * mask */
+} cnr_loss_config;
+size_t cnr_loss_scratch_bytes(int64_t n_rays);
+int cnr_loss_sums(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight /* or NULL */,
+                  const float* rgb_gt, const float* mask /* [R] or NULL */, int64_t n_rays, int32_t n_samples, float* sums /* device [4] */,
+                  void* scratch, size_t scratch_bytes, void* stream);
+int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* rgb_gt, const float* mask,
+                   int64_t n_rays, int32_t n_samples, const float* coef /* device [4] */, float* d_color_fine, float* d_weight_sum,
+                   float* d_delta_relight /* or NULL */, void* stream);
+
 int cnr_abi_version(void);
 const char* cnr_backend_name(void);
 const char* cnr_last_error(void);

@@ -1,0 +1,73 @@
+"""The fused training loss (cnr_loss_sums / cnr_loss_grads) against compute_loss -- the build's restatement of
+NeuS_Trainer.compute_loss that the golden loss vectors pin (test_oracle_golden.py) -- values and gradients w.r.t. every renderer output."""
+import os
+
+import pytest
+import torch
+
+import _native as N
+
+VARIANTS = [dict(), dict(rgb_loss_type="l1"), dict(include_mask=False), dict(lambda_mask=0.0), dict(lambda_relight=0.0)]
+
+
+def _case(device, R=53, M=12, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    out = {"color_fine": torch.rand(R, 3, generator=g), "weight_sum": torch.rand(R, 1, generator=g) * 1.2 - 0.1,   # some outside the clip range
+           "gradient_error": torch.tensor(0.3), "delta_relight": torch.randn(R, M, 3, generator=g) * 0.1}
+    out = {k: v.to(device).requires_grad_(True) for k, v in out.items()}
+    gt = torch.rand(R, 3, generator=g).to(device)
+    mask = (torch.rand(R, generator=g) > 0.4).float().to(device)
+    return out, gt, mask
+
+
+def _compare(lib, device):
+    import color_neus_amd as cn
+    for kw in VARIANTS:
+        for use_mask in (True, False):
+            out, gt, mask = _case(device)
+            m = mask if use_mask else None
+            l1, d1 = cn.compute_loss(out, gt, m, **kw)
+            g1 = torch.autograd.grad(l1, list(out.values()), allow_unused=True)
+            l2, d2 = cn.compute_loss_fused(out, gt, m, library=lib, **kw)
+            g2 = torch.autograd.grad(l2 * 1.0, list(out.values()), allow_unused=True)
+            assert abs(float(l1) - float(l2)) < 1e-6 * max(1.0, abs(float(l1))), (kw, use_mask)
+            for k in d1:
+                assert abs(float(d1[k]) - float(d2[k])) < 1e-6 * max(1.0, abs(float(d1[k]))), (kw, use_mask, k)
+            for name, a, b in zip(out.keys(), g1, g2):
+                za = torch.zeros_like(out[name]) if a is None else a
+                zb = torch.zeros_like(out[name]) if b is None else b
+                assert float((za - zb).abs().max()) <= 1e-6 * max(float(za.abs().max()), 1e-6), (kw, use_mask, name)
+
+
+@pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
+def test_fused_loss_matches_compute_loss_cpu_emulation():
+    import color_neus_amd as cn
+    _compare(cn.load_library(N.EMU_LIB), "cpu")
+
+
+@pytest.mark.gpu
+def test_fused_loss_matches_compute_loss_hip():
+    import color_neus_amd as cn
+    _compare(cn.load_library(), "cuda:0")
+
+
+@pytest.mark.gpu
+def test_fused_loss_end_to_end_gradients_match():
+    """A whole training step with the fused loss gives the parameter gradients of the step with the torch loss."""
+    import color_neus_amd as cn
+    import _golden as G
+    res = {}
+    for fused in (False, True):
+        fx = G.load("dtu_sharp")
+        ocfg, P = G.weights_of("dtu_sharp", fx)
+        r = N.make_renderer(ocfg, P, None, "cuda:0")
+        t = lambda k: torch.from_numpy(fx[k]).to("cuda:0")
+        out = r(t("rays_o"), t("rays_d"), t("det:near"), t("det:far"), z_vals=t("det:z_vals"))
+        fn = cn.compute_loss_fused if fused else cn.compute_loss
+        loss, _ = fn(out, t("rgb_gt"), t("mask"))
+        loss.backward()
+        res[fused] = (float(loss), {k: p.grad.clone() for k, p in r.named_parameters()})
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * abs(res[0][0])
+    gmax = max(float(g.abs().max()) for g in res[0][1].values())
+    for k, g in res[0][1].items():
+        assert float((g - res[1][1][k]).abs().max()) <= 1e-5 * max(float(g.abs().max()), 0.1 * gmax), k

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, fused=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -42,7 +42,11 @@ def _worker(rank, world, port, q):
         out = r(t("rays_o"), t("rays_d"), t("jit:near"), t("jit:far"))
     finally:
         torch.rand = orig
-    loss, value = parallel.sharded_loss(out, t("rgb_gt"), t("mask"), n_rays_global=R, n_samples=ocfg.n_samples + ocfg.n_importance)
+    if fused:   # loss kernels of the render library with the all-reduce between their two phases
+        loss, _ = cn.compute_loss_fused(out, t("rgb_gt"), t("mask"), n_rays_global=R, library=cn.load_library(N.EMU_LIB))
+        value = loss.detach()
+    else:
+        loss, value = parallel.sharded_loss(out, t("rgb_gt"), t("mask"), n_rays_global=R, n_samples=ocfg.n_samples + ocfg.n_importance)
     loss.backward()
     params = list(r.parameters())
     parallel.allreduce_gradients(params)
@@ -52,12 +56,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_matches_single_process():
+@pytest.mark.parametrize("fused", [False, True])
+def test_two_rank_sharding_matches_single_process(fused):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fused)) for r in range(world)]
     for p in procs:
         p.start()
     value, grads, z0 = q.get(timeout=240)
