@@ -223,3 +223,58 @@ def test_idr_vertex_colour_mid_network():
     rgb = r.extract_color(fx["mid:pts"], DEV)
     assert G.relerr(rgb, want.detach()) < TOL
     assert G.relerr(r.sdf(pts.to(DEV)).cpu()[:, 0], fx["mid:sdf_out"][:, 0]) < TOL
+
+
+def test_full_size_properties_4096_rays():
+    """BASELINE-size batch (4096 rays x 128 samples, DTU network, trained-like weights): size-independent properties.
+    (1) compositing invariants of the outputs, (2) ray additivity: with a ray-separable objective the parameter gradients of
+    the whole batch equal the sum of the gradients of its two halves (what ray-sharding relies on), (3) run-to-run determinism."""
+    import color_neus_amd as cn
+    from color_neus_amd import synthetic
+    cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)
+    torch.manual_seed(0)
+    r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(DEV)
+    views = synthetic.synthetic_view(seed=1, device=DEV)
+    sel = torch.randperm(views[0].shape[0], generator=torch.Generator().manual_seed(11))[:4096].to(DEV)
+    o, d, near, far, gt, mask = [x[sel] for x in views]
+    t_rand = torch.rand(4096, 1, generator=torch.Generator().manual_seed(5))
+
+    def run(idx):
+        orig = torch.rand
+        try:
+            torch.rand = lambda *a, **k: t_rand[idx.cpu()].clone()
+            out = r(o[idx], d[idx], near[idx], far[idx])
+        finally:
+            torch.rand = orig
+        # ray-separable objective: plain sums over rays (no means over the batch, no ratio of batch sums)
+        obj = ((out["color_fine"] - gt[idx]) ** 2).sum() + 0.1 * out["weight_sum"].sum() + 0.01 * (out["gradients"] ** 2).sum() \
+            + 0.05 * out["delta_relight"].sum()
+        for p in r.parameters():
+            p.grad = None
+        obj.backward()
+        return out, {k: p.grad.clone() for k, p in r.named_parameters()}
+
+    allr = torch.arange(4096, device=DEV)
+    out, g_all = run(allr)
+    # (1) invariants
+    w = out["weights"].detach()
+    assert bool((w >= 0).all()) and bool(torch.isfinite(w).all())
+    assert float((w.sum(-1, keepdim=True) - out["weight_sum"].detach()).abs().max()) < 1e-5
+    assert float(out["weight_sum"].max()) <= 1.0 + 1e-5
+    assert bool((out["weight_max"].reshape(-1) <= w.max(-1).values + 1e-7).all())
+    z = out["z_vals"]
+    assert bool((z[:, 1:] >= z[:, :-1]).all()), "samples must be sorted along every ray"
+    ins = out["inside_sphere"]
+    assert bool(((ins == 0) | (ins == 1)).all())
+    assert bool((out["color_fine"] >= -1e-6).all()) and bool((out["color_fine"] <= 1 + 1e-5).all())
+    # (2) additivity over rays
+    _, g_a = run(allr[:2048])
+    _, g_b = run(allr[2048:])
+    gmax = max(float(g.abs().max()) for g in g_all.values())
+    for k, g in g_all.items():
+        err = float((g - (g_a[k] + g_b[k])).abs().max())
+        assert err <= 2e-4 * max(float(g.abs().max()), 0.1 * gmax), (k, err)
+    # (3) determinism
+    _, g_again = run(allr)
+    for k, g in g_all.items():
+        assert torch.equal(g, g_again[k]), k
