@@ -66,11 +66,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the render path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CNR_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than ranks (ranks then share
+    # devices, collectives go through the host); the measured configuration is always one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("CNR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import color_neus_amd as cn
     from color_neus_amd import synthetic, parallel
@@ -147,7 +154,7 @@ def main():
         "config": {"workload": "Color_NeuS_dtu.yml renderer block (SDF 8x256 + colour 4x256 + relight 4x256), synthetic 800x800 "
                                "view, %d rays/step/GPU x (64+64) samples, trained-like weights" % R,
                    "rays_per_step_per_gpu": R, "samples_per_ray": M, "parallelism": "ray-sharded dp%d" % world,
-                   "step": "fwd+" + ("torch-loss" if args.torch_loss else "fused-loss") + "+bwd" + ("" if args.no_optim else "+clip+adam") + ("+rccl-allreduce" if world > 1 else ""),
+                   "step": "fwd+" + ("torch-loss" if args.torch_loss else "fused-loss") + "+bwd" + ("" if args.no_optim else "+clip+adam") + (("+rccl-allreduce" if backend == "nccl" else "+%s-allreduce" % backend) if world > 1 else ""),
                    "final_loss": float(loss.detach())},
     }
 
