@@ -1,15 +1,14 @@
-// FP32-MFMA GEMM kernels for gfx950 (MI355X / CDNA4): the fully-connected layers of the SDF / colour / relight stacks
-// (forward, input-gradient chain, second-order sweep, backward) and their weight gradients.
+// Layer GEMM dispatch for gfx950 (MI355X / CDNA4): the fully-connected layers of the SDF / colour / relight stacks (forward,
+// input-gradient chain, second-order sweep, backward).
 //
-//   layer_gemm_kernel<NT>   C[P x N] = epilogue(A[P x K] * W[N x K]^T): 128-point tile x full N per workgroup (4 waves x
-//                           32 rows, v_mfma_f32_32x32x2_f32, NT*16 accumulator registers per lane), K streamed in 16-wide
-//                           slabs through double-buffered LDS (row stride 20 floats -> conflict-free ds_read_b128).
-//                           Staging = unconditional 16-byte loads issued BEFORE the MFMAs of the current slab, prologue
-//                           math (cnr_views.h) applied AFTER them on the way to LDS.  Epilogue: accumulators are transposed
-//                           through a wave-private LDS tile so that every lane handles 4 consecutive columns of one row
-//                           (16-byte loads/stores of the side inputs/outputs, 128-byte contiguous segments per 8 lanes).
-//   dw_gemm_kernel<...>     dW[N x K] = sum_pts X[pt][n] * Y[pt][k]: 8 waves, up to 256x256 output tile held in registers,
-//                           points streamed 16 at a time, per-chunk partial results (deterministic reduction afterwards).
+//   be_layer_gemm            splits a layer into <= 256-column launches and picks the kernel:
+//     layer_gemm_ws_kernel   (cnr_gemm_ws.h, instantiated in cnr_gemm_ws_a.hip / _b.hip) weight-stationary split-f16 kernel for
+//                            >= 96 output columns and K <= 272: the HBM-bound streaming kernel that carries 2/3 of a training step;
+//     layer_gemm_kernel<NT>  (cnr_gemm_fp32.h) FP32-MFMA 128-point tiles: narrow outputs (sdf / rgb / embedding cotangents, view
+//                            and epilogue kinds pinned at compile time for the combinations of the plan) and the fallback when
+//                            the weight-stationary kernel is switched off (CNR_DISABLE_WS) or not applicable.
+//   row_scale_kernel         slow-path producer of LayerGemm::rs_out for launches that bypass the weight-stationary kernel.
+// The weight-gradient GEMMs live in cnr_gemm_dw.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
