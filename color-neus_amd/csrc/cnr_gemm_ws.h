@@ -91,25 +91,30 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   const int srow = tid >> 4, scol = (tid & 15) * 4;
   const bool pv0 = scol < kpad, pv1 = 64 + scol < kpad, pv2 = 128 + scol < kpad, pv3 = 192 + scol < kpad;
   const bool pv4 = K17 && 256 + scol < kpad;   // 17th block: 4 of the 16 threads of a row
-  Raw4 r0, r1, r2, r3, r4;
+  // DEEP: a second staging register set keeps the activation tiles of two iterations in flight (+7 % on a plain layer,
+  // tools/probes/ws_depth_probe.hip); only the instantiations with >= 20 spare VGPRs take it
+  constexpr bool DEEP = PLAIN && !K17 && FULLK && (VK == VK_DIRECT || VK == VK_SOFTPLUS) && (EK == EK_STORE || EK == EK_RELU || EK == EK_SDF_TOP);
+  Raw4 r0a, r1a, r2a, r3a, r4a, r0b, r1b, r2b, r3b, r4b;
   const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-  r0.a = z4; r0.b = z4; r1 = r0; r2 = r0; r3 = r0; r4 = r0;
-#define WS_FETCH_TILE(tile_)                                                      \
+  r0a.a = z4; r0a.b = z4; r1a = r0a; r2a = r0a; r3a = r0a; r4a = r0a;
+  r0b = r0a; r1b = r0a; r2b = r0a; r3b = r0a; r4b = r0a;
+#define WS_FETCH_SET(tile_, S_)                                                   \
   {                                                                               \
     long row_ = (tile_) * WS_TP + srow; if (row_ >= Pn) row_ = Pn - 1;            \
-    if (pv0) r0 = view_fetch4(g.A, row_, scol);                                   \
-    if (pv1) r1 = view_fetch4(g.A, row_, 64 + scol);                              \
-    if (pv2) r2 = view_fetch4(g.A, row_, 128 + scol);                             \
-    if (pv3) r3 = view_fetch4(g.A, row_, 192 + scol);                             \
-    if (K17 && pv4) r4 = view_fetch4(g.A, row_, 256 + scol);                      \
+    if (pv0) r0##S_ = view_fetch4(g.A, row_, scol);                               \
+    if (pv1) r1##S_ = view_fetch4(g.A, row_, 64 + scol);                          \
+    if (pv2) r2##S_ = view_fetch4(g.A, row_, 128 + scol);                         \
+    if (pv3) r3##S_ = view_fetch4(g.A, row_, 192 + scol);                         \
+    if (K17 && pv4) r4##S_ = view_fetch4(g.A, row_, 256 + scol);                  \
   }
-#define WS_PUT_TILE(buf_, tile_)                                                  \
+#define WS_FETCH_TILE(tile_) WS_FETCH_SET(tile_, a)
+#define WS_PUT_SET(buf_, tile_, S_)                                               \
   {                                                                               \
-    const f4 v0 = pv0 ? view_finish4(g.A, r0, scol) : z4;                         \
-    const f4 v1 = pv1 ? view_finish4(g.A, r1, 64 + scol) : z4;                    \
-    const f4 v2 = pv2 ? view_finish4(g.A, r2, 128 + scol) : z4;                   \
-    const f4 v3 = pv3 ? view_finish4(g.A, r3, 192 + scol) : z4;                   \
-    const f4 v4 = (K17 && pv4) ? view_finish4(g.A, r4, 256 + scol) : z4;          \
+    const f4 v0 = pv0 ? view_finish4(g.A, r0##S_, scol) : z4;                     \
+    const f4 v1 = pv1 ? view_finish4(g.A, r1##S_, 64 + scol) : z4;                \
+    const f4 v2 = pv2 ? view_finish4(g.A, r2##S_, 128 + scol) : z4;               \
+    const f4 v3 = pv3 ? view_finish4(g.A, r3##S_, 192 + scol) : z4;               \
+    const f4 v4 = (K17 && pv4) ? view_finish4(g.A, r4##S_, 256 + scol) : z4;      \
     float mx = fmaxf(fmaxf(fmaxf(ws_absmax4(v0), ws_absmax4(v1)), fmaxf(ws_absmax4(v2), ws_absmax4(v3))), ws_absmax4(v4)); \
     _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16)); \
     float sc = 1.0f;                                                              \
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       if (g.rs_out && prow_ < Pn) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); /* 0: all-zero row, NaN: non-finite row (must keep poisoning the weight gradient) */ \
     }                                                                             \
   }
+#define WS_PUT_TILE(buf_, tile_) WS_PUT_SET(buf_, tile_, a)
 #define WS_MFMA(kb_)                                                                               \
   if ((kb_) < nkb) {                                                                               \
     const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + (kb_) * 32);                             \
@@ -140,20 +146,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   // its MFMAs of tile t, the early group fetches tile t+1 before and stores it after -- so one wave of each SIMD is in the
   // matrix pipe while the other does prologue math / LDS stores / epilogue.  One barrier per tile.
   const bool late = wave >= 4;
-  WS_FETCH_TILE(t0)
-  WS_PUT_TILE(0, t0)
-  if (late && t0 + 1 < t1) WS_FETCH_TILE(t0 + 1)
-  __syncthreads();
-
-  for (long t = t0; t < t1; ++t) {
-    const int buf = (int)((t - t0) & 1);
-    const bool more = t + 1 < t1;
-    if (!late) {
-      if (more) WS_FETCH_TILE(t + 1)
-    } else if (more) {
-      WS_PUT_TILE(buf ^ 1, t + 1)
-      if (t + 2 < t1) WS_FETCH_TILE(t + 2)
-    }
+  // MFMAs + epilogue of tile t from LDS buffer buf
+  auto compute = [&](const long t, const int buf) {
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -199,11 +193,64 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    if (!late && more) WS_PUT_TILE(buf ^ 1, t + 1)
+  };
+  if (!DEEP) {
+    WS_FETCH_TILE(t0)
+    WS_PUT_TILE(0, t0)
+    if (late && t0 + 1 < t1) WS_FETCH_TILE(t0 + 1)
     __syncthreads();
+    for (long t = t0; t < t1; ++t) {
+      const int buf = (int)((t - t0) & 1);
+      const bool more = t + 1 < t1;
+      if (!late) {
+        if (more) WS_FETCH_TILE(t + 1)
+      } else if (more) {
+        WS_PUT_TILE(buf ^ 1, t + 1)
+        if (t + 2 < t1) WS_FETCH_TILE(t + 2)
+      }
+      compute(t, buf);
+      if (!late && more) WS_PUT_TILE(buf ^ 1, t + 1)
+      __syncthreads();
+    }
+  } else {
+    // two staging sets: tile t0 + j lives in set a for even j, set b for odd j.  Early waves keep tiles t+1 and t+2 in flight,
+    // late waves t+2 and t+3.
+    WS_FETCH_SET(t0, a)
+    WS_PUT_SET(0, t0, a)
+    if (t0 + 1 < t1) WS_FETCH_SET(t0 + 1, b)
+    if (late && t0 + 2 < t1) WS_FETCH_SET(t0 + 2, a)
+    __syncthreads();
+    for (long t = t0; t < t1; t += 2) {
+      {   // even tile t (LDS buffer 0): the next tile waits in set b, set a is free
+        const bool more = t + 1 < t1;
+        if (!late) {
+          if (t + 2 < t1) WS_FETCH_SET(t + 2, a)
+        } else if (more) {
+          WS_PUT_SET(1, t + 1, b)
+          if (t + 3 < t1) WS_FETCH_SET(t + 3, b)
+        }
+        compute(t, 0);
+        if (!late && more) WS_PUT_SET(1, t + 1, b)
+        __syncthreads();
+      }
+      if (t + 1 < t1) {   // odd tile t + 1 (LDS buffer 1): the next tile waits in set a, set b is free
+        const bool more = t + 2 < t1;
+        if (!late) {
+          if (t + 3 < t1) WS_FETCH_SET(t + 3, b)
+        } else if (more) {
+          WS_PUT_SET(0, t + 2, a)
+          if (t + 4 < t1) WS_FETCH_SET(t + 4, a)
+        }
+        compute(t + 1, 1);
+        if (!late && more) WS_PUT_SET(0, t + 2, a)
+        __syncthreads();
+      }
+    }
   }
 #undef WS_FETCH_TILE
 #undef WS_PUT_TILE
+#undef WS_FETCH_SET
+#undef WS_PUT_SET
 #undef WS_MFMA
 }
 
