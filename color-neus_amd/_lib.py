@@ -50,7 +50,7 @@ class CnrLossConfig(C.Structure):
 
 
 class CnrInGrads(C.Structure):
-    _fields_ = [("d_params", C.POINTER(_FP)), ("d_rays_o", _FP), ("d_rays_d", _FP)]
+    _fields_ = [("d_params", C.POINTER(_FP)), ("d_rays_o", _FP), ("d_rays_d", _FP), ("d_near", _FP), ("d_far", _FP)]
 
 
 _MODE = {"idr": 0, "no_view_dir": 1, "no_normal": 2}
@@ -74,7 +74,8 @@ def c_config(cfg) -> CnrConfig:
 EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_count", "cnr_param_info", "cnr_ctx_bytes",
            "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
-           "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_grads"]
+           "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_grads",
+           "cnr_sample_pdf", "cnr_up_sample"]
 
 
 class RenderLibrary:
@@ -108,10 +109,12 @@ class RenderLibrary:
         L.cnr_loss_scratch_bytes.argtypes = [C.c_int64]
         L.cnr_loss_sums.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_size_t, _FP]
         L.cnr_loss_grads.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, _FP]
+        L.cnr_sample_pdf.argtypes = [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, _FP]
+        L.cnr_up_sample.argtypes = [_FP, _FP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_float, _FP, _FP]
         L.cnr_timing_enable.argtypes = [C.c_int]
         L.cnr_timing_enable.restype = None
         L.cnr_timing_collect.argtypes = [C.POINTER(CnrKernelTiming), C.c_int]
-        if L.cnr_abi_version() != 1:
+        if L.cnr_abi_version() != 2:
             raise RuntimeError("colorneus library ABI mismatch")
 
     @property

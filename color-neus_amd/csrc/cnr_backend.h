@@ -56,6 +56,8 @@ struct UpSample {   // NeuS.py:136-181 + ray_utils.py:123-154 (det=True)
   int m;                                             // new samples per ray
   float inv_s;
   float* new_z;                                      // [R][m]
+  const float* w_in = nullptr;                       // optional [R][n-1]: section weights given by the caller (plain sample_pdf(det=True),
+                                                     // ray_utils.py:123-154, bins = z); o / d / sdf / inv_s are then unused
 };
 
 struct MergeZ {     // NeuS.py:183-197
@@ -121,7 +123,7 @@ struct CompositeBwd {
   float* gc_a;                 // [P][kTop] cotangent of the global colour (post-sigmoid): direct + inverse-sigmoid path
   float* dinvs_partial;        // [R]
   float* d_rays_d;             // [R][3] (null when rays need no grad): sum_j d tc_j * g_j
-  float* d_z;                  // [R][M] cotangent of z through dists/depth (null unless needed)
+  float* d_z;                  // [P][2] or null: {d loss / d z_j through depth, d loss / d dist_j through alpha} (near / far gradients, N_IMPORTANCE == 0)
 };
 
 struct ColTopBwd {  // cotangent of the colour net's last pre-activation
@@ -140,7 +142,10 @@ struct RaysGradFinish {  // d rays_o / d rays_d from the point cotangents (only 
   const float* pbar;      // [P][4] total cotangent of p
   const float* daux_dir_c; const float* daux_dir_r; int lddir; int multires_view;   // cotangent of PE(dir) parts (may be null)
   const float* d_rays_d_alpha;   // [R][3] from CompositeBwd
-  float* d_o; float* d_d;
+  float* d_o; float* d_d;        // may both be null (only near / far need gradients)
+  // N_IMPORTANCE == 0: z_j = near + (far - near) * linspace(0,1,S)[j] (+ jitter) is differentiable w.r.t. near / far (NeuS.py:311-313)
+  const float* dz_parts;         // [P][2] from CompositeBwd::d_z, or null
+  float* d_near; float* d_far;   // [R] or null
 };
 
 struct PbarFinish {   // total cotangent of p: colour/relight aux inputs + SDF value path + gradient path (PE second derivative)

@@ -165,10 +165,9 @@ static void launch_dw(const DwGemm& g, int n0, int k0, cnr_stream s) {
   constexpr int TN = WR * MT * 32, TK = WC * KT * 32;
   constexpr int DW_BP = dw_bp(TN, TK);
   const size_t lds = (size_t)(2 * DW_BP * (TN + TK)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;   // the opt-in is per device
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_kernel<WR, WC, MT, KT, KINDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const int tn_ = (g.N - n0) < TN ? (g.N - n0) : TN, tk_ = (g.K - k0) < TK ? (g.K - k0) : TK;
   TimingScope ts_("dw_gemm", 1, WR * 1000 + WC * 100 + MT * 10 + KT, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
@@ -365,10 +364,9 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_bx_kernel(const DwGemm g_in, i
 template <int XK0, int YK0, int XK1, int YK1>
 static void launch_dw_bx_t(const DwGemm& g, int n0, int k0, cnr_stream s) {
   const size_t lds = (size_t)2 * DX_BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;   // the opt-in is per device
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_bx_kernel<XK0, YK0, XK1, YK1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const int tn_ = (g.N - n0) < 256 ? (g.N - n0) : 256, tk_ = (g.K - k0) < 256 ? (g.K - k0) : 256;
   TimingScope ts_("dw_gemm_bx", 1, 4224, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
@@ -566,10 +564,9 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, i
 template <int XK0, int YK0, int XK1, int YK1>
 static void launch_dw_hx_t(const DwGemm& g, int n0, int k0, cnr_stream s) {
   const size_t lds = (size_t)2 * DH_BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;   // the opt-in is per device
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_gemm_hx_kernel<XK0, YK0, XK1, YK1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const int tn_ = (g.N - n0) < 256 ? (g.N - n0) : 256, tk_ = (g.K - k0) < 256 ? (g.K - k0) : 256;
   TimingScope ts_("dw_gemm_hx", 1, 4224, g.P, tn_, tk_, g.npairs, s, dw_gemm_bytes(g, tn_, tk_));
@@ -734,10 +731,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void dw_skinny_kernel(const DwGemm g
 template <bool NARROW_X, bool NG2, int KINDS>
 static void launch_dw_skinny_td(const DwGemm& g, int n0, int k0, int ncnt, cnr_stream s) {
   const size_t lds = ((size_t)SK_WAVES * 8 * 256 + SK_WAVES * 8) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;   // the opt-in is per device
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_skinny_kernel<NARROW_X, NG2, KINDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   const int wide = NARROW_X ? ((g.K - k0) < 256 ? (g.K - k0) : 256) : ((g.N - n0) < 256 ? (g.N - n0) : 256);
   const int tn_ = NARROW_X ? ncnt : wide, tk_ = NARROW_X ? wide : ncnt;

@@ -148,10 +148,9 @@ void launch_layer_gemm(const LayerGemm& g, cnr_stream s) {
   const size_t lds = (size_t)(2 * LG_BM * LG_LD + 2 * NT * 32 * LG_LD) * sizeof(float);
   const unsigned grid = (unsigned)((g.P + LG_BM - 1) / LG_BM);
   if (grid == 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;   // the opt-in is per device
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_kernel<NT, VK, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   TimingScope ts_("layer_gemm", 0, NT, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
   hipLaunchKernelGGL((layer_gemm_kernel<NT, VK, EK>), dim3(grid), dim3(256), lds, s, g);

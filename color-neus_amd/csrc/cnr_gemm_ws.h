@@ -266,10 +266,9 @@ static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
   long tpw = (ntiles + ws_wgs - 1) / ws_wgs;   // one workgroup per CU: the weights are loaded once per CU (measured best of 256 / 512 / 768 / 1024)
   if (tpw < ws_mintpw) tpw = ws_mintpw;
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;   // the opt-in is per device
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN, K17, FULLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
   hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN, K17, FULLK>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);

@@ -7,6 +7,18 @@ extern const char* g_first_error_where;
 // optional per-launch timing with HIP events on the launch stream (bench / profiling only; off by default)
 void timing_begin(const char* name, int kind, int nt, long P, int N, int K, int pairs, hipStream_t s, double bytes);
 void timing_end(hipStream_t s);
+// hipFuncSetAttribute is a per-device setting: remember per (kernel instantiation, device) that it has been applied.
+// Usage: static DeviceOnce once; if (once.first()) hipFuncSetAttribute(...);
+struct DeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;   // unknown device: just apply the attribute again
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+  }
+};
 struct TimingScope {
   hipStream_t s;
   TimingScope(const char* name, int kind, int nt, long P, int N, int K, int pairs, hipStream_t st, double bytes = 0.0) : s(st) {

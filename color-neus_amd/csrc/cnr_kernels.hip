@@ -598,26 +598,33 @@ __global__ __launch_bounds__(256) void upsample_kernel(const UpSample p) {
   if (!active) ray = p.R - 1;
   float* zs = sh[wave][0]; float* ss = sh[wave][1]; float* cs = sh[wave][2]; float* rs = sh[wave][3]; float* as = sh[wave][4];
   const int n = p.n, nsec = p.n - 1;
-  float o[3], d[3];
-  for (int c = 0; c < 3; ++c) { o[c] = p.o[ray * 3 + c]; d[c] = p.d[ray * 3 + c]; }
-  for (int i = lane; i < n; i += 64) {
-    float z = p.z[ray * p.ldz + i];
-    zs[i] = z;
-    ss[i] = p.sdf[ray * p.lds + i];
-    float x = o[0] + d[0] * z, y = o[1] + d[1] * z, w = o[2] + d[2] * z;
-    rs[i] = sqrtf(x * x + y * y + w * w);
+  const bool given_w = p.w_in != nullptr;   // wave-uniform
+  if (given_w) {
+    for (int i = lane; i < n; i += 64) zs[i] = p.z[ray * p.ldz + i];
+    for (int i = lane; i < nsec; i += 64) as[i] = p.w_in[ray * nsec + i];
+  } else {
+    float o[3], d[3];
+    for (int c = 0; c < 3; ++c) { o[c] = p.o[ray * 3 + c]; d[c] = p.d[ray * 3 + c]; }
+    for (int i = lane; i < n; i += 64) {
+      float z = p.z[ray * p.ldz + i];
+      zs[i] = z;
+      ss[i] = p.sdf[ray * p.lds + i];
+      float x = o[0] + d[0] * z, y = o[1] + d[1] * z, w = o[2] + d[2] * z;
+      rs[i] = sqrtf(x * x + y * y + w * w);
+    }
   }
   __syncthreads();
-  for (int i = lane; i < nsec; i += 64) cs[i] = (ss[i + 1] - ss[i]) / (zs[i + 1] - zs[i] + 1e-5f);
+  if (!given_w) for (int i = lane; i < nsec; i += 64) cs[i] = (ss[i + 1] - ss[i]) / (zs[i + 1] - zs[i] + 1e-5f);
   __syncthreads();
-  for (int i = lane; i < nsec; i += 64) {
-    float prev = i > 0 ? cs[i - 1] : 0.0f;
-    float c = fminf(prev, cs[i]);
-    c = fminf(fmaxf(c, -1e3f), 0.0f);
-    const bool inside = rs[i] < 1.0f || rs[i + 1] < 1.0f;
-    c = inside ? c : c * 0.0f;
-    as[i] = upsample_alpha(ss[i], ss[i + 1], zs[i], zs[i + 1], c, p.inv_s);
-  }
+  if (!given_w)
+    for (int i = lane; i < nsec; i += 64) {
+      float prev = i > 0 ? cs[i - 1] : 0.0f;
+      float c = fminf(prev, cs[i]);
+      c = fminf(fmaxf(c, -1e3f), 0.0f);
+      const bool inside = rs[i] < 1.0f || rs[i + 1] < 1.0f;
+      c = inside ? c : c * 0.0f;
+      as[i] = upsample_alpha(ss[i], ss[i + 1], zs[i], zs[i + 1], c, p.inv_s);
+    }
   __syncthreads();
   // weights = alpha * exclusive cumprod(1 - alpha + 1e-7), + 1e-5 (sample_pdf), and their sum
   float carry = 1.0f, part = 0.0f;
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const UpSample p) {
     const float incl = wave_scan_incl_mul(f, lane);
     float excl = __shfl_up(incl, 1);
     if (lane == 0) excl = 1.0f;
-    const float w = a * (carry * excl) + 1e-5f;
+    const float w = (given_w ? a : a * (carry * excl)) + 1e-5f;
     if (ok) { as[i] = w; part += w; }
     carry = carry * __shfl(incl, 63);
   }
@@ -890,6 +897,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
           drd[k] += ag.d_tc * q[c].g[k];
         }
         if (active) {
+          if (p.d_z) { p.d_z[pt * 2] = ddepth * w[c]; p.d_z[pt * 2 + 1] = ag.d_dist; }
           p.ztop[pt * p.ldztop + p.ztop_col] = ag.d_sdf / p.sdf_scale;
           for (int k = 0; k < 3; ++k) p.gbar[pt * 4 + k] = gb[k];
           p.gbar[pt * 4 + 3] = 0.0f;
@@ -1047,33 +1055,53 @@ __global__ __launch_bounds__(256) void rays_grad_finish_kernel(const RaysGradFin
   const int npe = p.multires_view > 0 ? 3 + 6 * p.multires_view : 3;
   float spe[27];
   for (int q = 0; q < 27; ++q) spe[q] = 0.0f;
+  float dr[3];
+  for (int k = 0; k < 3; ++k) dr[k] = p.d[ray * 3 + k];
+  float snear = 0.0f, sfar = 0.0f;
   for (int j = lane; j < M; j += 64) {
     const long pt = ray * M + j;
     const float z0 = p.z[pt];
     const float dist = j + 1 < M ? p.z[pt + 1] - z0 : p.sample_dist;
     const float mid = z0 + dist * 0.5f;
-    for (int k = 0; k < 3; ++k) { float pb = p.pbar[pt * 4 + k]; so[k] += pb; sd[k] += pb * mid; }
+    float dmid = 0.0f;
+    for (int k = 0; k < 3; ++k) { float pb = p.pbar[pt * 4 + k]; so[k] += pb; sd[k] += pb * mid; dmid += pb * dr[k]; }
     for (int q = 0; q < npe; ++q) {
       float v = 0.0f;
       if (p.daux_dir_c) v += p.daux_dir_c[pt * p.lddir + 6 + q];
       if (p.daux_dir_r) v += p.daux_dir_r[pt * p.lddir + 6 + q];
       spe[q] += v;
     }
+    if (p.dz_parts) {
+      // mid_j = z_j + dist_j / 2, dist_j = z_{j+1} - z_j (the last section has the constant length 2/S): total cotangent of z_j
+      float dz = p.dz_parts[pt * 2] + dmid;
+      if (j + 1 < M) dz -= p.dz_parts[pt * 2 + 1] + 0.5f * dmid;
+      if (j > 0) {
+        float dmid_prev = 0.0f;
+        for (int k = 0; k < 3; ++k) dmid_prev += p.pbar[(pt - 1) * 4 + k] * dr[k];
+        dz += p.dz_parts[(pt - 1) * 2 + 1] + 0.5f * dmid_prev;
+      }
+      const float lin = linspace_at(0.0f, 1.0f, M, j);
+      snear += dz * (1.0f - lin);
+      sfar += dz * lin;
+    }
   }
   for (int k = 0; k < 3; ++k) { so[k] = wave_sum(so[k]); sd[k] = wave_sum(sd[k]); }
   for (int q = 0; q < npe; ++q) spe[q] = wave_sum(spe[q]);
+  snear = wave_sum(snear); sfar = wave_sum(sfar);
   if (lane == 0) {
-    for (int k = 0; k < 3; ++k) {
-      const float dk = p.d[ray * 3 + k];
-      float acc = sd[k] + p.d_rays_d_alpha[ray * 3 + k] + spe[k];
-      float f = 1.0f;
-      for (int m = 0; m < p.multires_view; ++m) {
-        acc += f * (cosf(dk * f) * spe[3 + 6 * m + k] - sinf(dk * f) * spe[6 + 6 * m + k]);
-        f *= 2.0f;
+    if (p.d_o && p.d_d)
+      for (int k = 0; k < 3; ++k) {
+        const float dk = dr[k];
+        float acc = sd[k] + p.d_rays_d_alpha[ray * 3 + k] + spe[k];
+        float f = 1.0f;
+        for (int m = 0; m < p.multires_view; ++m) {
+          acc += f * (cosf(dk * f) * spe[3 + 6 * m + k] - sinf(dk * f) * spe[6 + 6 * m + k]);
+          f *= 2.0f;
+        }
+        p.d_d[ray * 3 + k] = acc;
+        p.d_o[ray * 3 + k] = so[k];
       }
-      p.d_d[ray * 3 + k] = acc;
-      p.d_o[ray * 3 + k] = so[k];
-    }
+    if (p.dz_parts && p.d_near && p.d_far) { p.d_near[ray] = snear; p.d_far[ray] = sfar; }
   }
 }
 void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s) {

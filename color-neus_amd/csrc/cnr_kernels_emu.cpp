@@ -195,14 +195,17 @@ void be_upsample(const UpSample& p, cnr_stream) {
   for (long ray = 0; ray < p.R; ++ray) {
     const int n = p.n, nsec = n - 1;
     const float* z = p.z + ray * p.ldz;
-    const float* s = p.sdf + ray * p.lds;
+    const float* s = p.w_in ? nullptr : p.sdf + ray * p.lds;
     std::vector<float> rad(n), cs(n), w(n), cdf(n);
+    float T = 1.0f, total = 0.0f;
+    if (p.w_in) {
+      for (int i = 0; i < nsec; ++i) { w[i] = p.w_in[ray * nsec + i] + 1e-5f; total += w[i]; }
+    } else {
     for (int i = 0; i < n; ++i) {
       float x = p.o[ray * 3] + p.d[ray * 3] * z[i], y = p.o[ray * 3 + 1] + p.d[ray * 3 + 1] * z[i], q = p.o[ray * 3 + 2] + p.d[ray * 3 + 2] * z[i];
       rad[i] = sqrtf(x * x + y * y + q * q);
     }
     for (int i = 0; i < nsec; ++i) cs[i] = (s[i + 1] - s[i]) / (z[i + 1] - z[i] + 1e-5f);
-    float T = 1.0f, total = 0.0f;
     for (int i = 0; i < nsec; ++i) {
       float prev = i > 0 ? cs[i - 1] : 0.0f;
       float c = std::min(prev, cs[i]);
@@ -212,6 +215,7 @@ void be_upsample(const UpSample& p, cnr_stream) {
       w[i] = a * T + 1e-5f;
       T = T * (1.0f - a + 1e-7f);
       total += w[i];
+    }
     }
     cdf[0] = 0.0f;
     float run = 0.0f;
@@ -349,6 +353,7 @@ void be_composite_bwd(const CompositeBwd& p, cnr_stream) {
         drd[k] += ag.d_tc * q[j].g[k];
       }
       p.gbar[pt * 4 + 3] = 0.0f;
+      if (p.d_z) { p.d_z[pt * 2] = ddepth * w[j]; p.d_z[pt * 2 + 1] = ag.d_dist; }
       p.ztop[pt * p.ldztop + p.ztop_col] = ag.d_sdf / p.sdf_scale;
       for (int k = 0; k < 3; ++k) {
         float cbar = dcol[k] * w[j];
@@ -384,19 +389,36 @@ void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream) {
   for (long ray = 0; ray < p.R; ++ray) {
     float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, spe[27];
     for (int q = 0; q < 27; ++q) spe[q] = 0.0f;
+    const float* dr = p.d + ray * 3;
+    float snear = 0.0f, sfar = 0.0f;
+    std::vector<float> dmid(p.M);
     for (int j = 0; j < p.M; ++j) {
       long pt = ray * p.M + j;
       float z0 = p.z[pt];
       float dist = j + 1 < p.M ? p.z[pt + 1] - z0 : p.sample_dist;
       float mid = z0 + dist * 0.5f;
-      for (int k = 0; k < 3; ++k) { float pb = p.pbar[pt * 4 + k]; so[k] += pb; sd[k] += pb * mid; }
+      dmid[j] = 0.0f;
+      for (int k = 0; k < 3; ++k) { float pb = p.pbar[pt * 4 + k]; so[k] += pb; sd[k] += pb * mid; dmid[j] += pb * dr[k]; }
       for (int q = 0; q < npe; ++q) {
         if (p.daux_dir_c) spe[q] += p.daux_dir_c[pt * p.lddir + 6 + q];
         if (p.daux_dir_r) spe[q] += p.daux_dir_r[pt * p.lddir + 6 + q];
       }
     }
+    if (p.dz_parts && p.d_near && p.d_far) {
+      for (int j = 0; j < p.M; ++j) {
+        long pt = ray * p.M + j;
+        float dz = p.dz_parts[pt * 2] + dmid[j];
+        if (j + 1 < p.M) dz -= p.dz_parts[pt * 2 + 1] + 0.5f * dmid[j];
+        if (j > 0) dz += p.dz_parts[(pt - 1) * 2 + 1] + 0.5f * dmid[j - 1];
+        float lin = linspace_at(0.0f, 1.0f, p.M, j);
+        snear += dz * (1.0f - lin);
+        sfar += dz * lin;
+      }
+      p.d_near[ray] = snear; p.d_far[ray] = sfar;
+    }
+    if (!(p.d_o && p.d_d)) continue;
     for (int k = 0; k < 3; ++k) {
-      float dk = p.d[ray * 3 + k];
+      float dk = dr[k];
       float acc = sd[k] + p.d_rays_d_alpha[ray * 3 + k] + spe[k];
       float f = 1.0f;
       for (int m = 0; m < p.multires_view; ++m) {

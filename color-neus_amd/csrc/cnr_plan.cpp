@@ -303,7 +303,7 @@ static void layout_ctx(Model& m, long R, Arena& a, Ctx& x) {
 }
 
 struct Bwd {   // backward scratch
-  float *ZTOP, *gbar_a, *dtop, *gc_a, *gc_b, *dctop, *dinvs, *drd_alpha, *dAUXc, *dAUXr, *gbar_t, *cbar, *ebar0, *ebars, *pbar;
+  float *ZTOP, *gbar_a, *dtop, *gc_a, *gc_b, *dctop, *dinvs, *drd_alpha, *dAUXc, *dAUXr, *gbar_t, *cbar, *ebar0, *ebars, *pbar, *dzparts;
   std::vector<float*> D, DC, VB, Z2;
   std::vector<float*> rsX0, rsY1;   // row scales of the SDF cotangents z-bar_l (value pair) and q-bar_l (gradient-chain pair)
   float* rsD;                       // row scales of the colour / relight cotangent consumed right after its layer GEMM
@@ -331,6 +331,7 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   b.ebar0 = a.f((size_t)P * kEmb);
   b.ebars = a.f((size_t)P * kEmb);
   b.pbar = a.f((size_t)P * 4);
+  b.dzparts = m.I == 0 ? a.f((size_t)P * 2) : nullptr;
   b.D.resize(m.NR);
   for (int i = 0; i < m.NR; ++i) b.D[i] = a.f((size_t)P * m.Hr);
   b.DC.resize(m.NC - 1);
@@ -469,6 +470,12 @@ static int skip_off(const Model& m) {
 static void sdf_grad_chain(const Model& m, long P, const float* E, const float* const* Z, float* const* V, float* CE0, float* CES,
                            cnr_stream s, float* const* rs = nullptr /* [L] row scales of sigma'(z_l) v_l, see Ctx::rsX1 */) {
   const float inv_scale = 1.0f / m.c.sdf_scale;
+  // V[l-1] of a skip layer is written over n < round_up(n,16) columns only (EK_SPLIT) but read back over the padded width by the
+  // next GEMM of this chain: its pad columns must hold finite values whatever the caller's scratch contained (every user of the
+  // chain -- render, vertex colour -- gets this here rather than at the call site)
+  for (int l = 1; l < m.L; ++l)
+    if (m.skip(l) && V[l - 1] && round_up(m.sdf[l - 1].n, 16) > m.sdf[l - 1].n)
+      be_zero_cols(V[l - 1], m.Hs, m.sdf[l - 1].n, round_up(m.sdf[l - 1].n, 16), P, s);
   for (int l = m.L - 1; l >= 0; --l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;
@@ -587,8 +594,6 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   fs.scale = scale; fs.multires = m.c.sdf_multires; fs.multires_view = m.mv; fs.E = x.E; fs.AUX = x.AUX;
   be_fine_setup(fs, s);
   sdf_chain(m, P, x.E, x.Z.data(), x.sdf, x.featx, x.ldfx, 1.0f / scale, s, x.rsY.data());
-  for (int l = 1; l < m.L; ++l)   // V[l-1] feeds a GEMM over round_up(n,16) columns: its unwritten pad columns must be finite
-    if (m.skip(l) && x.V[l - 1]) be_zero_cols(x.V[l - 1], m.Hs, m.sdf[l - 1].n, round_up(m.sdf[l - 1].n, 16), P, s);
   sdf_grad_chain(m, P, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s, x.rsX1.data());
   GradFinish gf;
   gf.featx = x.featx; gf.ldfx = x.ldfx; gf.F = m.F;
@@ -692,8 +697,16 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   layout_bwd(m, R, x, sa, b);
   if (sa.off > scratch_bytes) return fail("backward scratch too small: need %zu bytes, got %zu", sa.off, scratch_bytes);
   const float scale = m.c.sdf_scale;
-  const bool rays_grad = gi->d_rays_o != nullptr || gi->d_rays_d != nullptr;
-  if (rays_grad && (!gi->d_rays_o || !gi->d_rays_d)) return fail("d_rays_o and d_rays_d must be given together");
+  const bool rays_out = gi->d_rays_o != nullptr || gi->d_rays_d != nullptr;
+  if (rays_out && (!gi->d_rays_o || !gi->d_rays_d)) return fail("d_rays_o and d_rays_d must be given together");
+  if ((gi->d_near != nullptr) != (gi->d_far != nullptr)) return fail("d_near and d_far must be given together");
+  // z depends on near / far only without importance sampling and without an override (NeuS.py:311-313 vs :343)
+  const bool nf_live = gi->d_near != nullptr && m.I == 0 && !in->z_vals_override;
+  if (gi->d_near && !nf_live) {
+    be_memset_zero(gi->d_near, (size_t)R * sizeof(float), s);
+    be_memset_zero(gi->d_far, (size_t)R * sizeof(float), s);
+  }
+  const bool rays_grad = rays_out || nf_live;   // both need the total cotangent of the sample points
   float* const* dP = gi->d_params;
   const bool skipnet = has_skip(m);
 
@@ -710,7 +723,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   cb.d_gradient_error = go->gradient_error; cb.d_depth = go->depth; cb.d_global_color = m.has_relight ? go->global_color : nullptr;
   cb.d_delta_relight = m.has_relight ? go->delta_relight : nullptr;
   cb.ztop = b.ZTOP; cb.ldztop = x.ldztop; cb.ztop_col = m.F; cb.gbar = b.gbar_a; cb.dtop = b.dtop; cb.gc_a = b.gc_a; cb.dinvs_partial = b.dinvs;
-  cb.d_rays_d = rays_grad ? b.drd_alpha : nullptr; cb.d_z = nullptr;
+  cb.d_rays_d = rays_grad ? b.drd_alpha : nullptr; cb.d_z = nf_live ? b.dzparts : nullptr;
   be_composite_bwd(cb, s);
   VarianceFinish vf;
   vf.partial = b.dinvs; vf.R = R; vf.variance = params[m.p_variance]; vf.d_variance = dP[m.p_variance];
@@ -857,6 +870,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     rg.daux_dir_c = (m.c.col_mode != 1 && m.nv > 0) ? b.dAUXc : nullptr;
     rg.daux_dir_r = (m.has_relight && m.nv > 0) ? b.dAUXr : nullptr;
     rg.lddir = kAux; rg.multires_view = m.mv; rg.d_rays_d_alpha = b.drd_alpha; rg.d_o = gi->d_rays_o; rg.d_d = gi->d_rays_d;
+    rg.dz_parts = nf_live ? b.dzparts : nullptr; rg.d_near = nf_live ? gi->d_near : nullptr; rg.d_far = nf_live ? gi->d_far : nullptr;
     be_rays_grad_finish(rg, s);
   }
   return check_backend("render_backward");
@@ -1035,6 +1049,27 @@ int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const fl
 int cnr_timing_collect(cnr_kernel_timing* out, int max_records) {
   static_assert(sizeof(cnr_kernel_timing) == sizeof(KernelTiming), "timing record layout");
   return be_timing_collect(reinterpret_cast<KernelTiming*>(out), max_records);
+}
+
+int cnr_sample_pdf(const float* bins, const float* weights, int64_t n_rays, int32_t n, int32_t n_samples, float* out, void* stream) {
+  if (!bins || !weights || !out) return fail("null argument");
+  if (n_rays <= 0 || n < 2 || n > kMaxRaySamples || n_samples < 1 || n_samples > 64) return fail("sample_pdf: need 2 <= n <= %d bins and 1 <= n_samples <= 64", kMaxRaySamples);
+  UpSample u;
+  u.o = nullptr; u.d = nullptr; u.R = n_rays; u.z = bins; u.ldz = n; u.sdf = nullptr; u.lds = 0; u.n = n; u.m = n_samples; u.inv_s = 0.0f;
+  u.new_z = out; u.w_in = weights;
+  be_upsample(u, (cnr_stream)stream);
+  return check_backend("sample_pdf");
+}
+
+int cnr_up_sample(const float* rays_o, const float* rays_d, const float* z_vals, const float* sdf, int64_t n_rays, int32_t n,
+                  int32_t n_importance, float inv_s, float* out, void* stream) {
+  if (!rays_o || !rays_d || !z_vals || !sdf || !out) return fail("null argument");
+  if (n_rays <= 0 || n < 2 || n > kMaxRaySamples || n_importance < 1 || n_importance > 64) return fail("up_sample: need 2 <= n <= %d samples and 1 <= n_importance <= 64", kMaxRaySamples);
+  UpSample u;
+  u.o = rays_o; u.d = rays_d; u.R = n_rays; u.z = z_vals; u.ldz = n; u.sdf = sdf; u.lds = n; u.n = n; u.m = n_importance; u.inv_s = inv_s;
+  u.new_z = out;
+  be_upsample(u, (cnr_stream)stream);
+  return check_backend("up_sample");
 }
 
 size_t cnr_sdf_eval_scratch_bytes(const cnr_config* cfg, int64_t n_points) { return eval_scratch_bytes(cfg, n_points); }

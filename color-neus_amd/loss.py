@@ -97,12 +97,19 @@ class _FusedLoss(torch.autograd.Function):
         ctx.save_for_backward(color_c, wsum_c, gt_c, mask_c if mask_c is not None else torch.empty(0, device=dev),
                               mean_rel if mean_rel is not None else torch.zeros((), device=dev),
                               eik_factor if eik_factor is not None else torch.ones((), device=dev))
-        ctx.mark_non_differentiable(*[t for t in (rgb_loss, eik) if t is not None])
+        # only ``loss`` carries gradients: the four components are logging values (the reference's loss_dict entries are read with
+        # .item(), NeuS_Trainer.py:155-171); back-propagating through them would bypass the fused coefficients, so they are all
+        # non-differentiable outputs rather than some silently yielding zero gradients
         zero = torch.zeros((), device=dev)
-        return loss, rgb_loss, eik, (mask_loss if mask_loss is not None else zero), (relight_loss if relight_loss is not None else zero)
+        mask_out = mask_loss if mask_loss is not None else zero
+        rel_out = relight_loss if relight_loss is not None else zero
+        ctx.mark_non_differentiable(rgb_loss, eik, mask_out, rel_out)
+        return loss, rgb_loss, eik, mask_out, rel_out
 
     @staticmethod
     def backward(ctx, g_loss, *_unused):
+        if g_loss is None:   # nothing depends on ``loss`` (cannot happen through the components: they are non-differentiable)
+            return (None,) * 12
         color_c, wsum_c, gt_c, mask_c, mean_rel, eik_factor = ctx.saved_tensors
         lam_f, lam_e, lam_m, lam_r = ctx.lambdas
         has_mask, has_rel, _ = ctx.has

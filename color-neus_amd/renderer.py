@@ -72,6 +72,9 @@ class _RenderFunction(torch.autograd.Function):
             saved.append(background_rgb)
         ctx.save_for_backward(*saved, *plist)
         ctx.rays_need_grad = rays_o.requires_grad or rays_d.requires_grad
+        # z is an affine function of near / far only without importance sampling (NeuS.py:311-313; with it z is built under no_grad, :343)
+        ctx.nearfar_need_grad = (near.requires_grad or far.requires_grad) and cfg.n_importance == 0 and z_override is None
+        ctx.nearfar_shapes = (near.shape, far.shape)
         ctx.mark_non_differentiable(out["inside_sphere"], out["z_vals"], out["eik_sums"])
         res = [out[k] for k in _OUT_DIFF if out[k] is not None] + [out["inside_sphere"], out["z_vals"], out["eik_sums"]]
         return tuple(res)
@@ -102,7 +105,10 @@ class _RenderFunction(torch.autograd.Function):
         darr = (C.c_void_p * len(dparams))(*[p.data_ptr() for p in dparams])
         d_o = torch.empty_like(rays_o) if ctx.rays_need_grad else None
         d_d = torch.empty_like(rays_d) if ctx.rays_need_grad else None
-        gin = _lib.CnrInGrads(d_params=C.cast(darr, C.POINTER(C.c_void_p)), d_rays_o=_ptr(d_o), d_rays_d=_ptr(d_d))
+        d_near = torch.empty_like(near) if ctx.nearfar_need_grad else None
+        d_far = torch.empty_like(far) if ctx.nearfar_need_grad else None
+        gin = _lib.CnrInGrads(d_params=C.cast(darr, C.POINTER(C.c_void_p)), d_rays_o=_ptr(d_o), d_rays_d=_ptr(d_d),
+                              d_near=_ptr(d_near), d_far=_ptr(d_far))
         parr = (C.c_void_p * len(plist))(*[p.data_ptr() for p in plist])
         cin = _lib.CnrInputs(rays_o=_ptr(rays_o), rays_d=_ptr(rays_d), near_=_ptr(near), far_=_ptr(far), t_rand=_ptr(t_rand),
                              z_vals_override=_ptr(z_vals) if had_override else None,
@@ -113,7 +119,26 @@ class _RenderFunction(torch.autograd.Function):
         rc = lib.lib.cnr_render_backward(C.byref(ccfg), parr, C.byref(cin), C.byref(cout), _ptr(ctx_buf), ctx_buf.numel(),
                                          C.byref(cg), C.byref(gin), _ptr(scratch), nbytes, _stream_of(rays_o))
         lib.check(rc, "cnr_render_backward")
-        return (None, d_o, d_d, None, None, None, None, None, None, None) + tuple(dparams)
+        if d_near is not None:
+            d_near, d_far = d_near.reshape(ctx.nearfar_shapes[0]), d_far.reshape(ctx.nearfar_shapes[1])
+        return (None, d_o, d_d, d_near, d_far, None, None, None, None, None) + tuple(dparams)
+
+
+def sample_pdf(bins, weights, n_samples, det=True, library=None):
+    """ray_utils.sample_pdf(bins, weights, n_samples, det=True) (lib/models/tools/ray_utils.py:123-154) on the device: the
+    hierarchical sampler's own kernel (cnr_sample_pdf).  Only the deterministic variant exists -- the renderer never uses another."""
+    if not det:
+        raise NotImplementedError("sample_pdf: only det=True (the only mode NeuS.up_sample uses, NeuS.py:180)")
+    lib = library if isinstance(library, _lib.RenderLibrary) else _lib.load_library(library)
+    bins = bins.detach().contiguous().float()
+    weights = weights.detach().contiguous().float()
+    n = bins.shape[-1]
+    assert weights.shape[-1] == n - 1 and bins.shape[:-1] == weights.shape[:-1]
+    R = bins.numel() // n
+    out = torch.empty(*bins.shape[:-1], n_samples, dtype=torch.float32, device=bins.device)
+    rc = lib.lib.cnr_sample_pdf(_ptr(bins), _ptr(weights), R, n, int(n_samples), _ptr(out), _stream_of(bins))
+    lib.check(rc, "cnr_sample_pdf")
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -318,6 +343,17 @@ class NeuSRenderer(nn.Module):
         ret["z_vals"] = out["z_vals"]       # extra keys (not in the reference dict)
         ret["eik_sums"] = out["eik_sums"]   # {sum relax*(|g|-1)^2, sum relax}: needed by ray-sharded training
         return ret
+
+    def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
+        """NeuS.up_sample (NeuS.py:136-181): n_importance new sample positions per ray from the current z / sdf."""
+        z = z_vals.detach().contiguous().float()
+        R, n = z.shape
+        out = torch.empty(R, int(n_importance), dtype=torch.float32, device=z.device)
+        rc = self._lib.lib.cnr_up_sample(_ptr(rays_o.detach().contiguous().float()), _ptr(rays_d.detach().contiguous().float()), _ptr(z),
+                                         _ptr(sdf.detach().reshape(R, n).contiguous().float()), R, n, int(n_importance), float(inv_s),
+                                         _ptr(out), _stream_of(z))
+        self._lib.check(rc, "cnr_up_sample")
+        return out
 
     # -- evaluation paths (NeuS.py:14-64, 410-420) ---------------------------------------------------------------------
     def _param_array(self):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CNR_ABI_VERSION 1
+#define CNR_ABI_VERSION 2
 
 typedef struct cnr_config {
   int32_t type;              /* 0 = NeuS (NeuS.py:68), 1 = Color_NeuS (Color_NeuS.py:10) */
@@ -87,6 +87,8 @@ typedef struct cnr_render_in_grads {
   float* const* d_params;   /* host array of device pointers, same order/shapes as the parameters; overwritten (not accumulated) */
   float* d_rays_o;          /* [R][3] or NULL */
   float* d_rays_d;          /* [R][3] or NULL */
+  float* d_near;            /* [R] or NULL; with d_far.  Non-zero only when n_importance == 0 and no z override: z is then an affine   */
+  float* d_far;             /* function of near / far (NeuS.py:311-313); with importance sampling z is built under no_grad (:343)     */
 } cnr_render_in_grads;
 
 /* optional per-launch timing (HIP events on the launch stream); used by bench.py for the roofline figures */
@@ -145,6 +147,16 @@ int cnr_render_backward(const cnr_config* cfg, const float* const* params, const
                         const cnr_render_outputs* out, const void* ctx, size_t ctx_bytes,
                         const cnr_render_out_grads* gout, const cnr_render_in_grads* gin,
                         void* scratch, size_t scratch_bytes, void* stream);
+
+/* the two sampler functions on their own (the render call runs them inside the hierarchical sampler; these entry points expose the
+ * same kernel so that its tie / flat-cdf / denom < 1e-5 semantics can be exercised directly):
+ *   cnr_sample_pdf = ray_utils.sample_pdf(bins, weights, n_samples, det=True)            (lib/models/tools/ray_utils.py:123-154)
+ *   cnr_up_sample  = NeuS.up_sample(rays_o, rays_d, z_vals, sdf, n_importance, inv_s)     (lib/models/renderers/NeuS.py:136-181)
+ * n <= 256 bins / samples per ray, n_samples (n_importance) <= 64 */
+int cnr_sample_pdf(const float* bins /* [R][n] */, const float* weights /* [R][n-1] */, int64_t n_rays, int32_t n, int32_t n_samples,
+                   float* out /* [R][n_samples] */, void* stream);
+int cnr_up_sample(const float* rays_o, const float* rays_d, const float* z_vals /* [R][n] */, const float* sdf /* [R][n] */, int64_t n_rays,
+                  int32_t n, int32_t n_importance, float inv_s, float* out /* [R][n_importance] */, void* stream);
 
 /* sdf_network.sdf(pts): out[i] = sign * sdf(pts[i]); extract_fields uses sign = -1 (NeuS.py:416) */
 size_t cnr_sdf_eval_scratch_bytes(const cnr_config* cfg, int64_t n_points);

@@ -32,13 +32,16 @@ def make_renderer(ocfg, P, library, device):
     return r.to(device)
 
 
-def run_native(name, tag, library, device, fixed_z=True, rays_grad=True):
+def run_native(name, tag, library, device, fixed_z=True, rays_grad=True, nearfar_grad=False):
     fx = G.load(name)
     ocfg, P = G.weights_of(name, fx)
     r = make_renderer(ocfg, P, library, device)
     o = torch.from_numpy(fx["rays_o"]).to(device).requires_grad_(rays_grad)
     d = torch.from_numpy(fx["rays_d"]).to(device).requires_grad_(rays_grad)
     near, far = torch.from_numpy(fx[f"{tag}:near"]).to(device), torch.from_numpy(fx[f"{tag}:far"]).to(device)
+    if nearfar_grad:
+        near.requires_grad_(True)
+        far.requires_grad_(True)
     z = torch.from_numpy(fx[f"{tag}:z_vals"]).to(device) if fixed_z else None
     if fixed_z:
         out = r(o, d, near, far, z_vals=z)
@@ -56,4 +59,6 @@ def run_native(name, tag, library, device, fixed_z=True, rays_grad=True):
     loss, _ = cn.compute_loss(out, torch.from_numpy(fx["rgb_gt"]).to(device), torch.from_numpy(fx["mask"]).to(device))
     loss.backward()
     grads = {k: p.grad for k, p in r.named_parameters()}
+    if nearfar_grad:
+        return fx, r, out, loss, grads, o, d, near, far
     return fx, r, out, loss, grads, o, d

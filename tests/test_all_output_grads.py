@@ -41,18 +41,19 @@ def _run(library, device, name="tiny_sharp", cos_anneal=0.3, bg=(0.2, 0.5, 0.7))
     errs = {}
     for k in coefs:
         errs["out:" + k] = G.relerr(out_n[k].detach().cpu().reshape(out_o[k].shape), out_o[k].detach())
-    gmax = max(float(p.grad.abs().max()) for p in P64.values())
     for k, p in r.named_parameters():
         ref = P64[k].grad
-        errs["grad:" + k] = float((p.grad.detach().cpu().double() - ref).abs().max()) / max(float(ref.abs().max()), 0.1 * gmax)
+        errs["grad:" + k] = float((p.grad.detach().cpu().double() - ref).abs().max()) / float(ref.abs().max())   # own scale per tensor
     errs["grad:rays_o"] = G.relerr(on.grad.cpu(), o64.grad)
     errs["grad:rays_d"] = G.relerr(dn.grad.cpu(), d64.grad)
     return errs
 
 
 def _check(errs):
+    # parameter gradients: own scale per tensor, hard cap of tests/_golden.py (random cotangents on every output, no float32 twin to
+    # calibrate a tighter per-tensor value against)
     loose = {"out:weights": 5e-4, "out:weight_max": 5e-4, "out:cdf_fine": 5e-4}   # see test_hip_parity.test_against_oracle_larger_batch
-    bad = {k: e for k, e in errs.items() if not e < loose.get(k, 2e-4 if k.startswith("grad:") else 1e-4)}
+    bad = {k: e for k, e in errs.items() if not e < loose.get(k, 1e-3 if k.startswith("grad:") else 1e-4)}
     assert not bad, bad
 
 

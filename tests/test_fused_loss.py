@@ -68,6 +68,5 @@ def test_fused_loss_end_to_end_gradients_match():
         loss.backward()
         res[fused] = (float(loss), {k: p.grad.clone() for k, p in r.named_parameters()})
     assert abs(res[0][0] - res[1][0]) < 1e-6 * abs(res[0][0])
-    gmax = max(float(g.abs().max()) for g in res[0][1].values())
     for k, g in res[0][1].items():
-        assert float((g - res[1][1][k]).abs().max()) <= 1e-5 * max(float(g.abs().max()), 0.1 * gmax), k
+        assert float((g - res[1][1][k]).abs().max()) <= 1e-4 * float(g.abs().max()), k   # own scale per tensor

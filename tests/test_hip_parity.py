@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 DEV = "cuda:0"
 
-E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "neus_dtu_sharp"]
+E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "dtu_noimp_sharp", "neus_dtu_sharp"]
 
 
 def test_library_is_hip():
@@ -26,19 +26,53 @@ def test_library_is_hip():
     assert cn.load_library().backend == "hip-gfx950"
 
 
-@pytest.mark.parametrize("name", E2E)
-@pytest.mark.parametrize("tag", ["det", "jit"])
-def test_g2_render_core_forward_backward(name, tag):
-    fx, r, out, loss, grads, o, d = N.run_native(name, tag, None, DEV, fixed_z=True)
+def _g2(name, tag):
+    noimp = "noimp" in name   # no importance sampling (BASELINE C2): z is a closed form of near / far, which then carry gradients
+    res = N.run_native(name, tag, None, DEV, fixed_z=not noimp, nearfar_grad=noimp)
+    fx, r, out, loss, grads, o, d = res[:7]
     for k in G.OUTPUT_KEYS:
         if f"{tag}:out_{k}" in fx:
             ref = fx[f"{tag}:out_{k}"]
             assert G.relerr(out[k].detach().cpu().reshape(ref.shape), ref) < TOL, k
     assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
-    bad = G.check_param_grads(fx, tag, grads, TOL)
+    checks = [("grad_rays_o", o.grad), ("grad_rays_d", d.grad)] + ([("grad_near", res[7].grad), ("grad_far", res[8].grad)] if noimp else [])
+    return fx, grads, checks
+
+
+@pytest.mark.parametrize("name", E2E)
+@pytest.mark.parametrize("tag", ["det", "jit"])
+def test_g2_render_core_forward_backward(name, tag):
+    """12 outputs and the loss to 1e-4; every parameter-gradient tensor and d rays (d near / d far without importance sampling) at its
+    OWN scale against the reference's float64 run (tests/_golden.py: check_param_grads)."""
+    fx, grads, checks = _g2(name, tag)
+    bad = G.check_param_grads(fx, tag, grads)
     assert not bad, bad
-    assert G.relerr(o.grad.cpu(), fx[f"{tag}:grad_rays_o"]) < TOL
-    assert G.relerr(d.grad.cpu(), fx[f"{tag}:grad_rays_d"]) < TOL
+    for key, got in checks:
+        assert G.check_input_grad(fx, tag, key, got) is None, G.check_input_grad(fx, tag, key, got)
+
+
+def test_param_grad_error_table():
+    """The per-tensor error table of the HIP path on the DTU-size fixtures (what the gate above condenses); written to
+    gpurun_out/ so that it can be committed under profiles/."""
+    lines = []
+    for name in ("dtu_sharp", "dtu_init", "dtu_noimp_sharp", "neus_dtu_sharp"):
+        for tag in ("det", "jit"):
+            fx, grads, checks = _g2(name, tag)
+            rows = G.param_grad_table(fx, tag, grads)
+            lines.append(G.format_grad_table(f"{name} / {tag}: HIP parameter gradients vs the reference's float64 run (own scale per tensor)", rows))
+            for key, got in checks:
+                ref64 = fx[f"{tag}:f64:{key}"]
+                e = float(np.abs(got.detach().cpu().double().numpy().reshape(ref64.shape) - ref64).max()) / float(np.abs(ref64).max())
+                lines.append("%-42s %8d %10.2e" % (key, ref64.size, e))
+            lines.append("")
+            assert max(r[2] for r in rows) <= G.GRAD_TOL_CAP
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "param_grad_error_table.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize("name", E2E)
@@ -167,14 +201,22 @@ def test_parameter_gradients_against_float64_oracle_larger_batch():
     assert abs(float(loss.detach()) - float(l64.detach())) < 2e-4 * abs(float(l64.detach()))
     got = dict(r.named_parameters())
     ref = {k: v.grad for k, v in P64.items()}
-    gmax = max(float(v.abs().max()) for v in ref.values())
+    # the same algorithm in plain float32 (= the reference's arithmetic): its distance from float64 calibrates the tolerance per tensor
+    P32 = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    o32 = O.render(P32, ocfg, o, d, near, far, z_vals=z32)
+    l32, _ = O.compute_loss(o32, gt, mask)
+    l32.backward()
     bad = []
     for k, gr in ref.items():
         name = k if k in got else "renderer." + k
-        err = float((got[name].grad.detach().cpu().double() - gr).abs().max())
-        lim = G.grad_tolerance(float(gr.abs().max()), gmax, 3e-4)   # fp32 vs float64 of the same algorithm (the reference's own spread is 4.5e-4)
-        if not err <= lim:
-            bad.append((k, err, lim))
+        den = float(gr.abs().max())
+        e = ((got[name].grad.detach().cpu().double() - gr).abs() / den).reshape(-1)
+        spread = float((P32[k].grad.double() - gr).abs().max()) / den
+        lim = G.grad_tolerance(spread)
+        allowed = max(1, int(G.GRAD_OUTLIER_FRAC * e.numel())) if e.numel() > 1 else 0
+        bulk = float(torch.sort(e).values[-(allowed + 1)]) if e.numel() > allowed else 0.0
+        if not (float(e.max()) <= G.GRAD_TOL_CAP and bulk <= lim):   # own scale: hard cap on every entry + bulk tolerance (tests/_golden.py)
+            bad.append((k, float(e.max()), bulk, lim))
     assert not bad, bad
 
 
@@ -208,6 +250,53 @@ def test_sdf_grid_and_vertex_colour():
     pts = torch.from_numpy(fx["tiny:pts"]).to(DEV)
     s = r.sdf(pts).cpu()
     assert G.relerr(s[:, 0], fx["tiny:sdf_out"][:, 0]) < TOL
+
+
+def _c5_renderer(device, library=None):
+    fx = G.load("functions")
+    from oracle import colorneus_oracle as O
+    ocfg = O.dtu_config()
+    P = O.init_params(ocfg, seed=0, dtype=torch.float32, trained_like=True)
+    assert abs(O.params_checksum(P) - float(fx["c5:weight_checksum"])) <= 1e-9 * abs(float(fx["c5:weight_checksum"]))
+    return fx, N.make_renderer(ocfg, P, library, device)
+
+
+def test_c5_dtu_size_lattice_and_vertex_colours():
+    """BASELINE config C5 on the DTU-size network (weight-stationary kernels): a 32^3 lattice of extract_fields and 1000 vertex colours
+    of extract_color against the vectors captured from the reference (NeuS.py:14-64)."""
+    fx, r = _c5_renderer(DEV)
+    u = r.extract_fields([-1.01] * 3, [1.01] * 3, DEV, 32).cpu()
+    assert u.shape == (32, 32, 32)
+    assert G.relerr(u, fx["c5:u32"]) < TOL
+    rgb = r.extract_color(fx["c5:verts"], DEV)
+    assert rgb.shape == (1000, 3)
+    assert float(np.abs(rgb - fx["c5:rgb"]).max()) < TOL      # colours are in [0, 1]
+
+
+def test_eval_paths_do_not_depend_on_scratch_contents():
+    """extract_fields / extract_color / sdf with NaN-filled scratch buffers are bit-identical to a clean run (the GEMMs read padded
+    columns: every one of them must be written by the library itself)."""
+    fx, r = _c5_renderer(DEV)
+    pts = torch.from_numpy(fx["c5:verts"]).to(DEV)
+
+    def run():
+        return (r.extract_fields([-1.01] * 3, [1.01] * 3, DEV, 24).clone(), torch.from_numpy(r.extract_color(fx["c5:verts"], DEV)),
+                r.sdf(pts).clone())
+    ref = run()
+    orig_empty = torch.empty
+
+    def poisoned_empty(*a, **k):
+        t = orig_empty(*a, **k)
+        if t.dtype == torch.uint8 and t.numel() > 4096:
+            t.fill_(0xFF)
+        return t
+    try:
+        torch.empty = poisoned_empty
+        got = run()
+    finally:
+        torch.empty = orig_empty
+    for a, b in zip(ref, got):
+        assert torch.equal(a.cpu(), b.cpu())
 
 
 def test_idr_vertex_colour_mid_network():
@@ -270,10 +359,9 @@ def test_full_size_properties_4096_rays():
     # (2) additivity over rays
     _, g_a = run(allr[:2048])
     _, g_b = run(allr[2048:])
-    gmax = max(float(g.abs().max()) for g in g_all.values())
     for k, g in g_all.items():
         err = float((g - (g_a[k] + g_b[k])).abs().max())
-        assert err <= 2e-4 * max(float(g.abs().max()), 0.1 * gmax), (k, err)
+        assert err <= 1e-3 * float(g.abs().max()), (k, err, float(g.abs().max()))   # own scale per tensor
     # (3) determinism
     _, g_again = run(allr)
     for k, g in g_all.items():

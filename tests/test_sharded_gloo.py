@@ -81,7 +81,6 @@ def test_two_rank_sharding_matches_single_process(fused):
     loss.backward()
     assert torch.equal(out["z_vals"][:z0.shape[0]], torch.from_numpy(z0)), "rank 0 must see the single-process jitter rows"
     assert abs(value - float(loss)) < 1e-5 * abs(float(loss))
-    gmax = max(float(p.grad.abs().max()) for p in r.parameters())
     for k, p in r.named_parameters():
         err = float((torch.from_numpy(grads[k]) - p.grad).abs().max())
-        assert err <= 2e-5 * max(float(p.grad.abs().max()), 0.1 * gmax) + 1e-9, (k, err)
+        assert err <= 1e-4 * float(p.grad.abs().max()) + 1e-12, (k, err)   # own scale per tensor

@@ -58,24 +58,40 @@ def make_rays(R, seed, dtype=torch.float32):
     return o.to(dtype), d.to(dtype), gt.to(dtype), mask.to(dtype)
 
 
-def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0.1, rays_grad=True):
-    """Returns dict of numpy arrays: outputs, z_vals, loss, grads."""
+def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0.1, rays_grad=True, dtype=torch.float32, t_rand=None, z_override=None):
+    """Returns dict of numpy arrays: outputs, z_vals, loss, grads.  dtype=float64 runs the SAME reference code in double
+    (its own fp32-vs-fp64 spread is what the gradient gate is calibrated on); near / far are leaves that require grad so that the
+    N_IMPORTANCE == 0 path (z differentiable w.r.t. near / far, NeuS.py:311-313) is pinned as well."""
     r = cls(node)
     r.load_state_dict(P)
+    r = r.to(dtype)
     captured = {}
     orig = r.render_core
 
     def wrapped(rays_o, rays_d, z_vals, *a, **k):
+        if z_override is not None:   # float64 twin: render_core at the float32 run's sample positions (the sampler amplifies
+            z_vals = torch.from_numpy(z_override).to(z_vals.dtype)   # round-off, SURVEY 8c; gate G2 is defined at identical z)
         captured["z_vals"] = z_vals.detach().clone()
         return orig(rays_o, rays_d, z_vals, *a, **k)
 
     r.render_core = wrapped
-    o = o.clone().requires_grad_(rays_grad)
-    d = d.clone().requires_grad_(rays_grad)
+    o = o.to(dtype).clone().requires_grad_(rays_grad)
+    d = d.to(dtype).clone().requires_grad_(rays_grad)
+    gt, mask = gt.to(dtype), mask.to(dtype)
     near, far = mods["ray_utils"].near_far_from_sphere(o.detach(), d.detach())
+    near = near.detach().clone().requires_grad_(True)
+    far = far.detach().clone().requires_grad_(True)
     res = {}
     if jitter_seed is None:
         out = r(o, d, near, far, perturb_overwrite=0)
+    elif t_rand is not None:
+        # float64 twin of a jittered run: replay the float32 draw (torch.rand would produce a different, float64, stream)
+        orig_rand = torch.rand
+        try:
+            torch.rand = lambda *a, **k: torch.from_numpy(t_rand).to(dtype).clone()
+            out = r(o, d, near, far)
+        finally:
+            torch.rand = orig_rand
     else:
         torch.manual_seed(jitter_seed)
         res["t_rand"] = torch.rand([o.shape[0], 1]).numpy()
@@ -88,16 +104,25 @@ def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0
             out["weight_sum"].squeeze().clip(1e-3, 1.0 - 1e-3), mask)
     if "delta_relight" in out:
         dr = out["delta_relight"] * mask.unsqueeze(-1).unsqueeze(-1)
-        loss = loss + 1.0 * torch.nn.functional.mse_loss(torch.mean(dr), torch.tensor(0, dtype=torch.float32))
+        loss = loss + 1.0 * torch.nn.functional.mse_loss(torch.mean(dr), torch.tensor(0, dtype=dtype))
     loss.backward()
     res.update({"out_" + k: v.detach().numpy() for k, v in out.items()})
     res["z_vals"] = captured["z_vals"].numpy()
-    res["near"], res["far"] = near.numpy(), far.numpy()
+    res["near"], res["far"] = near.detach().numpy(), far.detach().numpy()
     res["loss"] = loss.detach().numpy()
     grads = {k: p.grad.detach().clone() for k, p in r.named_parameters()}
     if rays_grad:
         res["grad_rays_o"], res["grad_rays_d"] = o.grad.numpy(), d.grad.numpy()
+    if near.grad is not None:
+        res["grad_near"], res["grad_far"] = near.grad.numpy(), far.grad.numpy()
     return res, grads
+
+
+FULL_TENSOR_LIMIT = 8192   # gradient tensors up to this many entries are stored in full (no striding)
+
+
+def tensor_stride(numel, grad_stride):
+    return 1 if numel <= FULL_TENSOR_LIMIT else grad_stride
 
 
 def e2e_fixture(name, cfg, cls, CN, mods, R, weight_seed, trained_like, store_weights, grad_stride):
@@ -112,13 +137,26 @@ def e2e_fixture(name, cfg, cls, CN, mods, R, weight_seed, trained_like, store_we
             fx["w:" + k] = v.numpy()
     for tag, js in (("det", None), ("jit", 2)):
         res, grads = run_reference(cls, node, P, o, d, gt, mask, js, mods)
+        # the same reference code in float64 at the float32 run's sample positions (same jitter draw): per-tensor truth
+        res64, grads64 = run_reference(cls, node, P, o, d, gt, mask, js, mods, dtype=torch.float64, t_rand=res.get("t_rand"),
+                                       z_override=res["z_vals"] if cfg.n_importance > 0 else None)
         for k, v in res.items():
             fx[f"{tag}:{k}"] = v
+        for k in ("loss", "grad_rays_o", "grad_rays_d", "grad_near", "grad_far"):
+            if k in res64:
+                fx[f"{tag}:f64:{k}"] = res64[k]
         for k, g in grads.items():
-            flat = g.reshape(-1)
-            fx[f"{tag}:g:{k}"] = flat[::grad_stride].numpy().copy()
+            flat, flat64 = g.reshape(-1), grads64[k].reshape(-1)
+            st = tensor_stride(flat.numel(), grad_stride)
+            fx[f"{tag}:g:{k}"] = flat[::st].numpy().copy()
+            fx[f"{tag}:g64:{k}"] = flat64[::st].numpy().copy()
             fx[f"{tag}:gsum:{k}"] = np.float64(flat.double().sum())
             fx[f"{tag}:gabs:{k}"] = np.float64(flat.double().abs().sum())
+            fx[f"{tag}:gsum64:{k}"] = np.float64(flat64.sum())
+            fx[f"{tag}:gabs64:{k}"] = np.float64(flat64.abs().sum())
+            fx[f"{tag}:gmax64:{k}"] = np.float64(flat64.abs().max())
+            # the reference's own float32 round-off on this tensor, relative to the tensor's own scale
+            fx[f"{tag}:gspread:{k}"] = np.float64((flat.double() - flat64).abs().max() / max(float(flat64.abs().max()), 1e-300))
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **fx)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
@@ -197,6 +235,16 @@ def function_fixture(CN, mods, Color_NeuS, NeuS):
     verts = (torch.randn(100, 3, generator=g) * 0.3).numpy()
     fx["vcol:verts"] = verts
     fx["vcol:rgb"] = extract_color(verts, torch.device("cpu"), r.sdf_network, r.color_network, N=64)
+    # --- BASELINE config C5 at the DTU network size: 32^3 lattice (chunks of 16) and 1000 vertex colours; weights from the recipe
+    dtu = O.dtu_config()
+    Pd = O.init_params(dtu, seed=0, dtype=torch.float32, trained_like=True)
+    rd = Color_NeuS(node_from_config(dtu, CN)); rd.load_state_dict(Pd)
+    fx["c5:weight_checksum"] = np.float64(O.params_checksum(Pd))
+    fx["c5:u32"] = extract_fields(bmin, bmax, torch.device("cpu"), 32, lambda p: -rd.sdf_network.sdf(p), N=16)
+    vd = torch.randn(1000, 3, generator=g)
+    vd = (vd / vd.norm(dim=-1, keepdim=True) * (0.5 + 0.05 * torch.randn(1000, 1, generator=g))).numpy()   # near the r = 0.5 surface
+    fx["c5:verts"] = vd
+    fx["c5:rgb"] = extract_color(vd, torch.device("cpu"), rd.sdf_network, rd.color_network, N=64)
     # --- compute_loss harness counterpart: mask on / off (NeuS_Trainer.py:129-171), reproduced inline
     R = 12
     cf = torch.rand(R, 3, generator=g); gtc = torch.rand(R, 3, generator=g)
@@ -261,6 +309,9 @@ def main():
     dtu = O.dtu_config()
     e2e_fixture("dtu_init", dtu, Color_NeuS, CN, mods, R=16, weight_seed=0, trained_like=False, store_weights=False, grad_stride=97)
     e2e_fixture("dtu_sharp", dtu, Color_NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97)
+    # BASELINE config C2: the DTU network with 64 coarse samples and no importance sampling; near / far gradients are live here
+    dtu_noimp = O.dtu_config(); dtu_noimp.n_importance = 0
+    e2e_fixture("dtu_noimp_sharp", dtu_noimp, Color_NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97)
     neus_dtu = O.RenderConfig(type="NeuS", relight=None)  # config/NeuS_dtu.yml: idr, D_IN 9, MULTIRES_VIEW 4
     e2e_fixture("neus_dtu_sharp", neus_dtu, NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97)
 
