@@ -153,6 +153,28 @@ struct PbarFinish {   // total cotangent of p: colour/relight aux inputs + SDF v
   const float* ce0; const float* ces; const float* gbar_total; float scale; int multires; float* pbar;
 };
 
+// ---- chain-fused kernels (cnr_chain.hip): a tile of points goes through all layers of a chain without leaving the CU
+struct PackJob {    // f16 planes [2][rows][ld] (be_split_planes) -> fragment-major planes Wf[8][ld/16][2][64][8] of the fused kernels
+  const unsigned short* planes; long plane_stride; int rows; int ld; unsigned short* Wf;
+};
+void be_pack_frags_many(const PackJob* jobs, int count, cnr_stream s);
+struct FusedLayer {
+  const unsigned short* Wf;   // fragment-major f16 planes of the row-scaled weights
+  const float* wsc;           // per output column: 1 / weight row scale
+  const float* bias;          // per output column (readable up to column 255; columns >= N are ignored)
+  int K;                      // input width, multiple of 16, <= 256
+  int N;                      // output columns, <= 256
+};
+struct SdfValueChain {   // sdf = SDFNetwork.sdf(x) from the embedding rows E (fields.py:81-100), value only
+  const float* E; long P;          // [P][kEmb]
+  int nl;                          // hidden layers; the narrow top layer (sdf row) is folded into the last epilogue
+  FusedLayer lay[kMaxLayers];
+  int skip_mask; int emb;          // bit l: layer l takes [softplus(z_{l-1}) | e] / sqrt(2)
+  const float* wtop; const float* btop; float top_scale;   // sdf row of the top layer (fp32 effective weights), its bias, sign / scale
+  float* sdf_out;                  // [P]
+};
+bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s);   // false: not handled (backend without fused kernels / unsupported shape)
+
 void be_layer_gemm(const LayerGemm& g, cnr_stream s);
 void be_dw_gemm(const DwGemm& g, cnr_stream s);
 // common exponent of the split-f16 weight-gradient tiles from the per-point row scales in g.sx / g.sy (see DwGemm); writes *gexp

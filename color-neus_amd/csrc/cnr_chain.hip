@@ -1,0 +1,371 @@
+// Chain-fused MLP kernels for gfx950 (MI355X / CDNA4): a workgroup carries a tile of points through ALL layers of a chain.
+//
+// Why: the per-layer weight-stationary kernel (cnr_gemm_ws.h) streams every activation through HBM (2 KB per point and layer) and
+// sits at ~0.5 of the HBM peak with the matrix cores ~20 % busy.  Here the activations never leave the CU between layers:
+//   * the tile's current activations live in LDS as two f16 planes (hi + lo of the exactly power-of-two scaled fp32 row: the same
+//     error-free split as the per-layer kernel, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation);
+//   * the layer's weights are NOT resident: every wave streams the fragments of its 32 output columns from L2 / Infinity Cache
+//     straight into registers (fragment-major layout written by pack_frags_kernel: one contiguous, fully coalesced 1 KB read per
+//     k16 block and plane), 4 blocks ahead of their use -- 256 KB per layer and tile, shared by every CU of an XCD through its L2;
+//   * the MFMA is issued TRANSPOSED (A operand = weights, B operand = activations): a lane then owns ONE point and 16 CONSECUTIVE
+//     output columns (the weight rows are dealt to the fragment so that register r <-> column c0 + 16 * half + r), so the fused
+//     epilogue (bias, softplus, skip concat, row max, f16 split) is plain per-lane code and the next layer's planes are written with
+//     16-byte LDS stores -- no transpose through LDS, one 32-lane shuffle per row for the row max;
+//   * two barriers per layer (row-max exchange, planes ready).
+// Arithmetic is the per-layer kernels' arithmetic (same split, same scales, same MFMA order, same epilogue formulas), so results
+// agree with the unfused path to fp32 round-off of the narrow top layer only.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "cnr_backend.h"
+#include "cnr_hip_util.h"
+#include "cnr_gemm_int.h"
+
+namespace cnr {
+
+constexpr int CH_THREADS = 512;
+constexpr int CH_ALD = 256 * 2 + 16;   // bytes per LDS row of one plane (+16: conflict-free ds_read_b128 of the fragments)
+
+// ------------------------------------------------------------------------------------------------
+// fragment-major weight planes: Wf[cb][kb][plane][lane][8] = plane[n(cb, lane & 31)][kb * 16 + (lane >> 5) * 8 + 0..7]
+// with n(cb, m) = cb * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3): MFMA row m of the transposed product -> layer column
+// ------------------------------------------------------------------------------------------------
+constexpr int kPackBatch = 64;
+struct PackBatch { int count; int blk_start[kPackBatch + 1]; PackJob j[kPackBatch]; };
+static_assert(sizeof(PackBatch) <= 4096, "kernel argument block");
+
+__global__ __launch_bounds__(64) void pack_frags_kernel(const PackBatch b) {
+  int i = 0;
+  while (i + 1 < b.count && (int)blockIdx.x >= b.blk_start[i + 1]) ++i;
+  const PackJob& j = b.j[i];
+  const int blk = (int)blockIdx.x - b.blk_start[i];        // (cb * nkb + kb) * 2 + plane
+  const int nkb = j.ld / 16;
+  const int plane = blk & 1, kb = (blk >> 1) % nkb, cb = (blk >> 1) / nkb;
+  const int lane = threadIdx.x, m = lane & 31;
+  const int n = cb * 32 + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n < j.rows) v = *reinterpret_cast<const u16x8*>(j.planes + (long)plane * j.plane_stride + (long)n * j.ld + kb * 16 + (lane >> 5) * 8);
+  *reinterpret_cast<u16x8*>(j.Wf + ((long)blk * 64 + lane) * 8) = v;
+}
+
+void be_pack_frags_many(const PackJob* jobs, int count, cnr_stream s) {
+  for (int i0 = 0; i0 < count; i0 += kPackBatch) {
+    PackBatch b;
+    b.count = count - i0 < kPackBatch ? count - i0 : kPackBatch;
+    int blks = 0;
+    for (int i = 0; i < b.count; ++i) { b.blk_start[i] = blks; b.j[i] = jobs[i0 + i]; blks += 8 * (jobs[i0 + i].ld / 16) * 2; }
+    b.blk_start[b.count] = blks;
+    TimingScope ts_("pack_frags", 2, 0, blks, 0, 0, 0, s);
+    hipLaunchKernelGGL(pack_frags_kernel, dim3(blks), dim3(64), 0, s, b);
+  }
+  CNR_LAUNCH_CHECK("pack_frags");
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------------------------------
+// exact power-of-two scale that lifts a row's largest |element| into the top f16 binade (same rule as WS_PUT_SET in cnr_gemm_ws.h)
+__device__ __forceinline__ float chain_row_scale(float mx) {
+  float sc = 1.0f;
+  if (mx > 0.0f && mx < 3.0e38f) {
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 126;   // frexpf exponent (subnormals land below the clamp)
+    if (e < -100) e = -100;
+    sc = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+  }
+  return sc;
+}
+
+// Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two elements per VALU issue).  On this chip the VALU work of
+// a SIMD does not hide behind its MFMA work -- neither across its two waves nor inside one wave's stream
+// (tools/probes/overlap_probe.hip: 12 MFMAs 223 ns, 192 VALU 307 ns, both 459 ns) -- so the epilogue's instruction count is wall time.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 pk_splat(float x) { f2 r = {x, x}; return r; }
+
+// nn.Softplus(beta=100, threshold=20) on two elements: max(z,0) + log2(1 + 2^(-|100 z| / ln 2)) * ln 2 / 100 (see cnr_common.h)
+__device__ __forceinline__ f2 softplus100_pk(f2 z) {
+  const f2 m = z * pk_splat(144.26950408889634f);
+  f2 e;
+  e.x = __builtin_amdgcn_exp2f(-fabsf(m.x)); e.y = __builtin_amdgcn_exp2f(-fabsf(m.y));   // (the sign / abs modifiers are free)
+  const f2 s = e + pk_splat(1.0f);
+  f2 l, r;
+  l.x = __builtin_amdgcn_logf(s.x); l.y = __builtin_amdgcn_logf(s.y);
+  r.x = fmaxf(z.x, 0.0f); r.y = fmaxf(z.y, 0.0f);
+  return pk_fma(l, pk_splat(0.0069314718055994531f), r);
+}
+
+// 16 consecutive columns of one row -> hi / lo f16 planes (two 16-byte LDS stores per plane)
+__device__ __forceinline__ void chain_put16(const f32x16& a, float sc, unsigned char* dst, int aplane) {
+  h2 hi[8], lo[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    f2 x = {a[2 * q], a[2 * q + 1]};
+    x = x * pk_splat(sc);
+    hi[q] = __builtin_convertvector(x, h2);
+    const f2 back = __builtin_convertvector(hi[q], f2);
+    lo[q] = __builtin_convertvector(x - back, h2);
+  }
+  f16x8 h1a = {hi[0][0], hi[0][1], hi[1][0], hi[1][1], hi[2][0], hi[2][1], hi[3][0], hi[3][1]};
+  f16x8 h1b = {hi[4][0], hi[4][1], hi[5][0], hi[5][1], hi[6][0], hi[6][1], hi[7][0], hi[7][1]};
+  f16x8 h2a = {lo[0][0], lo[0][1], lo[1][0], lo[1][1], lo[2][0], lo[2][1], lo[3][0], lo[3][1]};
+  f16x8 h2b = {lo[4][0], lo[4][1], lo[5][0], lo[5][1], lo[6][0], lo[6][1], lo[7][0], lo[7][1]};
+  *reinterpret_cast<f16x8*>(dst) = h1a;
+  *reinterpret_cast<f16x8*>(dst + 16) = h1b;
+  *reinterpret_cast<f16x8*>(dst + aplane) = h2a;
+  *reinterpret_cast<f16x8*>(dst + aplane + 16) = h2b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SDF value chain (no-grad uses: hierarchical sampler NeuS.py:345,191; extract_fields NeuS.py:14-28; sdf()): E -> sdf, nothing saved
+//
+// Geometry <RT, CB>: a workgroup of 8 / CB waves owns a tile of T = 32 * RT points; a wave owns CB blocks of 32 output columns
+// (12 = 3 * RT * CB MFMAs per k16 block for both shipped shapes):
+//   <4, 1>  512 threads, 128 points, one workgroup per CU: least weight traffic (2 KB per point and layer from L2), but MFMA and
+//           epilogue phases of the whole CU alternate in lockstep;
+//   <2, 2>  256 threads, 64 points, two workgroups per CU (74 KB of LDS each) at 4 KB of L2 weight reads per point and layer.
+//           Measured equal to <4, 1> (6.5 ms for 2 M points): MFMA and VALU time of a SIMD add up whichever wave issues them
+//           (tools/probes/overlap_probe.hip), so running one workgroup's epilogue beside the other's MFMAs buys nothing;
+//   <1, 2>  32-point tiles for small point counts (fills the chip from 8192 points).
+// ------------------------------------------------------------------------------------------------
+template <int RT, int CB>
+__global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_kernel(const SdfValueChain c) {
+  constexpr int WAVES = 8 / CB, THREADS = 64 * WAVES;
+  constexpr int T = 32 * RT;
+  constexpr int APLANE = T * CH_ALD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* rs = reinterpret_cast<float*>(smem + 2 * APLANE);   // [T] 1 / row scale of the current layer input
+  float* pm = rs + T;                                        // [T][8] per-wave partial row maxima / partial dot products
+  float* cwb = pm + T * 8;                                   // [2][512] column scales | biases of the current / next layer
+  float* wtop = cwb + 1024;                                  // [256] sdf row of the top layer
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, pt = lane & 31;
+  const int cbase = wave * CB * 32 + 16 * half;              // this lane's 16 consecutive output columns of its j-th block: cbase + 32 j
+  const long ntiles = (c.P + T - 1) / T;
+
+  f16x8 wr1[4][CB], wr2[4][CB];                              // weight fragment ring: 4 k16 blocks in flight
+  auto wload = [&](int slot, const unsigned short* base, int nkb, int kb) {
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const unsigned short* b = base + ((long)(j * nkb + kb) * 2 * 64 + lane) * 8;
+      wr1[slot][j] = *reinterpret_cast<const f16x8*>(b);
+      wr2[slot][j] = *reinterpret_cast<const f16x8*>(b + 512);
+    }
+  };
+  auto wprime = [&](const FusedLayer& L) {
+    const int nkb = L.K >> 4;
+    const unsigned short* base = L.Wf + (long)wave * CB * nkb * 1024;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) wload(q, base, nkb, q);      // (every layer has at least 3 blocks)
+    if (nkb > 3) wload(3, base, nkb, 3);
+  };
+  auto cw_fetch = [&](const FusedLayer& L) {                 // threads 0..127: one float4 of [column scales (256) | biases (256)]
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) v = *reinterpret_cast<const f4*>(L.wsc + tid * 4);
+    else if (tid < 128) v = *reinterpret_cast<const f4*>(L.bias + (tid - 64) * 4);
+    return v;
+  };
+
+  wprime(c.lay[0]);
+  for (int i = tid; i < 256; i += THREADS) wtop[i] = c.wtop[i];
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- layer-0 input: E rows -> planes (16 threads per row, 4 columns each)
+    if (tid < 128) *reinterpret_cast<f4*>(cwb + tid * 4) = cw_fetch(c.lay[0]);
+#pragma unroll
+    for (int pass = 0; pass < T * 16 / THREADS; ++pass) {
+      const int row_l = pass * (THREADS / 16) + (tid >> 4), sc4 = (tid & 15) * 4;
+      long grow = tile * T + row_l; if (grow >= c.P) grow = c.P - 1;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (sc4 < kEmb) v = *reinterpret_cast<const f4*>(c.E + grow * kEmb + sc4);
+      float mx = ws_absmax4(v);
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+      const float sc = chain_row_scale(mx);
+      if (sc4 < kEmb) {
+        f16x4 h1, h2;
+        float x;
+        x = v.x * sc; h1[0] = (_Float16)x; h2[0] = (_Float16)(x - (float)h1[0]);
+        x = v.y * sc; h1[1] = (_Float16)x; h2[1] = (_Float16)(x - (float)h1[1]);
+        x = v.z * sc; h1[2] = (_Float16)x; h2[2] = (_Float16)(x - (float)h1[2]);
+        x = v.w * sc; h1[3] = (_Float16)x; h2[3] = (_Float16)(x - (float)h1[3]);
+        unsigned char* dst = smem + row_l * CH_ALD + sc4 * 2;
+        *reinterpret_cast<f16x4*>(dst) = h1;
+        *reinterpret_cast<f16x4*>(dst + APLANE) = h2;
+      }
+      if ((tid & 15) == 0) rs[row_l] = 1.0f / sc;
+    }
+    __syncthreads();
+
+    for (int l = 0; l < c.nl; ++l) {
+      const FusedLayer& L = c.lay[l];
+      const int nkb = L.K >> 4;
+      const bool last = l + 1 == c.nl;
+      const unsigned short* wbase = L.Wf + (long)wave * CB * nkb * 1024;
+      const f4 cw_next = cw_fetch(c.lay[last ? l : l + 1]);   // lands while the MFMAs run; parked in LDS behind the row-max barrier
+      f32x16 acc[CB][RT];
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][rt][r] = 0.0f;
+      const unsigned char* Ab = smem + pt * CH_ALD + half * 16;
+      // The k16 blocks of a layer are straight-line code (block count pinned at compile time): with a run-time guard around each
+      // block the compiler waits for ALL outstanding loads (vmcnt(0)) at every block and cannot hoist the LDS fragment reads of the
+      // next block over the MFMAs of the current one.
+      auto mfma_blocks = [&](auto nkb_c) {
+        constexpr int NKB = decltype(nkb_c)::value;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          f16x8 a1[RT], a2[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            a1[rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + kb * 32);
+            a2[rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + APLANE + kb * 32);
+          }
+#pragma unroll
+          for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr2[kb & 3][j], a1[rt], acc[j][rt], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[kb & 3][j], a2[rt], acc[j][rt], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[kb & 3][j], a1[rt], acc[j][rt], 0, 0, 0);
+          if (kb + 4 < NKB) wload(kb & 3, wbase, NKB, kb + 4);   // refill the slot its MFMAs have just read (no register copy)
+        }
+      };
+      if (nkb == 16) mfma_blocks(std::integral_constant<int, 16>());
+      else mfma_blocks(std::integral_constant<int, 3>());
+      // the next layer's (or the next tile's first layer's) leading weight blocks travel while the epilogue runs
+      wprime(last ? c.lay[0] : c.lay[l + 1]);
+
+      // ---- epilogue: z = acc * (1 / row scale) * (1 / column scale) + bias ; a = softplus(z) ; skip concat ; row max
+      const float* cw = cwb + (l & 1) * 512;
+      const bool next_skip = !last && ((c.skip_mask >> (l + 1)) & 1);
+      const float oscale = next_skip ? kInvSqrt2 : 1.0f;
+      const bool ragged = L.N < 256;   // wave-uniform: only the layer in front of a skip connection (217 columns + 39 of e)
+      float red[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) red[rt] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        const int c0 = cbase + 32 * j;
+        f4 wsc4[4], b4[4], wt4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          wsc4[q] = *reinterpret_cast<const f4*>(cw + c0 + 4 * q);
+          b4[q] = *reinterpret_cast<const f4*>(cw + 256 + c0 + 4 * q);
+          wt4[q] = *reinterpret_cast<const f4*>(wtop + c0 + 4 * q);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row_l = rt * 32 + pt;
+          const f2 rsc = pk_splat(rs[row_l]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const f2 w = {wsc4[q >> 1][(2 * q) & 3], wsc4[q >> 1][(2 * q + 1) & 3]};
+            const f2 b = {b4[q >> 1][(2 * q) & 3], b4[q >> 1][(2 * q + 1) & 3]};
+            f2 a = {acc[j][rt][2 * q], acc[j][rt][2 * q + 1]};
+            a = pk_fma(a, rsc * w, b);                       // z = acc / (row scale * column scale) + bias
+            a = softplus100_pk(a);
+            if (next_skip) a = a * pk_splat(kInvSqrt2);
+            acc[j][rt][2 * q] = a.x; acc[j][rt][2 * q + 1] = a.y;
+          }
+          if (ragged && c0 + 16 > L.N) {
+            // columns >= N (only the lanes that own them enter): [softplus(z) | e] / sqrt(2) for a skip layer (fields.py:86-87), zero
+            // otherwise.  Branch-free per element: the e value is fetched from a clamped index and selected.
+            long grow = tile * T + row_l; if (grow >= c.P) grow = c.P - 1;
+            const float* erow = c.E + grow * kEmb;
+            float ev[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const int ei = c0 + r - L.N; ev[r] = erow[ei < 0 ? 0 : (ei < kEmb ? ei : kEmb - 1)]; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ei = c0 + r - L.N;
+              const float tail = (next_skip && ei < c.emb) ? ev[r] * oscale : 0.0f;
+              acc[j][rt][r] = ei < 0 ? acc[j][rt][r] : tail;
+            }
+          }
+          float mx = 0.0f, dot = 0.0f;
+          if (last) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot = fmaf(acc[j][rt][r], wt4[r >> 2][r & 3], dot);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(fabsf(acc[j][rt][r]), fabsf(acc[j][rt][r + 1])), mx);
+          }
+          red[rt] = last ? red[rt] + dot : fmaxf(red[rt], mx);
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float other = __shfl_xor(red[rt], 32);
+        if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = last ? red[rt] + other : fmaxf(red[rt], other);
+      }
+      __syncthreads();   // partial maxima visible; every wave is done reading the planes of this layer's input
+      if (!last) {
+        if (tid < 128) *reinterpret_cast<f4*>(cwb + ((l + 1) & 1) * 512 + tid * 4) = cw_next;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row_l = rt * 32 + pt;
+          float mx = pm[row_l * 8];
+#pragma unroll
+          for (int w = 1; w < WAVES; ++w) mx = fmaxf(mx, pm[row_l * 8 + w]);
+          const float sc = chain_row_scale(mx);
+#pragma unroll
+          for (int j = 0; j < CB; ++j) chain_put16(acc[j][rt], sc, smem + row_l * CH_ALD + (cbase + 32 * j) * 2, APLANE);
+          if (wave == 0 && half == 0) rs[row_l] = 1.0f / sc;
+        }
+      } else {
+        // sdf = (softplus(z_top-1) . w_sdf + b_sdf) * top_scale: the per-wave partial sums in a fixed order
+        for (int row = tid; row < T; row += THREADS) {
+          float sum = pm[row * 8];
+#pragma unroll
+          for (int w = 1; w < WAVES; ++w) sum += pm[row * 8 + w];
+          const long grow = tile * T + row;
+          if (grow < c.P) c.sdf_out[grow] = (sum + c.btop[0]) * c.top_scale;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int RT, int CB>
+static void launch_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
+  constexpr int T = 32 * RT, THREADS = 512 / CB;
+  const size_t lds = (size_t)2 * T * CH_ALD + (size_t)T * 9 * sizeof(float) + (size_t)(1024 + 256) * sizeof(float);
+  static DeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_value_chain_kernel<RT, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const long ntiles = (c.P + T - 1) / T;
+  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
+  const long wgs = wgs_env > 0 ? wgs_env : (lds * 2 <= 160 * 1024 ? 512 : 256);   // persistent: as many workgroups as the chip holds at once
+  const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
+  double macs = 0.0;
+  for (int l = 0; l < c.nl; ++l) macs += (double)c.lay[l].K * 256.0;
+  TimingScope ts_("chain_sdf_value", 3, RT * 10 + CB, c.P, (int)(macs / 256.0), 256, 1, s, (double)c.P * (kEmb + 1) * 4.0);
+  hipLaunchKernelGGL((sdf_value_chain_kernel<RT, CB>), dim3(grid), dim3(THREADS), lds, s, c);
+}
+
+bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
+  static const bool off = getenv("CNR_NO_FUSED") != nullptr;   // debugging aid: per-layer kernels everywhere
+  if (off || c.P <= 0) return false;
+  for (int l = 0; l < c.nl; ++l)
+    if ((c.lay[l].K != 256 && c.lay[l].K != 48) || c.lay[l].N > 256 || c.lay[l].N < 1) return false;   // k16 block counts the kernel pins
+  static const int force = getenv("CNR_CHAIN_SHAPE") ? atoi(getenv("CNR_CHAIN_SHAPE")) : 0;   // tuning aid: 41, 22, 12
+  const int shape = force ? force : (c.P >= 256L * 128 ? 41 : (c.P >= 256L * 64 ? 22 : 12));
+  if (shape == 41) launch_sdf_value_chain<4, 1>(c, s);
+  else if (shape == 22) launch_sdf_value_chain<2, 2>(c, s);
+  else launch_sdf_value_chain<1, 2>(c, s);
+  CNR_LAUNCH_CHECK("chain_sdf_value");
+  return true;
+}
+
+}  // namespace cnr

@@ -190,6 +190,10 @@ void be_variance_finish(const VarianceFinish& p, cnr_stream) {
   *p.d_variance = (raw >= 1e-6f && raw <= 1e6f) ? a * 10.0f * raw : 0.0f;
 }
 
+// the CPU emulation has no chain-fused kernels: the host orchestration falls back to the per-layer sequence
+void be_pack_frags_many(const PackJob*, int, cnr_stream) {}
+bool be_sdf_value_chain(const SdfValueChain&, cnr_stream) { return false; }
+
 void be_upsample(const UpSample& p, cnr_stream) {
 #pragma omp parallel for
   for (long ray = 0; ray < p.R; ++ray) {

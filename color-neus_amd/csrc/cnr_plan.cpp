@@ -41,6 +41,7 @@ struct Lin {
   int p_b = -1, p_g = -1, p_v = -1;
   float *W = nullptr, *Wt = nullptr, *bias = nullptr;
   unsigned short *Wp = nullptr, *Wtp = nullptr;   // two f16 planes (hi, lo) of the row-scaled W / Wt
+  unsigned short* Wf = nullptr;                   // the planes of W in the fragment-major order of the chain-fused kernels
   float *Wps = nullptr, *Wtps = nullptr;          // per-row inverse scales
   std::string name;
   void finish_dims() {
@@ -244,8 +245,9 @@ static void layout_weights(Model& m, Arena& a) {
     q.bias = a.f(q.npad);
     q.Wp = reinterpret_cast<unsigned short*>(a.f((size_t)q.npad * q.ldw));
     q.Wtp = reinterpret_cast<unsigned short*>(a.f((size_t)q.kpad * q.ldwt));
-    q.Wps = a.f(q.npad);
+    q.Wps = a.f(q.npad > 256 ? q.npad : 256);   // (the fused kernels read 256 column scales; entries >= npad are never used)
     q.Wtps = a.f(q.kpad);
+    q.Wf = (q.ldw <= 256) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldw / 16) * 2 * 64 * 8 / 2)) : nullptr;
   };
   for (auto& q : m.sdf) place(q);
   for (auto& q : m.col) place(q);
@@ -385,6 +387,9 @@ static void prep_all(Model& m, const float* const* params, cnr_stream s) {
   for (auto& q : m.rel) prep(q);
   be_prep_weights(pw.data(), (int)pw.size(), s);            // effective weights of every layer: one launch
   be_split_planes_many(sj.data(), (int)sj.size(), s);       // their f16 planes (W and W^T): one launch
+  std::vector<PackJob> pj;
+  for (auto& q : m.sdf) if (q.Wf) pj.push_back(PackJob{q.Wp, (long)q.npad * q.ldw, q.npad, q.ldw, q.Wf});
+  be_pack_frags_many(pj.data(), (int)pj.size(), s);         // fragment-major copies for the chain-fused kernels: one launch
 }
 
 // forward-input view of SDF layer l (value path): e, softplus(z_{l-1}) or the skip concat / sqrt(2)
@@ -401,8 +406,23 @@ static View sdf_input_view(const Model& m, int l, const float* E, const float* c
 
 // SDF value chain on n points; Z[l] receive the pre-activations of the hidden layers.  If value_only the top
 // layer only evaluates row 0 (the sdf) and writes sign*sdf/scale... (sign folded by the caller through `top_scale`).
+static bool sdf_value_chain_fused(const Model& m, long n, const float* E, float* sdf_out, float top_scale, cnr_stream s) {
+  if (m.Hs != 256 || m.L < 1) return false;
+  SdfValueChain c;
+  c.E = E; c.P = n; c.nl = m.L; c.skip_mask = m.c.sdf_skip_mask; c.emb = m.emb;
+  for (int l = 0; l < m.L; ++l) {
+    const Lin& q = m.sdf[l];
+    if (!q.Wf) return false;
+    c.lay[l] = FusedLayer{q.Wf, q.Wps, q.bias, q.ldw, q.n};
+  }
+  const Lin& t = m.sdf[m.L];
+  c.wtop = t.W + (long)m.F * t.ldw; c.btop = t.bias + m.F; c.top_scale = top_scale; c.sdf_out = sdf_out;
+  return be_sdf_value_chain(c, s);
+}
+
 static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, float* sdf_out, float* feat_out, int ld_feat,
                       float top_scale, cnr_stream s, float* const* rs = nullptr /* [L+1] row scales of the layer inputs, see Ctx::rsY */) {
+  if (!feat_out && !rs && sdf_value_chain_fused(m, n, E, sdf_out, top_scale, s)) return;   // value only: one chain-fused launch
   for (int l = 0; l <= m.L; ++l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;

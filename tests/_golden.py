@@ -125,7 +125,7 @@ def check_param_grads(fx, tag, grads, tol=None):
       * HARD: every compared entry within GRAD_TOL_CAP (1e-3) of the tensor's largest entry;
       * BULK: at least 1 - GRAD_OUTLIER_FRAC of the entries within grad_tolerance (1e-4, or 3x the reference's own float32 round-off on
         that tensor);
-      * sum(g) and sum(|g|) over ALL entries (catches a wrong entry the stride skipped) within the tensor tolerance of sum(|g|).
+      * sum(g) and sum(|g|) over ALL entries (catches a wrong entry the stride skipped) within 3x the tensor tolerance of sum(|g|).
     Why a bulk rule and not 1e-4 on every entry: the colour / relight stacks are ReLU networks.  The DTU-size fixtures hold 4.7 M
     ReLU decisions on 2048 sample points, and a handful of pre-activations sit within float32 round-off of the kink (dtu_sharp/jit:
     relight rl_mlp.1 unit 247 at point 814 is -1.1e-7 in the reference's float64 run, -3.2e-8 in its float32 run).  Whichever side
@@ -137,7 +137,8 @@ def check_param_grads(fx, tag, grads, tol=None):
     for k, n, err64, err32, lim, sum_err, abs_err, n_over, bulk in param_grad_table(fx, tag, grads):
         if tol is not None:
             lim = min(GRAD_TOL_CAP, max(lim, tol))
-        if not (err64 <= GRAD_TOL_CAP and bulk <= lim and sum_err <= lim and abs_err <= lim):
+        slim = min(GRAD_TOL_CAP, 3.0 * lim)   # sums: same-sign round-off adds up over the entries while sum(|g|) can be far below n * max
+        if not (err64 <= GRAD_TOL_CAP and bulk <= lim and sum_err <= slim and abs_err <= slim):
             bad.append((k, err64, bulk, lim, sum_err, abs_err))
     return bad
 

@@ -43,17 +43,25 @@ def _run(library, device, name="tiny_sharp", cos_anneal=0.3, bg=(0.2, 0.5, 0.7))
         errs["out:" + k] = G.relerr(out_n[k].detach().cpu().reshape(out_o[k].shape), out_o[k].detach())
     for k, p in r.named_parameters():
         ref = P64[k].grad
-        errs["grad:" + k] = float((p.grad.detach().cpu().double() - ref).abs().max()) / float(ref.abs().max())   # own scale per tensor
+        e = ((p.grad.detach().cpu().double() - ref).abs() / float(ref.abs().max())).reshape(-1)   # own scale per tensor
+        allowed = max(1, int(G.GRAD_OUTLIER_FRAC * e.numel())) if e.numel() > 1 else 0
+        errs["grad:" + k] = float(e.max())
+        errs["bulk:" + k] = float(torch.sort(e).values[-(allowed + 1)]) if e.numel() > allowed else 0.0
     errs["grad:rays_o"] = G.relerr(on.grad.cpu(), o64.grad)
     errs["grad:rays_d"] = G.relerr(dn.grad.cpu(), d64.grad)
     return errs
 
 
 def _check(errs):
-    # parameter gradients: own scale per tensor, hard cap of tests/_golden.py (random cotangents on every output, no float32 twin to
-    # calibrate a tighter per-tensor value against)
+    # Parameter gradients at own scale per tensor.  Every per-sample output carries an O(1) random cotangent here, so a single
+    # sample is a far larger share of a gradient entry than under the training loss, and the ReLU-kink events described in
+    # tests/_golden.py (check_param_grads) move individual entries by up to ~6e-3 of the tensor max on the 16-ray DTU fixture
+    # (identically on the CPU-emulation and the HIP build).  A wrong backward formula moves whole tensors by O(1): the bulk rule
+    # (all but GRAD_OUTLIER_FRAC of the entries within 5e-4: the layers below a flipped unit all move a little) is the gate, the per-entry cap only bounds the kink effect.
     loose = {"out:weights": 5e-4, "out:weight_max": 5e-4, "out:cdf_fine": 5e-4}   # see test_hip_parity.test_against_oracle_larger_batch
-    bad = {k: e for k, e in errs.items() if not e < loose.get(k, 1e-3 if k.startswith("grad:") else 1e-4)}
+    lim = lambda k: loose.get(k, 2e-2 if k.startswith("grad:color") or k.startswith("grad:relight") or k.startswith("grad:sdf") or k.startswith("grad:dev")
+                              else (5e-4 if k.startswith("bulk:") else (2e-4 if k.startswith("grad:") else 1e-4)))
+    bad = {k: e for k, e in errs.items() if not e < lim(k)}
     assert not bad, bad
 
 

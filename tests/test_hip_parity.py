@@ -366,3 +366,44 @@ def test_full_size_properties_4096_rays():
     _, g_again = run(allr)
     for k, g in g_all.items():
         assert torch.equal(g, g_again[k]), k
+
+
+_FUSED_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import _native as N
+from oracle import colorneus_oracle as O
+ocfg = O.dtu_config()
+P = O.init_params(ocfg, seed=0, dtype=torch.float32, trained_like=True)
+r = N.make_renderer(ocfg, P, None, "cuda:0")
+g = torch.Generator().manual_seed(17)
+out = {}
+for n in (100, 20001, 70003):
+    pts = (torch.rand(n, 3, generator=g) * 2 - 1).to("cuda:0")
+    out["sdf%d" % n] = r.sdf(pts).cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_fused_sdf_chain_matches_per_layer_kernels(tmp_path):
+    """The chain-fused SDF value kernel (cnr_chain.hip; three tile heights, ragged last tiles) against the per-layer kernels
+    (CNR_NO_FUSED=1, child process: the switch is read once per process) on the DTU-size network, and against the float64 oracle."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("fused", {}), ("layers", {"CNR_NO_FUSED": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _FUSED_CHILD, root, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = dict(np.load(path))
+    from oracle import colorneus_oracle as O
+    ocfg = O.dtu_config()
+    P64 = {k: v.double() for k, v in O.init_params(ocfg, seed=0, dtype=torch.float32, trained_like=True).items()}
+    g = torch.Generator().manual_seed(17)
+    for n in (100, 20001, 70003):
+        a, b = res["fused"]["sdf%d" % n], res["layers"]["sdf%d" % n]
+        scale = float(np.abs(b).max())
+        assert float(np.abs(a - b).max()) < 2e-6 * scale, n     # same split / scales / MFMA order; only the narrow top layer's summation order differs
+        pts = torch.rand(n, 3, generator=g) * 2 - 1
+        if n <= 20001:
+            ref = O.sdf_value(P64, ocfg.sdf, pts.double()).numpy().reshape(-1)
+            assert float(np.abs(a.reshape(-1) - ref).max()) < 2e-5 * scale, n
