@@ -172,12 +172,6 @@ struct SdfValueChain {   // sdf = SDFNetwork.sdf(x) from the embedding rows E (f
   int skip_mask; int emb;          // bit l: layer l takes [softplus(z_{l-1}) | e] / sqrt(2)
   const float* wtop; const float* btop; float top_scale;   // sdf row of the top layer (fp32 effective weights), its bias, sign / scale
   float* sdf_out;                  // [P]
-  // optional outputs of the differentiable forward (Color_NeuS.py:52-54): what the gradient chain and the backward pass re-read
-  float* Zsave[kMaxLayers] = {};   // [P][256] pre-activations z_l, columns >= N hold the skip tail e (the layout of the per-layer path)
-  float* rs_out[kMaxLayers + 1] = {};   // [P] row scale of the INPUT of layer l (LayerGemm::rs_out convention); index nl = top layer input
-  FusedLayer top = {};             // the 256 feature rows of the top layer (K = N = 256), used when feat_out is set
-  int dbg = 0;
-  float* feat_out = nullptr; int ld_feat = 0;   // [P][ld_feat] features = top layer without its sdf row, no activation
 };
 bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s);   // false: not handled (backend without fused kernels / unsupported shape)
 

@@ -12,8 +12,13 @@
 //     epilogue (bias, softplus, skip concat, row max, f16 split) is plain per-lane code and the next layer's planes are written with
 //     16-byte LDS stores -- no transpose through LDS, one 32-lane shuffle per row for the row max;
 //   * two barriers per layer (row-max exchange, planes ready).
-// Arithmetic is the per-layer kernels' arithmetic (same split, same scales, same MFMA order, same epilogue formulas), so results
-// agree with the unfused path to fp32 round-off of the narrow top layer only.
+// Arithmetic is the per-layer kernels' arithmetic (same split, same scales, same MFMA order; the epilogue uses fused multiply-adds),
+// so results agree with the unfused path to fp32 round-off.
+// Scope: the chains that save nothing (sampler, lattice, sdf()).  A variant that also stored the pre-activations, features and
+// row scales for the backward pass was built and measured (commit eeb54d9: parity green, 3.8 ms against 2.4 ms for the nine
+// per-layer launches at 524 288 points): in the transposed layout a lane owns a 64-byte piece of a row, a wave-wide store
+// touches 32 rows, and such stores drain at ~8 B/clk/CU; with the activations saved the chain is no longer MFMA/VALU bound either
+// way (1 KB written per point and layer against 2 KB moved by the per-layer kernel), so the saving chains stay per layer.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -78,10 +83,9 @@ __device__ __forceinline__ float chain_row_scale(float mx) {
   return sc;
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and store
-// (s_waitcnt vmcnt(0)): here that would expose the latency of the weight blocks prefetched for the next layer and of the
-// activation rows just stored for the backward pass at every one of the two barriers per layer.  Global data written by one wave is
-// never read by another wave of the same launch, so no global ordering is needed.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global access (s_waitcnt
+// vmcnt(0)), i.e. it would wait for the weight blocks prefetched for the next layer at both barriers of every layer.  Global data
+// written by one wave is never read by another wave of the same launch, so no global ordering is needed.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -139,22 +143,19 @@ __device__ __forceinline__ void chain_put16(const f32x16& a, float sc, unsigned 
 //           (tools/probes/overlap_probe.hip), so running one workgroup's epilogue beside the other's MFMAs buys nothing;
 //   <1, 2>  32-point tiles for small point counts (fills the chip from 8192 points).
 // ------------------------------------------------------------------------------------------------
-template <int RT, int CB, bool SAVE>
+template <int RT, int CB>
 __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_kernel(const SdfValueChain c) {
   constexpr int WAVES = 8 / CB, THREADS = 64 * WAVES;
   constexpr int T = 32 * RT;
   constexpr int APLANE = T * CH_ALD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* rs = reinterpret_cast<float*>(smem + 2 * APLANE);   // [T] 1 / row scale of the current layer input
-  float* pm = rs + T;                                        // [T][8] per-wave partial row maxima
-  float* pd = pm + T * 8;                                    // [T][8] per-wave partial dot products of the sdf row
-  float* cwb = pd + T * 8;                                   // [2][512] column scales | biases of the current / next layer
+  float* pm = rs + T;                                        // [T][8] per-wave partial row maxima / partial dot products
+  float* cwb = pm + T * 8;                                   // [2][512] column scales | biases of the current / next layer
   float* wtop = cwb + 1024;                                  // [256] sdf row of the top layer
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, pt = lane & 31;
   const int cbase = wave * CB * 32 + 16 * half;              // this lane's 16 consecutive output columns of its j-th block: cbase + 32 j
   const long ntiles = (c.P + T - 1) / T;
-  const bool with_top = SAVE && c.feat_out != nullptr;       // the feature rows of the top layer run as one more 256-wide step
-  const int nsteps = c.nl + (with_top ? 1 : 0);
 
   f16x8 wr1[4][CB], wr2[4][CB];                              // weight fragment ring: 4 k16 blocks in flight
   auto wload = [&](int slot, const unsigned short* base, int nkb, int kb) {
@@ -178,9 +179,6 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
     else if (tid < 128) v = *reinterpret_cast<const f4*>(L.bias + (tid - 64) * 4);
     return v;
   };
-  auto step_layer = [&](int l) -> const FusedLayer& { return l < c.nl ? c.lay[l] : c.top; };
-  // the scale a row's consumers get (LayerGemm::rs_out convention): 0 for an all-zero row, NaN for a non-finite one
-  auto rs_value = [](float mx, float sc) { return (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); };
 
   wprime(c.lay[0]);
   for (int i = tid; i < 256; i += THREADS) wtop[i] = c.wtop[i];
@@ -212,14 +210,12 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
     }
     lds_barrier();
 
-    for (int l = 0; l < nsteps; ++l) {
-      const bool is_top = l == c.nl;                          // (only with_top)
-      const FusedLayer& L = step_layer(l);
+    for (int l = 0; l < c.nl; ++l) {
+      const FusedLayer& L = c.lay[l];
       const int nkb = L.K >> 4;
-      const bool last = l + 1 == nsteps;                      // no further MFMA step for this tile
-      const bool last_hidden = l + 1 == c.nl;                 // its activations feed the sdf row of the top layer
+      const bool last = l + 1 == c.nl;
       const unsigned short* wbase = L.Wf + (long)wave * CB * nkb * 1024;
-      const f4 cw_next = cw_fetch(step_layer(last ? l : l + 1));   // lands while the MFMAs run; parked in LDS behind the row-max barrier
+      const f4 cw_next = cw_fetch(c.lay[last ? l : l + 1]);   // lands while the MFMAs run; parked in LDS behind the row-max barrier
       f32x16 acc[CB][RT];
 #pragma unroll
       for (int j = 0; j < CB; ++j)
@@ -258,121 +254,75 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
       };
       if (nkb == 16) mfma_blocks(std::integral_constant<int, 16>());
       else mfma_blocks(std::integral_constant<int, 3>());
-      // the next step's (or the next tile's first layer's) leading weight blocks travel while the epilogue runs
-      wprime(last ? c.lay[0] : step_layer(l + 1));
-
-      const float* cw = cwb + (l & 1) * 512;
-      if (SAVE && is_top) {
-        // ---- feature rows of the top layer: feat = acc / (row scale * column scale) + bias, no activation (EK_SDF_TOP)
-#pragma unroll
-        for (int j = 0; j < CB; ++j) {
-          const int c0 = cbase + 32 * j;
-          f4 wsc4[4], b4[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            wsc4[q] = *reinterpret_cast<const f4*>(cw + c0 + 4 * q);
-            b4[q] = *reinterpret_cast<const f4*>(cw + 256 + c0 + 4 * q);
-          }
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            const int row_l = rt * 32 + pt;
-            const f2 rsc = pk_splat(rs[row_l]);
-            const long grow = tile * T + row_l;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              f2 lo = {acc[j][rt][4 * q], acc[j][rt][4 * q + 1]}, hi = {acc[j][rt][4 * q + 2], acc[j][rt][4 * q + 3]};
-              const f2 wl = {wsc4[q].x, wsc4[q].y}, wh = {wsc4[q].z, wsc4[q].w}, bl = {b4[q].x, b4[q].y}, bh = {b4[q].z, b4[q].w};
-              lo = pk_fma(lo, rsc * wl, bl); hi = pk_fma(hi, rsc * wh, bh);
-              const f4 o = {lo.x, lo.y, hi.x, hi.y};
-              if (grow < c.P && c0 + 4 * q < L.N) *reinterpret_cast<f4*>(c.feat_out + grow * c.ld_feat + c0 + 4 * q) = o;
-            }
-          }
-        }
-        lds_barrier();   // the next tile's prologue overwrites the planes
-        continue;
-      }
+      // the next layer's (or the next tile's first layer's) leading weight blocks travel while the epilogue runs
+      wprime(last ? c.lay[0] : c.lay[l + 1]);
 
       // ---- epilogue: z = acc * (1 / row scale) * (1 / column scale) + bias ; a = softplus(z) ; skip concat ; row max
-      const bool next_skip = !last_hidden && ((c.skip_mask >> (l + 1)) & 1);
+      const float* cw = cwb + (l & 1) * 512;
+      const bool next_skip = !last && ((c.skip_mask >> (l + 1)) & 1);
       const float oscale = next_skip ? kInvSqrt2 : 1.0f;
       const bool ragged = L.N < 256;   // wave-uniform: only the layer in front of a skip connection (217 columns + 39 of e)
-      float* zsave = SAVE ? c.Zsave[l] : nullptr;
-      float rmax[RT], rdot[RT];
+      float red[RT];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) { rmax[rt] = 0.0f; rdot[rt] = 0.0f; }
+      for (int rt = 0; rt < RT; ++rt) red[rt] = 0.0f;
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
         const int c0 = cbase + 32 * j;
-        f4 wsc4[4], b4[4];
+        f4 wsc4[4], b4[4], wt4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           wsc4[q] = *reinterpret_cast<const f4*>(cw + c0 + 4 * q);
           b4[q] = *reinterpret_cast<const f4*>(cw + 256 + c0 + 4 * q);
+          wt4[q] = *reinterpret_cast<const f4*>(wtop + c0 + 4 * q);
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int row_l = rt * 32 + pt;
           const f2 rsc = pk_splat(rs[row_l]);
-          const long grow_s = tile * T + row_l;
-          const long grow = grow_s < c.P ? grow_s : c.P - 1;
-          const bool tail_lane = ragged && c0 + 16 > L.N;   // owns columns >= N: [softplus(z) | e] / sqrt(2) in front of a skip layer
-          float ev[16];
-          asm volatile("" ::: "memory");   // keep the e loads of the later row tiles from being hoisted up here (16 live registers each)
-          if (tail_lane) {
-            // (fields.py:86-87).  Branch-free per element: the e value is fetched from a clamped index and selected.
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const f2 w = {wsc4[q >> 1][(2 * q) & 3], wsc4[q >> 1][(2 * q + 1) & 3]};
+            const f2 b = {b4[q >> 1][(2 * q) & 3], b4[q >> 1][(2 * q + 1) & 3]};
+            f2 a = {acc[j][rt][2 * q], acc[j][rt][2 * q + 1]};
+            a = pk_fma(a, rsc * w, b);                       // z = acc / (row scale * column scale) + bias
+            a = softplus100_pk(a);
+            if (next_skip) a = a * pk_splat(kInvSqrt2);
+            acc[j][rt][2 * q] = a.x; acc[j][rt][2 * q + 1] = a.y;
+          }
+          if (ragged && c0 + 16 > L.N) {
+            // columns >= N (only the lanes that own them enter): [softplus(z) | e] / sqrt(2) for a skip layer (fields.py:86-87), zero
+            // otherwise.  Branch-free per element: the e value is fetched from a clamped index and selected.
+            long grow = tile * T + row_l; if (grow >= c.P) grow = c.P - 1;
             const float* erow = c.E + grow * kEmb;
+            float ev[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const int ei = c0 + r - L.N; ev[r] = erow[ei < 0 ? 0 : (ei < kEmb ? ei : kEmb - 1)]; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int ei = c0 + r - L.N;
-              const float e = erow[ei < 0 ? 0 : (ei < kEmb ? ei : kEmb - 1)];
-              ev[r] = (next_skip && ei < c.emb) ? e : 0.0f;
+              const float tail = (next_skip && ei < c.emb) ? ev[r] * oscale : 0.0f;
+              acc[j][rt][r] = ei < 0 ? acc[j][rt][r] : tail;
             }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {   // four consecutive columns: one 16-byte store of z, two packed pairs of arithmetic
-            const f2 wl = {wsc4[q].x, wsc4[q].y}, wh = {wsc4[q].z, wsc4[q].w}, bl = {b4[q].x, b4[q].y}, bh = {b4[q].z, b4[q].w};
-            f2 zl = {acc[j][rt][4 * q], acc[j][rt][4 * q + 1]}, zh = {acc[j][rt][4 * q + 2], acc[j][rt][4 * q + 3]};
-            zl = pk_fma(zl, rsc * wl, bl);                   // z = acc / (row scale * column scale) + bias
-            zh = pk_fma(zh, rsc * wh, bh);
-            f2 al = softplus100_pk(zl), ah = softplus100_pk(zh);
-            if (tail_lane) {                                 // the saved row is [z | e] (tail fill of EK_STORE), the activation row [softplus(z) | e]
-              const int cq = c0 + 4 * q;
-              const bool t0 = cq >= L.N, t1 = cq + 1 >= L.N, t2 = cq + 2 >= L.N, t3 = cq + 3 >= L.N;
-              zl.x = t0 ? ev[4 * q] : zl.x; zl.y = t1 ? ev[4 * q + 1] : zl.y; zh.x = t2 ? ev[4 * q + 2] : zh.x; zh.y = t3 ? ev[4 * q + 3] : zh.y;
-              al.x = t0 ? ev[4 * q] : al.x; al.y = t1 ? ev[4 * q + 1] : al.y; ah.x = t2 ? ev[4 * q + 2] : ah.x; ah.y = t3 ? ev[4 * q + 3] : ah.y;
-            }
-            if (SAVE && zsave != nullptr && grow_s < c.P && !(c.dbg & 4)) {
-              const f4 o = {zl.x, zl.y, zh.x, zh.y};
-              *reinterpret_cast<f4*>(zsave + grow_s * 256 + c0 + 4 * q) = o;
-            }
-            if (next_skip) { al = al * pk_splat(kInvSqrt2); ah = ah * pk_splat(kInvSqrt2); }
-            acc[j][rt][4 * q] = al.x; acc[j][rt][4 * q + 1] = al.y; acc[j][rt][4 * q + 2] = ah.x; acc[j][rt][4 * q + 3] = ah.y;
           }
           float mx = 0.0f, dot = 0.0f;
-          if (last_hidden) {
-            f4 wt4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wt4[q] = *reinterpret_cast<const f4*>(wtop + c0 + 4 * q);
+          if (last) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dot = fmaf(acc[j][rt][r], wt4[r >> 2][r & 3], dot);
-          }
-          if (!last) {
+          } else {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(fabsf(acc[j][rt][r]), fabsf(acc[j][rt][r + 1])), mx);
           }
-          rmax[rt] = fmaxf(rmax[rt], mx);
-          rdot[rt] += dot;
+          red[rt] = last ? red[rt] + dot : fmaxf(red[rt], mx);
         }
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        if (!last) { const float o = __shfl_xor(rmax[rt], 32); if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = fmaxf(rmax[rt], o); }
-        if (last_hidden) { const float o = __shfl_xor(rdot[rt], 32); if (half == 0) pd[(rt * 32 + pt) * 8 + wave] = rdot[rt] + o; }
+        const float other = __shfl_xor(red[rt], 32);
+        if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = last ? red[rt] + other : fmaxf(red[rt], other);
       }
-      lds_barrier();   // partial maxima / dot products visible; every wave is done reading the planes of this layer's input
+      lds_barrier();   // partial maxima visible; every wave is done reading the planes of this layer's input
       if (!last) {
         if (tid < 128) *reinterpret_cast<f4*>(cwb + ((l + 1) & 1) * 512 + tid * 4) = cw_next;
-        float* rso = SAVE ? c.rs_out[l + 1] : nullptr;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int row_l = rt * 32 + pt;
@@ -382,19 +332,14 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
           const float sc = chain_row_scale(mx);
 #pragma unroll
           for (int j = 0; j < CB; ++j) chain_put16(acc[j][rt], sc, smem + row_l * CH_ALD + (cbase + 32 * j) * 2, APLANE);
-          if (wave == 0 && half == 0) {
-            rs[row_l] = 1.0f / sc;
-            const long grow = tile * T + row_l;
-            if (SAVE && rso != nullptr && grow < c.P) rso[grow] = rs_value(mx, sc);
-          }
+          if (wave == 0 && half == 0) rs[row_l] = 1.0f / sc;
         }
-      }
-      if (last_hidden) {
+      } else {
         // sdf = (softplus(z_top-1) . w_sdf + b_sdf) * top_scale: the per-wave partial sums in a fixed order
         for (int row = tid; row < T; row += THREADS) {
-          float sum = pd[row * 8];
+          float sum = pm[row * 8];
 #pragma unroll
-          for (int w = 1; w < WAVES; ++w) sum += pd[row * 8 + w];
+          for (int w = 1; w < WAVES; ++w) sum += pm[row * 8 + w];
           const long grow = tile * T + row;
           if (grow < c.P) c.sdf_out[grow] = (sum + c.btop[0]) * c.top_scale;
         }
@@ -404,29 +349,21 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
   }
 }
 
-template <int RT, int CB, bool SAVE>
+template <int RT, int CB>
 static void launch_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
   constexpr int T = 32 * RT, THREADS = 512 / CB;
-  const size_t lds = (size_t)2 * T * CH_ALD + (size_t)T * 17 * sizeof(float) + (size_t)(1024 + 256) * sizeof(float);
+  const size_t lds = (size_t)2 * T * CH_ALD + (size_t)T * 9 * sizeof(float) + (size_t)(1024 + 256) * sizeof(float);
   static DeviceOnce attr_once;
   if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_value_chain_kernel<RT, CB, SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_value_chain_kernel<RT, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = (c.P + T - 1) / T;
   static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
   const long wgs = wgs_env > 0 ? wgs_env : (lds * 2 <= 160 * 1024 ? 512 : 256);   // persistent: as many workgroups as the chip holds at once
   const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
-  double macs = 0.0, bytes = (double)c.P * (kEmb + 1) * 4.0;
-  for (int l = 0; l < c.nl; ++l) {
-    macs += (double)c.lay[l].K * 256.0;
-    if (SAVE && c.Zsave[l]) bytes += (double)c.P * 1024.0;
-    if (SAVE && c.rs_out[l + 1]) bytes += (double)c.P * 4.0;
-  }
-  if (SAVE && c.feat_out) { macs += 256.0 * 256.0; bytes += (double)c.P * 1024.0; }
-  TimingScope ts_(SAVE ? "chain_sdf_fwd" : "chain_sdf_value", 3, RT * 10 + CB, c.P, (int)(macs / 256.0), 256, 1, s, bytes);
-  SdfValueChain cc = c;
-  static const int dbg = getenv("CNR_CHAIN_DBG") ? atoi(getenv("CNR_CHAIN_DBG")) : 0;
-  cc.dbg = dbg;
-  hipLaunchKernelGGL((sdf_value_chain_kernel<RT, CB, SAVE>), dim3(grid), dim3(THREADS), lds, s, cc);
+  double macs = 0.0;
+  for (int l = 0; l < c.nl; ++l) macs += (double)c.lay[l].K * 256.0;
+  TimingScope ts_("chain_sdf_value", 3, RT * 10 + CB, c.P, (int)(macs / 256.0), 256, 1, s, (double)c.P * (kEmb + 1) * 4.0);
+  hipLaunchKernelGGL((sdf_value_chain_kernel<RT, CB>), dim3(grid), dim3(THREADS), lds, s, c);
 }
 
 bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
@@ -434,21 +371,12 @@ bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
   if (off || c.P <= 0) return false;
   for (int l = 0; l < c.nl; ++l)
     if ((c.lay[l].K != 256 && c.lay[l].K != 48) || c.lay[l].N > 256 || c.lay[l].N < 1) return false;   // k16 block counts the kernel pins
-  bool save = c.feat_out != nullptr;
-  for (int l = 0; l <= c.nl; ++l) save = save || (l < c.nl && c.Zsave[l]) || c.rs_out[l];
-  if (c.feat_out && (c.top.K != 256 || c.top.N != 256 || (c.ld_feat & 3))) return false;
   static const int force = getenv("CNR_CHAIN_SHAPE") ? atoi(getenv("CNR_CHAIN_SHAPE")) : 0;   // tuning aid: 41, 22, 12
   const int shape = force ? force : (c.P >= 256L * 128 ? 41 : (c.P >= 256L * 64 ? 22 : 12));
-  if (save) {
-    if (shape == 41) launch_sdf_value_chain<4, 1, true>(c, s);
-    else if (shape == 22) launch_sdf_value_chain<2, 2, true>(c, s);
-    else launch_sdf_value_chain<1, 2, true>(c, s);
-  } else {
-    if (shape == 41) launch_sdf_value_chain<4, 1, false>(c, s);
-    else if (shape == 22) launch_sdf_value_chain<2, 2, false>(c, s);
-    else launch_sdf_value_chain<1, 2, false>(c, s);
-  }
-  CNR_LAUNCH_CHECK("chain_sdf");
+  if (shape == 41) launch_sdf_value_chain<4, 1>(c, s);
+  else if (shape == 22) launch_sdf_value_chain<2, 2>(c, s);
+  else launch_sdf_value_chain<1, 2>(c, s);
+  CNR_LAUNCH_CHECK("chain_sdf_value");
   return true;
 }
 

@@ -406,10 +406,7 @@ static View sdf_input_view(const Model& m, int l, const float* E, const float* c
 
 // SDF value chain on n points; Z[l] receive the pre-activations of the hidden layers.  If value_only the top
 // layer only evaluates row 0 (the sdf) and writes sign*sdf/scale... (sign folded by the caller through `top_scale`).
-// One chain-fused launch for the whole SDF network on n points (cnr_chain.hip).  Value only (Z == nullptr: sampler, lattice, sdf())
-// or the differentiable forward that also leaves the pre-activations Z[l], the features and the row scales rs[l] behind.
-static bool sdf_chain_fused(const Model& m, long n, const float* E, float* const* Z, float* sdf_out, float* feat_out, int ld_feat,
-                            float top_scale, float* const* rs, cnr_stream s) {
+static bool sdf_value_chain_fused(const Model& m, long n, const float* E, float* sdf_out, float top_scale, cnr_stream s) {
   if (m.Hs != 256 || m.L < 1) return false;
   SdfValueChain c;
   c.E = E; c.P = n; c.nl = m.L; c.skip_mask = m.c.sdf_skip_mask; c.emb = m.emb;
@@ -417,22 +414,15 @@ static bool sdf_chain_fused(const Model& m, long n, const float* E, float* const
     const Lin& q = m.sdf[l];
     if (!q.Wf) return false;
     c.lay[l] = FusedLayer{q.Wf, q.Wps, q.bias, q.ldw, q.n};
-    c.Zsave[l] = feat_out ? Z[l] : nullptr;
   }
   const Lin& t = m.sdf[m.L];
   c.wtop = t.W + (long)m.F * t.ldw; c.btop = t.bias + m.F; c.top_scale = top_scale; c.sdf_out = sdf_out;
-  if (feat_out) {
-    if (!t.Wf || m.F != 256) return false;
-    c.top = FusedLayer{t.Wf, t.Wps, t.bias, t.ldw, m.F};
-    c.feat_out = feat_out; c.ld_feat = ld_feat;
-    if (rs) for (int l = 1; l <= m.L; ++l) c.rs_out[l] = rs[l];
-  }
   return be_sdf_value_chain(c, s);
 }
 
 static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, float* sdf_out, float* feat_out, int ld_feat,
                       float top_scale, cnr_stream s, float* const* rs = nullptr /* [L+1] row scales of the layer inputs, see Ctx::rsY */) {
-  if ((feat_out || !rs) && sdf_chain_fused(m, n, E, Z, sdf_out, feat_out, ld_feat, top_scale, rs, s)) return;   // one chain-fused launch
+  if (!feat_out && !rs && sdf_value_chain_fused(m, n, E, sdf_out, top_scale, s)) return;   // value only: one chain-fused launch
   for (int l = 0; l <= m.L; ++l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;
