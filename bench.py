@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """Benchmark of the Color-NeuS render hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    ... --scaling strong --rays-total 4096      BASELINE config C4: a fixed 4096-ray batch split over the N ranks (512 per GPU at N = 8)
 
-A step = forward + loss + backward (+ RCCL gradient all-reduce for N>1, + per-parameter clip + Adam) of the Color_NeuS DTU
+A step = forward + loss + backward (+ RCCL gradient all-reduce for N > 1) + per-parameter clip + Adam of the Color_NeuS DTU
 renderer block (config/Color_NeuS_dtu.yml: 8x256 SDF net, 4x256 colour net, 4x256 relight net, 64 coarse + 64 importance
-samples in 4 up-sampling steps) over one batch of synthetic rays of an 800x800 view; inputs resident in HBM.  Rays shard
-across ranks (weak scaling: --rays is per GPU).  Rank 0 prints ONE JSON line.
+samples in 4 up-sampling steps) over one batch of synthetic rays of an 800x800 view; inputs resident in HBM.  Rays shard across
+ranks (weak scaling by default: --rays is per GPU).  Rank 0 prints ONE JSON line.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (the weight-stationary layer GEMM): algorithmic HBM bytes per launch (operand matrices read
-               once + outputs written once) / per-launch HIP-event time, vs the 8 TB/s HBM3E peak.
-               Measured in a second, event-instrumented pass over the same steps.
-  cpu_baseline the CPU oracle (a port of the reference algorithm in plain PyTorch ops) timed on the host cores on a bounded
-               sample of the same workload (rank 0, N=1 only).
+  roofline            dominant kernel: algorithmic HBM bytes per launch (operand matrices read once + outputs written once,
+                      DESIGN.md section 4) / per-launch HIP-event time against the 8 TB/s HBM3E peak (hbm_frac), and its matrix-core
+                      work (3 f16 MFMAs per fp32 product) against the 2.5 PFLOP/s dense f16 peak (mfma_frac).  Measured in a second,
+                      event-instrumented pass over the same steps.
+  kernel_breakdown    per kernel family: ms per step, GB/s (algorithmic), TFLOP/s -- includes the sampler / compositor kernels.
+  small_batch         rays/s of the same step at 512 and 1024 rays per step (the reference trains at N_RAYS 1024; 512 is C4's per-GPU share).
+  torch_gpu_baseline  the plain-PyTorch restatement of the reference algorithm (oracle/) on the same GPU, bounded sample: the
+                      stand-in for "reference single-GPU PyTorch" (the reference's own Python cannot travel to the GPU box).
+  cpu_baseline        the same restatement on the host cores (contract object: best thread count), plus cpu_baseline_1thread (the
+                      reference pins OMP/MKL to one thread, train.py:4-8) and cpu_baseline_allcores; bounded samples, rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -29,30 +35,36 @@ import torch
 import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
+F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (no sparsity)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s measured with a float4 copy)
+SPLIT_F16_KERNELS = ("layer_gemm_ws", "dw_gemm_hx", "chain_sdf_value")   # 3 f16 MFMAs per fp32-equivalent product
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=4096, help="rays per step per GPU")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per step per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--rays-total", type=int, default=4096, help="rays per step over ALL GPUs (--scaling strong)")
     ap.add_argument("--no-optim", action="store_true", help="time fwd+loss+bwd only (skip clip + Adam)")
+    ap.add_argument("--torch-optim", action="store_true", help="torch._foreach clip + torch fused Adam instead of the library's one-launch clip+Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true")
+    ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="torch threads of the CPU baseline (16 was the fastest of {8,16,32,64,128} on the 2x64-core bench host)")
+                    help="torch threads of the contract CPU baseline (16 was the fastest of {8,16,32,64,128} on the 2x64-core bench host)")
     ap.add_argument("--torch-loss", action="store_true", help="evaluate the loss with torch ops instead of the library's fused loss kernels")
-    ap.add_argument("--torch-gpu-baseline", action="store_true", help="also time the plain-PyTorch restatement on the GPU")
     return ap.parse_args()
 
 
 def clip_per_parameter_(params, max_norm=1.0):
-    """clip_gradient (lib/utils/net_utils.py:174-184): each parameter tensor's L2 norm clipped separately."""
+    """clip_gradient (lib/utils/net_utils.py:174-184) with torch multi-tensor ops (--torch-optim)."""
     grads = [p.grad for p in params if p.grad is not None]
-    coefs = torch._foreach_norm(grads)                 # 5 multi-tensor launches instead of ~170 scalar ones
+    coefs = torch._foreach_norm(grads)
     torch._foreach_add_(coefs, 1e-6)
     torch._foreach_reciprocal_(coefs)
     torch._foreach_mul_(coefs, max_norm)
@@ -86,40 +98,50 @@ def main():
     torch.manual_seed(0)
     renderer = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(dev)
     params = list(renderer.parameters())
-    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.99), fused=True)
     lib = cn.load_library()
     assert lib.backend == "hip-gfx950"
+    if args.torch_optim:
+        opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.99), fused=True)
+    else:   # config/Color_NeuS_dtu.yml: adam, LR 5e-4, GRAD_CLIP NORM 1.0 TYPE 2 per parameter tensor
+        opt = cn.ClipAdam(renderer._ordered_params(), lr=5e-4, betas=(0.9, 0.99), eps=1e-8, max_norm=1.0, library=lib)
 
-    R = args.rays
+    if args.scaling == "strong":
+        if args.rays_total % world:
+            raise SystemExit("--rays-total must be divisible by the number of ranks")
+        R = args.rays_total // world
+    else:
+        R = args.rays
     M = cfg.n_total
     o_all, d_all, near_all, far_all, rgb_all, mask_all = synthetic.synthetic_view(seed=1 + rank, device=dev)
     n_all = o_all.shape[0]
     perm = torch.randperm(n_all, generator=torch.Generator().manual_seed(7)).to(dev)
-    Rg = R * world
 
-    def batch(i):
-        idx = perm[(i * R) % (n_all - R):(i * R) % (n_all - R) + R]
+    def batch(i, r):
+        idx = perm[(i * r) % (n_all - r):(i * r) % (n_all - r) + r]
         return o_all[idx], d_all[idx], near_all[idx], far_all[idx], rgb_all[idx], mask_all[idx]
 
     torch.manual_seed(2)   # jitter stream (CPU generator, like the reference)
 
-    def step(i):
-        o, d, near, far, gt, mask = batch(i)
+    def step(i, r=None):
+        r = R if r is None else r
+        rg = r * world
+        o, d, near, far, gt, mask = batch(i, r)
         out = renderer(o, d, near, far)
         if args.torch_loss:    # the torch restatement of compute_loss (and its sharded counterpart)
             if world == 1:
                 loss, _ = cn.compute_loss(out, gt, mask)
             else:
-                loss, _ = parallel.sharded_loss(out, gt, mask, n_rays_global=Rg, n_samples=M)
+                loss, _ = parallel.sharded_loss(out, gt, mask, n_rays_global=rg, n_samples=M)
         else:                  # loss kernels of the render library; ray-sharded runs all-reduce 5 floats between their two phases
-            loss, _ = cn.compute_loss_fused(out, gt, mask, n_rays_global=Rg if world > 1 else None, library=lib)
+            loss, _ = cn.compute_loss_fused(out, gt, mask, n_rays_global=rg if world > 1 else None, library=lib)
         for p in params:
             p.grad = None
         loss.backward()
         if world > 1:
-            parallel.allreduce_gradients(params)
+            parallel.allreduce_gradients(params)   # one in-place RCCL all-reduce of the flat gradient bucket
         if not args.no_optim:
-            clip_per_parameter_(params)
+            if args.torch_optim:
+                clip_per_parameter_(params)
             opt.step()
         return loss
 
@@ -129,32 +151,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    def timed(nsteps, warmup, r=None):
+        for i in range(warmup):
+            step(i, r)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            loss = step(warmup + i, r)
+        sync()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), loss
+
+    dt, loss = timed(args.steps, args.warmup)
+    Rg = R * world
     ms_per_step = dt / args.steps * 1e3
     value = Rg * args.steps / dt
 
+    optim_name = "" if args.no_optim else ("+torch-clip+torch-adam" if args.torch_optim else "+fused-clip-adam")
     result = {
         "metric": "rays/sec (fwd+bwd) at 128 samples/ray", "value": round(value, 1), "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "dtype_note": "fp32 tensors and fp32 accumulation; matrix products through error-free f16 hi/lo splits of the fp32 operands "
                       "(3 MFMAs per product, exact power-of-two scaling), parity gate 1e-4 relative",
         "data": "synthetic",
         "config": {"workload": "Color_NeuS_dtu.yml renderer block (SDF 8x256 + colour 4x256 + relight 4x256), synthetic 800x800 "
                                "view, %d rays/step/GPU x (64+64) samples, trained-like weights" % R,
-                   "rays_per_step_per_gpu": R, "samples_per_ray": M, "parallelism": "ray-sharded dp%d" % world,
-                   "step": "fwd+" + ("torch-loss" if args.torch_loss else "fused-loss") + "+bwd" + ("" if args.no_optim else "+clip+adam") + (("+rccl-allreduce" if backend == "nccl" else "+%s-allreduce" % backend) if world > 1 else ""),
+                   "rays_per_step_per_gpu": R, "rays_per_step_total": Rg, "samples_per_ray": M, "parallelism": "ray-sharded dp%d" % world,
+                   "step": "fwd+" + ("torch-loss" if args.torch_loss else "fused-loss") + "+bwd" + optim_name +
+                           (("+rccl-allreduce" if backend == "nccl" else "+%s-allreduce" % backend) if world > 1 else ""),
                    "final_loss": float(loss.detach())},
     }
 
@@ -186,42 +214,66 @@ def main():
                 "dw_gemm": "dw_gemm_kernel (FP32 MFMA weight-gradient GEMM, output-stationary)"}.get(dom_name, dom_name)
         gbs = dom[3] / (dom[0] * 1e-3) / 1e9
         tfl = dom[1] / (dom[0] * 1e-3) / 1e12
-        if dom_name == "dw_gemm":
-            roof = {"bound": "mfma", "achieved": round(tfl, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tfl / FP32_MFMA_PEAK_TFLOPS, 4)}
-        else:
-            # every layer launch streams its operand matrices once (1-4 KB per point in, 1-2 KB out) against 131 kFLOP per
-            # point: at the f16x3 matrix rate (~830 TFLOP/s fp32-equivalent) the launch is bound by HBM, not by the MFMA pipe
-            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "fp32_equiv_tflops": round(tfl, 2)}
+        f16_tfl = 3.0 * tfl if dom_name in SPLIT_F16_KERNELS else None
+        # Every layer launch streams its operand matrices once (1-4 KB per point in, 1-2 KB out) against 131 kFLOP per point: the
+        # launch is bound by HBM bytes, not by the matrix pipe -- both fractions are reported so that the claim can be checked.
+        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                "mfma_frac": round(f16_tfl / F16_MFMA_PEAK_TFLOPS, 4) if f16_tfl else round(tfl / FP32_MFMA_PEAK_TFLOPS, 4),
+                "mfma_achieved_tflops": round(f16_tfl, 1) if f16_tfl else round(tfl, 1),
+                "mfma_peak_tflops": F16_MFMA_PEAK_TFLOPS if f16_tfl else FP32_MFMA_PEAK_TFLOPS,
+                "mfma_note": "f16 MFMA FLOP/s actually issued (3 per fp32-equivalent product) against the 2.5 PFLOP/s dense f16 peak" if f16_tfl
+                             else "FP32 MFMA FLOP/s against the FP32 matrix peak",
+                "fp32_equiv_tflops": round(tfl, 2)}
         # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed summary
         # of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py)
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_%drays.json" % R)
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile))["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+        traffic, tfile = None, None
+        for rnd in ("r02", "r01"):
+            cand = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic_%drays.json" % (rnd, R))
+            if os.path.exists(cand):
+                t = json.load(open(cand))["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+                if t:
+                    traffic, tfile = t, cand
+                    break
         roof.update({"kernel": desc, "traffic": traffic, "traffic_source": os.path.relpath(tfile, ROOT) if traffic else None, "avg_launch_ms": round(dom[0] / dom[2], 4),
                      "algorithmic_bytes_per_launch": round(dom[3] / dom[2]), "launches_per_step": dom[2] // nrep,
                      "share_of_kernel_time": round(dom[0] / tot_ms, 3)})
         result["roofline"] = roof
-        top = sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]
-        result["kernel_breakdown"] = [{"kernel": k, "ms_per_step": round(v[0] / nrep, 3),
+        always = ("upsample", "merge", "composite_fwd", "composite_bwd", "chain_sdf_value", "clip_adam")   # north_star evidence: sampler / compositor GB/s
+        top = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        keep = [kv for i, kv in enumerate(top) if i < 8 or kv[0] in always]
+        result["kernel_breakdown"] = [{"kernel": k, "ms_per_step": round(v[0] / nrep, 4),
                                        "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[1] else None,
-                                       "gbs": round(v[3] / (v[0] * 1e-3) / 1e9, 1) if v[3] else None, "launches": v[2] // nrep}
-                                      for k, v in top]
+                                       "gbs": round(v[3] / (v[0] * 1e-3) / 1e9, 1) if v[3] else None,
+                                       "hbm_frac": round(v[3] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[3] else None,
+                                       "launches": v[2] // nrep}
+                                      for k, v in keep]
         result["kernel_ms_per_step"] = round(tot_ms / nrep, 3)
+        result["launches_per_step"] = sum(v[2] for v in agg.values()) // nrep
 
-    # ---- optional: the plain-PyTorch restatement on the same GPU (the 'reference single-GPU PyTorch' stand-in)
-    if args.torch_gpu_baseline and rank == 0:
+    # ---- the same step at the reference's own batch (N_RAYS 1024, config/Color_NeuS_dtu.yml:13) and at C4's per-GPU share (512)
+    if not args.no_small_batch:
+        small = {}
+        for r in (512, 1024):
+            if r == R:
+                small[str(r)] = round(value, 1)
+                continue
+            n = max(20, min(args.steps, 60))
+            dts, _ = timed(n, 5, r)
+            small[str(r)] = round(r * world * n / dts, 1)
+        result["small_batch"] = {"unit": "rays/s", "rays_per_step_per_gpu": small}
+
+    # ---- the plain-PyTorch restatement on the same GPU (the 'reference single-GPU PyTorch' stand-in), bounded sample
+    if not args.no_torch_gpu_baseline and rank == 0:
         from oracle import colorneus_oracle as O
         ocfg = O.dtu_config()
         P = {k: v.detach().clone().requires_grad_(True) for k, v in renderer.state_dict().items()}
-        Rt = min(R, 1024)
-        o, d, near, far, gt, mask = [x[:Rt] for x in batch(0)]
+        Rt = 1024   # the reference's N_RAYS
+        o, d, near, far, gt, mask = [x[:Rt] for x in batch(0, max(R, Rt))]
 
         def tstep():
             t_rand = torch.rand(Rt, 1).to(dev)
-            out = O.render(P, ocfg, o, d, near, far, t_rand=t_rand)
+            out = O.render(P, ocfg, o, d, near, far, t_rand=t_rand, reference_ops=True)
             l, _ = O.compute_loss(out, gt, mask)
             for p in P.values():
                 p.grad = None
@@ -230,40 +282,55 @@ def main():
             tstep()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        nt_ = 5
+        nt_ = 6
         for _ in range(nt_):
             tstep()
         torch.cuda.synchronize(dev)
-        result["torch_gpu_baseline"] = {"value": round(Rt * nt_ / (time.perf_counter() - t1), 1), "unit": "rays/s",
-                                        "sample": "%d rays x 128 samples, plain PyTorch-ROCm ops (oracle restatement), fwd+bwd" % Rt}
+        tv = Rt * nt_ / (time.perf_counter() - t1)
+        result["torch_gpu_baseline"] = {"value": round(tv, 1), "unit": "rays/s",
+                                        "sample": "%d iterations of %d rays x 128 samples, plain PyTorch-ROCm ops, the oracle restatement in its reference_ops mode "
+                                                  "(normals by a second SDF forward + autograd.grad(create_graph=True) like fields.py:105-115), fwd+bwd, no optimiser" % (nt_, Rt),
+                                        "speedup_at_4096": round(value / world / tv, 2) if R == 4096 else None,
+                                        "speedup_at_equal_batch": round(result.get("small_batch", {}).get("rays_per_step_per_gpu", {}).get("1024", 0.0) / world / tv, 2)
+                                        if not args.no_small_batch else None}
 
-    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
+    # ---- CPU baseline: the oracle on the host cores, bounded samples (rank 0, N=1 only)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         from oracle import colorneus_oracle as O
         ocfg = O.dtu_config()
-        cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        torch.set_num_threads(cores)
         P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in renderer.state_dict().items()}
-        Rc = args.cpu_rays
-        o, d, near, far, gt, mask = [x[:Rc].cpu() for x in batch(0)]
+        ncpu = os.cpu_count() or 1
 
-        def cstep():
-            t_rand = torch.rand(Rc, 1)
-            out = O.render(P, ocfg, o, d, near, far, t_rand=t_rand)
-            l, _ = O.compute_loss(out, gt, mask)
-            for p in P.values():
-                p.grad = None
-            l.backward()
-        cstep()
-        t1 = time.perf_counter()
-        n_it = 0
-        while n_it < 3 or (time.perf_counter() - t1 < 12.0 and n_it < 40):
+        def cpu_rate(threads, rays, budget_s, min_it):
+            torch.set_num_threads(threads)
+            o, d, near, far, gt, mask = [x[:rays].cpu() for x in batch(0, max(R, rays))]
+
+            def cstep():
+                t_rand = torch.rand(rays, 1)
+                out = O.render(P, ocfg, o, d, near, far, t_rand=t_rand, reference_ops=True)
+                l, _ = O.compute_loss(out, gt, mask)
+                for p in P.values():
+                    p.grad = None
+                l.backward()
             cstep()
-            n_it += 1
-        cdt = time.perf_counter() - t1
-        result["cpu_baseline"] = {"value": round(Rc * n_it / cdt, 2), "unit": "rays/s", "cores": cores, "kind": "port",
+            t1 = time.perf_counter()
+            n_it = 0
+            while n_it < min_it or (time.perf_counter() - t1 < budget_s and n_it < 40):
+                cstep()
+                n_it += 1
+            return rays * n_it / (time.perf_counter() - t1), n_it
+
+        cores = max(1, min(args.cpu_threads, ncpu))
+        v, n_it = cpu_rate(cores, args.cpu_rays, 10.0, 3)
+        result["cpu_baseline"] = {"value": round(v, 2), "unit": "rays/s", "cores": cores, "kind": "port",
                                   "sample": "%d iterations of %d rays x (64+64) samples, fwd+bwd, same network/weights, "
-                                            "torch CPU ops with %d threads (host has %d logical CPUs)" % (n_it, Rc, cores, os.cpu_count() or 0)}
+                                            "torch CPU ops with %d threads (host has %d logical CPUs)" % (n_it, args.cpu_rays, cores, ncpu)}
+        v1, n1 = cpu_rate(1, 32, 8.0, 1)
+        result["cpu_baseline_1thread"] = {"value": round(v1, 2), "unit": "rays/s", "cores": 1, "kind": "port",
+                                          "sample": "%d iterations of 32 rays x (64+64) samples, one thread (the reference pins OMP/MKL to 1, train.py:4-8)" % n1}
+        va, na = cpu_rate(ncpu, 64, 0.0, 1)   # (oversubscribed torch CPU ops are slow: one small iteration bounds the run)
+        result["cpu_baseline_allcores"] = {"value": round(va, 2), "unit": "rays/s", "cores": ncpu, "kind": "port",
+                                           "sample": "%d iteration of 64 rays x (64+64) samples, torch threads = all %d logical CPUs" % (na, ncpu)}
 
     if rank == 0:
         print(json.dumps(result))

@@ -49,6 +49,11 @@ class CnrLossConfig(C.Structure):
                 ("rgb_l1", C.c_int32), ("include_mask", C.c_int32)]
 
 
+class CnrAdamConfig(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_norm", C.c_float),
+                ("step", C.c_int32)]
+
+
 class CnrInGrads(C.Structure):
     _fields_ = [("d_params", C.POINTER(_FP)), ("d_rays_o", _FP), ("d_rays_d", _FP), ("d_near", _FP), ("d_far", _FP)]
 
@@ -75,7 +80,7 @@ EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_c
            "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
            "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_grads",
-           "cnr_sample_pdf", "cnr_up_sample"]
+           "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes"]
 
 
 class RenderLibrary:
@@ -111,6 +116,10 @@ class RenderLibrary:
         L.cnr_loss_grads.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, _FP]
         L.cnr_sample_pdf.argtypes = [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, _FP]
         L.cnr_up_sample.argtypes = [_FP, _FP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_float, _FP, _FP]
+        L.cnr_clip_adam_step.argtypes = [C.POINTER(CnrAdamConfig), C.c_int32, C.POINTER(C.c_int64), C.POINTER(_FP), C.POINTER(_FP), _FP, _FP, _FP,
+                                         C.c_size_t, _FP]
+        L.cnr_clip_adam_scratch_bytes.restype = C.c_size_t
+        L.cnr_clip_adam_scratch_bytes.argtypes = [C.c_int32, C.POINTER(C.c_int64)]
         L.cnr_timing_enable.argtypes = [C.c_int]
         L.cnr_timing_enable.restype = None
         L.cnr_timing_collect.argtypes = [C.POINTER(CnrKernelTiming), C.c_int]

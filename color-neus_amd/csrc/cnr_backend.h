@@ -217,6 +217,32 @@ struct LossArgs {
 constexpr int kLossBlocks = 256;
 void be_loss_sums(const LossArgs& a, float* partial /* [kLossBlocks][4] */, float* sums /* [4] */, cnr_stream s);
 void be_loss_grads(const LossArgs& a, const float* coef, float* d_color, float* d_wsum, float* d_drel, cnr_stream s);
+// per-parameter gradient clip + Adam over up to kAdamBatch tensors per launch (clip_gradient + torch.optim.Adam, net_utils.py:174-184, :88)
+constexpr int kAdamBatch = 64;
+constexpr int kAdamChunk = 4096;   // elements per workgroup: a tensor is cut into ceil(n / kAdamChunk) chunks
+struct AdamTensor { float* w; const float* g; long off; long n; int chunk0; };   // off: offset of this tensor's moments in the flat m / v buffers; chunk0: its first chunk
+struct AdamArgs {
+  int count; AdamTensor t[kAdamBatch];
+  int nchunks; float* partial;         // [nchunks] per-chunk sums of squared gradient entries (scratch)
+  float* m; float* v;                  // flat exp_avg / exp_avg_sq
+  float lr, beta1, beta2, eps, max_norm;   // max_norm <= 0: no clipping
+  float bc1, bc2_sqrt;                 // 1 - beta1^step, sqrt(1 - beta2^step)
+};
+// one tensor's update; norm2 = the tensor's sum of squared gradient entries (fixed-order reduction by the caller)
+CNR_HD float adam_clip_coef(float norm2, float max_norm) {
+  if (!(max_norm > 0.0f)) return 1.0f;
+  const float c = max_norm / (sqrtf(norm2) + 1e-6f);    // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+  return c < 1.0f ? c : 1.0f;
+}
+CNR_HD void adam_update1(const AdamArgs& a, float* w, float g, float* m, float* v) {
+  const float m1 = *m + (g - *m) * (1.0f - a.beta1);               // exp_avg.lerp_(grad, 1 - beta1)
+  const float v1 = *v * a.beta2 + (1.0f - a.beta2) * g * g;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+  *m = m1; *v = v1;
+  const float denom = sqrtf(v1) / a.bc2_sqrt + a.eps;
+  *w = *w - (a.lr / a.bc1) * (m1 / denom);                         // param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
+}
+void be_clip_adam(const AdamArgs& a, cnr_stream s);   // a.partial must hold a.nchunks floats
+
 // p[row][c] = 0 for c in [c0, c1), row < rows: zero the pad columns a GEMM reads without touching the rest of a wide buffer
 void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream s);
 void be_grid_points(float* pts /*unused*/, cnr_stream s);

@@ -669,7 +669,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const UpSample p) {
   }
 }
 void be_upsample(const UpSample& p, cnr_stream s) {
-  TimingScope ts_("upsample", 2, 0, p.R, 0, 0, 0, s);
+  // algorithmic bytes per ray: z and sdf (or the given weights) in, o / d, the new positions out
+  TimingScope ts_("upsample", 2, 0, p.R, 0, 0, 0, s, (double)p.R * (4.0 * p.n + 4.0 * (p.w_in ? p.n - 1 : p.n) + (p.w_in ? 0.0 : 24.0) + 4.0 * p.m));
   hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("upsample");
 }
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeZ p) {
   }
 }
 void be_merge(const MergeZ& p, cnr_stream s) {
-  TimingScope ts_("merge", 2, 0, p.R, 0, 0, 0, s);
+  TimingScope ts_("merge", 2, 0, p.R, 0, 0, 0, s, (double)p.R * (p.new_sdf ? 2.0 : 1.0) * (4.0 * p.n + 4.0 * p.m + 4.0 * (p.n + p.m)));
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("merge");
 }
@@ -797,7 +798,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeFwd p
   }
 }
 void be_composite_fwd(const CompositeFwd& p, cnr_stream s) {
-  TimingScope ts_("composite_fwd", 2, 0, p.R, 0, 0, 0, s);
+  // algorithmic bytes per ray: z, sdf, gradients, colour(s) in; cdf, weights, inside_sphere and the per-ray outputs out
+  TimingScope ts_("composite_fwd", 2, 0, p.R, 0, 0, 0, s,
+                  (double)p.R * ((4.0 + 4.0 + 12.0 + 12.0 + (p.gcolor ? 12.0 : 0.0)) * p.M + 24.0 + 12.0 * p.M + 52.0));
   hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("composite_fwd");
 }
@@ -937,7 +940,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
   }
 }
 void be_composite_bwd(const CompositeBwd& p, cnr_stream s) {
-  TimingScope ts_("composite_bwd", 2, 0, p.R, 0, 0, 0, s);
+  // algorithmic bytes per ray: the forward inputs again, the upstream gradients, and per sample d sdf (4), d g (12), the colour /
+  // relight cotangents (12 + 12) -- the buffers themselves are padded to the 16-float rows the narrow GEMMs read
+  TimingScope ts_("composite_bwd", 2, 0, p.R, 0, 0, 0, s,
+                  (double)p.R * ((4.0 + 4.0 + 12.0 + 12.0 + (p.gcolor ? 12.0 : 0.0)) * p.M + 24.0 + (p.d_delta_relight ? 12.0 * p.M : 0.0) + 32.0 +
+                                 (4.0 + 12.0 + 12.0 + (p.has_relight ? 12.0 : 0.0)) * p.M + 16.0));
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("composite_bwd");
 }
@@ -1108,6 +1115,50 @@ void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s) {
   TimingScope ts_("rays_grad_finish", 2, 0, p.R, 0, 0, 0, s);
   hipLaunchKernelGGL(rays_grad_finish_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);
   CNR_LAUNCH_CHECK("rays_grad_finish");
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-parameter clip + Adam (53 tensors, 1 M floats): two launches over 4096-element chunks instead of ~150 torch launches.
+//   1. per-chunk sum of squared gradient entries (fixed order inside a chunk);
+//   2. every chunk's workgroup folds its OWN tensor's chunk sums in chunk order (<= 17 values) -> clip coefficient -> Adam update.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int adam_find_tensor(const AdamArgs& a, int chunk) {
+  int k = 0;
+  while (k + 1 < a.count && chunk >= a.t[k + 1].chunk0) ++k;
+  return k;
+}
+__global__ __launch_bounds__(256) void clip_norm_kernel(const AdamArgs a) {
+  __shared__ float red[4];
+  const int chunk = blockIdx.x;
+  const AdamTensor t = a.t[adam_find_tensor(a, chunk)];
+  const long i0 = (long)(chunk - t.chunk0) * kAdamChunk;
+  float ss = 0.0f;
+  for (int j = threadIdx.x; j < kAdamChunk; j += 256) { const long i = i0 + j; if (i < t.n) { const float g = t.g[i]; ss += g * g; } }
+  ss = block_sum_256(ss, red);
+  if (threadIdx.x == 0) a.partial[chunk] = ss;
+}
+__global__ __launch_bounds__(256) void clip_adam_kernel(const AdamArgs a) {
+  const int chunk = blockIdx.x;
+  const AdamTensor t = a.t[adam_find_tensor(a, chunk)];
+  float coef = 1.0f;
+  if (a.max_norm > 0.0f) {
+    const int nch = (int)((t.n + kAdamChunk - 1) / kAdamChunk);
+    float tot = 0.0f;
+    for (int c = 0; c < nch; ++c) tot += a.partial[t.chunk0 + c];   // fixed order, the same in every workgroup of the tensor
+    coef = adam_clip_coef(tot, a.max_norm);
+  }
+  const long i0 = (long)(chunk - t.chunk0) * kAdamChunk;
+  for (int j = threadIdx.x; j < kAdamChunk; j += 256) {
+    const long i = i0 + j;
+    if (i < t.n) adam_update1(a, t.w + i, t.g[i] * coef, a.m + t.off + i, a.v + t.off + i);
+  }
+}
+void be_clip_adam(const AdamArgs& a, cnr_stream s) {
+  if (a.count <= 0 || a.nchunks <= 0) return;
+  TimingScope ts_("clip_adam", 2, 0, a.count, 0, 0, 0, s);
+  if (a.max_norm > 0.0f) hipLaunchKernelGGL(clip_norm_kernel, dim3(a.nchunks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(a.nchunks), dim3(256), 0, s, a);
+  CNR_LAUNCH_CHECK("clip_adam");
 }
 
 void be_grid_points(float*, cnr_stream) {}

@@ -190,6 +190,23 @@ void be_variance_finish(const VarianceFinish& p, cnr_stream) {
   *p.d_variance = (raw >= 1e-6f && raw <= 1e6f) ? a * 10.0f * raw : 0.0f;
 }
 
+void be_clip_adam(const AdamArgs& a, cnr_stream) {
+  for (int k = 0; k < a.count; ++k) {
+    const AdamTensor& t = a.t[k];
+    float coef = 1.0f;
+    if (a.max_norm > 0.0f) {
+      float tot = 0.0f;   // chunk sums in chunk order, like the HIP kernels (the order inside a chunk differs: plain loop here)
+      for (long c0 = 0; c0 < t.n; c0 += kAdamChunk) {
+        float ss = 0.0f;
+        for (long i = c0; i < t.n && i < c0 + kAdamChunk; ++i) ss += t.g[i] * t.g[i];
+        tot += ss;
+      }
+      coef = adam_clip_coef(tot, a.max_norm);
+    }
+    for (long i = 0; i < t.n; ++i) adam_update1(a, t.w + i, t.g[i] * coef, a.m + t.off + i, a.v + t.off + i);
+  }
+}
+
 // the CPU emulation has no chain-fused kernels: the host orchestration falls back to the per-layer sequence
 void be_pack_frags_many(const PackJob*, int, cnr_stream) {}
 bool be_sdf_value_chain(const SdfValueChain&, cnr_stream) { return false; }

@@ -10,6 +10,7 @@
 //
 // This file contains no arithmetic on tensor data: it only sizes buffers, builds kernel descriptors and enqueues
 // kernels through cnr_backend.h.  It is shared verbatim by the HIP build and the CPU-emulation build (tests only).
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -1064,6 +1065,41 @@ int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const fl
   if (d_weight_sum && mask && !weight_sum) return fail("weight_sum is required with a mask");
   be_loss_grads(a, coef, d_color_fine, d_weight_sum, d_delta_relight, (cnr_stream)stream);
   return check_backend("loss_grads");
+}
+
+size_t cnr_clip_adam_scratch_bytes(int32_t n_tensors, const int64_t* sizes) {
+  if (!sizes || n_tensors <= 0) return 0;
+  size_t chunks = 0;
+  for (int i = 0; i < n_tensors; ++i) chunks += (size_t)((sizes[i] > 0 ? sizes[i] : 0) + kAdamChunk - 1) / kAdamChunk;
+  return (chunks + 1) * sizeof(float);
+}
+
+int cnr_clip_adam_step(const cnr_adam_config* cfg, int32_t n_tensors, const int64_t* sizes, float* const* params, const float* const* grads,
+                       float* exp_avg, float* exp_avg_sq, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!cfg || !sizes || !params || !grads || !exp_avg || !exp_avg_sq || !scratch) return fail("null argument");
+  if (n_tensors <= 0) return fail("n_tensors must be positive");
+  if (cfg->step < 1) return fail("step is 1-based");
+  if (scratch_bytes < cnr_clip_adam_scratch_bytes(n_tensors, sizes)) return fail("clip_adam scratch too small");
+  AdamArgs a;
+  a.m = exp_avg; a.v = exp_avg_sq;
+  a.lr = cfg->lr; a.beta1 = cfg->beta1; a.beta2 = cfg->beta2; a.eps = cfg->eps; a.max_norm = cfg->max_norm;
+  a.bc1 = (float)(1.0 - pow((double)cfg->beta1, (double)cfg->step));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)cfg->beta2, (double)cfg->step));
+  long off = 0;
+  float* part = static_cast<float*>(scratch);
+  a.count = 0; a.nchunks = 0; a.partial = part;
+  for (int i = 0; i < n_tensors; ++i) {
+    if (sizes[i] < 0 || !params[i] || !grads[i]) return fail("tensor %d: null pointer or negative size", i);
+    a.t[a.count++] = AdamTensor{params[i], grads[i], off, (long)sizes[i], a.nchunks};
+    a.nchunks += (int)((sizes[i] + kAdamChunk - 1) / kAdamChunk);
+    off += sizes[i];
+    if (a.count == kAdamBatch || i + 1 == n_tensors) {
+      be_clip_adam(a, (cnr_stream)stream);
+      part += a.nchunks;
+      a.count = 0; a.nchunks = 0; a.partial = part;
+    }
+  }
+  return check_backend("clip_adam_step");
 }
 
 int cnr_timing_collect(cnr_kernel_timing* out, int max_records) {

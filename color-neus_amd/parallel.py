@@ -72,10 +72,19 @@ def sharded_loss(out, rgb_gt, mask, n_rays_global, n_samples, group=None, lambda
 
 def allreduce_gradients(params, group=None):
     """One flat-bucket all-reduce(sum) over all parameter gradients.  The local losses are already
-    normalised by global counts, so SUM (not mean) reproduces the single-GPU gradient."""
+    normalised by global counts, so SUM (not mean) reproduces the single-GPU gradient.
+
+    The renderer's backward lays the gradients out in one flat buffer (renderer._RenderFunction.backward), so the collective runs on
+    that buffer in place; gradients that do not tile one buffer (a model with extra parameters) fall back to a gathered copy."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
+    from .optim import flat_view_of_grads
+    with_grad = [p for p in params if p.grad is not None]
+    flat = flat_view_of_grads(with_grad)
+    if flat is not None:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return
+    grads = [p.grad for p in with_grad]
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0

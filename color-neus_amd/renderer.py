@@ -101,7 +101,13 @@ class _RenderFunction(torch.autograd.Function):
         for k, g in zip(names, gouts[:len(names)]):
             gmap[k] = g.contiguous().float() if g is not None else None
         cg = _lib.CnrOutGrads(**{k: _ptr(gmap.get(k)) for k in _lib.OUT_GRAD_FIELDS})
-        dparams = [torch.empty_like(p) for p in plist]
+        # every parameter gradient is a view into ONE flat buffer (canonical parameter order): a ray-sharded run all-reduces it as is and
+        # the fused optimiser step (optim.ClipAdam) streams it -- no torch.cat, no copy back
+        flat = torch.empty(sum(p.numel() for p in plist), dtype=torch.float32, device=rays_o.device)
+        dparams, off = [], 0
+        for p in plist:
+            dparams.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
         darr = (C.c_void_p * len(dparams))(*[p.data_ptr() for p in dparams])
         d_o = torch.empty_like(rays_o) if ctx.rays_need_grad else None
         d_d = torch.empty_like(rays_d) if ctx.rays_need_grad else None
@@ -121,7 +127,11 @@ class _RenderFunction(torch.autograd.Function):
         lib.check(rc, "cnr_render_backward")
         if d_near is not None:
             d_near, d_far = d_near.reshape(ctx.nearfar_shapes[0]), d_far.reshape(ctx.nearfar_shapes[1])
-        return (None, d_o, d_d, d_near, d_far, None, None, None, None, None) + tuple(dparams)
+        # hand the views over without keeping a second reference: autograd then installs them as p.grad as they are (it clones a
+        # gradient that something else still references), so p.grad aliases the flat buffer
+        res = (None, d_o, d_d, d_near, d_far, None, None, None, None, None) + tuple(dparams)
+        del dparams, flat
+        return res
 
 
 def sample_pdf(bins, weights, n_samples, det=True, library=None):

@@ -125,6 +125,20 @@ int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const fl
                    int64_t n_rays, int32_t n_samples, const float* coef /* device [4] */, float* d_color_fine, float* d_weight_sum,
                    float* d_delta_relight /* or NULL */, void* stream);
 
+/* ---- optimiser step of the training loop (the consumer after loss.backward(), train.py:72-77): per-parameter gradient clipping
+ * (clip_gradient -> torch.nn.utils.clip_grad_norm_ on EACH parameter tensor, lib/utils/net_utils.py:174-184) followed by
+ * torch.optim.Adam (net_utils.py:88: betas (0.9, 0.99), eps 1e-8, no weight decay) in ONE launch over all tensors.
+ * params / grads: host arrays of n_tensors device pointers, sizes: host array of element counts; exp_avg / exp_avg_sq: device, flat,
+ * sum(sizes) floats each, tensor i at offset sum(sizes[0..i)); step is 1-based; max_norm <= 0 disables the clip.
+ * scratch: device, cnr_clip_adam_scratch_bytes(n_tensors, sizes) bytes (per-chunk partial sums of the gradient norms). */
+typedef struct cnr_adam_config {
+  float lr, beta1, beta2, eps, max_norm;
+  int32_t step;
+} cnr_adam_config;
+size_t cnr_clip_adam_scratch_bytes(int32_t n_tensors, const int64_t* sizes);
+int cnr_clip_adam_step(const cnr_adam_config* cfg, int32_t n_tensors, const int64_t* sizes, float* const* params, const float* const* grads,
+                       float* exp_avg, float* exp_avg_sq, void* scratch, size_t scratch_bytes, void* stream);
+
 int cnr_abi_version(void);
 const char* cnr_backend_name(void);
 const char* cnr_last_error(void);

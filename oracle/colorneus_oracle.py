@@ -449,14 +449,30 @@ def sample_z(P, cfg: RenderConfig, rays_o, rays_d, near, far, t_rand=None):
 # --------------------------------------------------------------------------------------
 # render core + full forward           (Color_NeuS.py:24-138, NeuS.py:199-292, 294-408)
 # --------------------------------------------------------------------------------------
-def render_core(P, cfg: RenderConfig, rays_o, rays_d, z, cos_anneal_ratio=0.0, background_rgb=None):
+def sdf_gradient_autograd(P, cfg: SDFConfig, x):
+    """SDFNetwork.gradient exactly as the reference executes it (fields.py:105-115): a SECOND forward of the SDF network on x with
+    requires_grad and torch.autograd.grad(create_graph=True) through it -- the double-backward graph the reference trains through.
+    Same value as the analytic reverse sweep of sdf_forward(want_grad=True); used where the reference's executed WORK is to be timed."""
+    with torch.enable_grad():
+        xg = x.detach().requires_grad_(True) if not x.requires_grad else x
+        y = sdf_forward(P, cfg, xg)[0]
+        g = torch.autograd.grad(outputs=y, inputs=xg, grad_outputs=torch.ones_like(y), create_graph=True, retain_graph=True,
+                                only_inputs=True)[0]
+    return g
+
+
+def render_core(P, cfg: RenderConfig, rays_o, rays_d, z, cos_anneal_ratio=0.0, background_rgb=None, reference_ops=False):
     R, M = z.shape
     sample_dist = 2.0 / cfg.n_samples
     dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], sample_dist)], -1)
     mid = z + dists * 0.5
     pts = (rays_o[:, None, :] + rays_d[:, None, :] * mid[..., None]).reshape(-1, 3)
     dirs = rays_d[:, None, :].expand(R, M, 3).reshape(-1, 3)
-    sdf, feat, g = sdf_forward(P, cfg.sdf, pts, want_grad=True)
+    if reference_ops:   # op for op what the reference runs: forward for (sdf, features), second forward + autograd.grad for the normals
+        sdf, feat, _ = sdf_forward(P, cfg.sdf, pts)
+        g = sdf_gradient_autograd(P, cfg.sdf, pts)
+    else:
+        sdf, feat, g = sdf_forward(P, cfg.sdf, pts, want_grad=True)
     out = {}
     if cfg.type == "Color_NeuS":
         gcol = color_forward(P, cfg.color, pts, g, dirs, feat)
@@ -491,13 +507,13 @@ def render_core(P, cfg: RenderConfig, rays_o, rays_d, z, cos_anneal_ratio=0.0, b
 
 
 def render(P, cfg: RenderConfig, rays_o, rays_d, near, far, t_rand=None, cos_anneal_ratio=0.0,
-           background_rgb=None, z_vals=None):
+           background_rgb=None, z_vals=None, reference_ops=False):
     """Full forward.  t_rand (R,1) is the uniform draw the reference takes from torch.rand([R,1]) on the CPU
     generator (NeuS.py:325); None means perturb == 0.  z_vals overrides the sampler (parity gate G2)."""
     if cfg.n_outside > 0:
         raise NotImplementedError("N_OUTSIDE > 0 (NeRF++ background) is outside the hot path")
     z = sample_z(P, cfg, rays_o, rays_d, near, far, t_rand) if z_vals is None else z_vals
-    out = render_core(P, cfg, rays_o, rays_d, z, cos_anneal_ratio, background_rgb)
+    out = render_core(P, cfg, rays_o, rays_d, z, cos_anneal_ratio, background_rgb, reference_ops=reference_ops)
     out["z_vals"] = z
     return out
 

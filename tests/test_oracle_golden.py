@@ -143,3 +143,20 @@ def test_g3_end_to_end_init_regime(name):
     for k in ("color_fine", "depth", "weight_sum", "gradient_error"):
         assert G.relerr(out[k].detach(), fx[f"jit:out_{k}"]) < TOL, k
     assert abs(float(loss.detach()) - float(fx["jit:loss"])) < TOL * abs(float(fx["jit:loss"]))
+
+
+def test_reference_ops_mode_matches_golden():
+    """reference_ops=True (second SDF forward + autograd.grad(create_graph=True), the reference's executed work -- what the
+    bench baselines time) gives the golden outputs and parameter gradients like the analytic sweep does."""
+    fx = G.load("tiny_sharp")
+    ocfg, P = G.weights_of("tiny_sharp", fx)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    t = lambda k: torch.from_numpy(fx[k])
+    out = O.render(P, ocfg, t("rays_o"), t("rays_d"), t("jit:near"), t("jit:far"), z_vals=t("jit:z_vals"), reference_ops=True)
+    for k in ("color_fine", "gradients", "weights", "delta_relight", "gradient_error"):
+        assert G.relerr(out[k].detach().reshape(fx[f"jit:out_{k}"].shape), fx[f"jit:out_{k}"]) < 1e-4, k
+    loss, _ = O.compute_loss(out, t("rgb_gt"), t("mask"))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(fx["jit:loss"])) < 1e-6 * abs(float(fx["jit:loss"]))
+    bad = G.check_param_grads(fx, "jit", {k: v.grad for k, v in P.items()})
+    assert not bad, bad
