@@ -243,6 +243,28 @@ CNR_HD void adam_update1(const AdamArgs& a, float* w, float g, float* m, float* 
 }
 void be_clip_adam(const AdamArgs& a, cnr_stream s);   // a.partial must hold a.nchunks floats
 
+// ---- ray generation for the selected pixels (the producer right in front of the path): get_rays_multicam / get_rays_at
+// (lib/models/tools/ray_utils.py:16-119) with the trainer's origin / radius normalisation and near_far_from_sphere
+// (NeuS_Trainer.py:117-119, ray_utils.py:7-13) folded in, and its backward to the camera poses and the focal lengths
+struct GenRays {
+  const long* pix_idx; long n;          // flat index over (camera, row, column); null: pixel i of camera 0 (get_rays_at)
+  const float* c2w; int n_cams;         // [n_cams][4][4]
+  const float* focal;                   // [2] (device)
+  int H, W, normalize, opengl;
+  const float* image; const float* mask;    // [n_cams][H][W][3] / [n_cams][H][W] or null
+  const float* origin; float radius;        // rays_o = (rays_o - origin) / radius when origin != null
+  float* rays_o; float* rays_d; float* rgb; float* mask_sel; float* near_; float* far_;   // any of rgb / mask_sel / near_ / far_ may be null
+};
+struct GenRaysBwd {
+  GenRays f;                            // the forward arguments (outputs unused)
+  const float* d_rays_o; const float* d_rays_d; const float* d_near; const float* d_far;   // upstream gradients (d_near / d_far may be null)
+  float* d_c2w;                         // [n_cams][4][4] (bottom row zero)
+  float* d_focal_partial;               // [n_cams][2] per-camera contributions, folded in camera order into d_focal
+  float* d_focal;                       // [2]
+};
+void be_gen_rays(const GenRays& p, cnr_stream s);
+void be_gen_rays_bwd(const GenRaysBwd& p, cnr_stream s);
+
 // p[row][c] = 0 for c in [c0, c1), row < rows: zero the pad columns a GEMM reads without touching the rest of a wide buffer
 void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream s);
 void be_grid_points(float* pts /*unused*/, cnr_stream s);

@@ -170,4 +170,67 @@ CNR_HD void body_pbar_finish(const PbarFinish& p, long pt) {
   p.pbar[pt * 4 + 3] = 0.0f;
 }
 
+// one ray of GenRays
+CNR_HD void body_gen_rays(const GenRays& p, long i) {
+  const long hw = (long)p.H * p.W;
+  const long idx = p.pix_idx ? p.pix_idx[i] : i;
+  const int cam = (int)(idx / hw);
+  const long pix = idx - (long)cam * hw;
+  const int py = (int)(pix / p.W), px = (int)(pix - (long)py * p.W);
+  const RayGeom r = ray_geometry(p.c2w + (long)cam * 16, p.focal[0], p.focal[1], p.H, p.W, px, py, p.normalize, p.opengl);
+  float o[3];
+  for (int k = 0; k < 3; ++k) {
+    o[k] = p.origin ? (r.o[k] - p.origin[k]) / p.radius : r.o[k];
+    p.rays_o[i * 3 + k] = o[k];
+    p.rays_d[i * 3 + k] = r.d[k];
+  }
+  if (p.rgb) for (int k = 0; k < 3; ++k) p.rgb[i * 3 + k] = p.image[idx * 3 + k];
+  if (p.mask_sel) p.mask_sel[i] = p.mask[idx];
+  if (p.near_ && p.far_) {   // near_far_from_sphere (ray_utils.py:7-13)
+    const float a = r.d[0] * r.d[0] + r.d[1] * r.d[1] + r.d[2] * r.d[2];
+    const float b = 2.0f * (o[0] * r.d[0] + o[1] * r.d[1] + o[2] * r.d[2]);
+    const float mid = 0.5f * (-b) / a;
+    p.near_[i] = mid - 1.0f;
+    p.far_[i] = mid + 1.0f;
+  }
+}
+
+// gradient contributions of one ray: out[0..11] = d c2w[cam][k][0..3] (k = 0..2), out[12..13] = d focal
+CNR_HD void body_gen_rays_bwd1(const GenRaysBwd& q, long i, int* cam_out, float out[14]) {
+  const GenRays& p = q.f;
+  const long hw = (long)p.H * p.W;
+  const long idx = p.pix_idx ? p.pix_idx[i] : i;
+  const int cam = (int)(idx / hw);
+  const long pix = idx - (long)cam * hw;
+  const int py = (int)(pix / p.W), px = (int)(pix - (long)py * p.W);
+  const float* c2w = p.c2w + (long)cam * 16;
+  const float fx = p.focal[0], fy = p.focal[1];
+  const RayGeom r = ray_geometry(c2w, fx, fy, p.H, p.W, px, py, p.normalize, p.opengl);
+  float dO[3], dD[3];
+  for (int k = 0; k < 3; ++k) { dO[k] = q.d_rays_o ? q.d_rays_o[i * 3 + k] : 0.0f; dD[k] = q.d_rays_d ? q.d_rays_d[i * 3 + k] : 0.0f; }
+  if (q.d_near && q.d_far) {   // mid = -(o.d) / (d.d): d mid / d o = -d / a, d mid / d d = (-o - 2 mid d) / a
+    float o[3];
+    for (int k = 0; k < 3; ++k) o[k] = p.origin ? (r.o[k] - p.origin[k]) / p.radius : r.o[k];
+    const float a = r.d[0] * r.d[0] + r.d[1] * r.d[1] + r.d[2] * r.d[2];
+    const float mid = -(o[0] * r.d[0] + o[1] * r.d[1] + o[2] * r.d[2]) / a;
+    const float dm = q.d_near[i] + q.d_far[i];
+    for (int k = 0; k < 3; ++k) { dO[k] += dm * (-r.d[k] / a); dD[k] += dm * (-o[k] - 2.0f * mid * r.d[k]) / a; }
+  }
+  float ddirs[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < 3; ++k) {
+    for (int j = 0; j < 3; ++j) { out[k * 4 + j] = dD[k] * r.dirs[j]; ddirs[j] += dD[k] * c2w[k * 4 + j]; }
+    out[k * 4 + 3] = p.origin ? dO[k] / p.radius : dO[k];
+  }
+  float du[3];
+  if (p.normalize) {
+    const float dot = r.dirs[0] * ddirs[0] + r.dirs[1] * ddirs[1] + r.dirs[2] * ddirs[2];
+    for (int j = 0; j < 3; ++j) du[j] = (ddirs[j] - r.dirs[j] * dot) / r.un;
+  } else {
+    for (int j = 0; j < 3; ++j) du[j] = ddirs[j];
+  }
+  out[12] = -r.u[0] / fx * du[0];
+  out[13] = -r.u[1] / fy * du[1];
+  *cam_out = cam;
+}
+
 }  // namespace cnr

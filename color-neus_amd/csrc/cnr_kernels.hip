@@ -115,6 +115,7 @@ CNR_PW_KERNEL(embed_pts, EmbedPts, body_embed_pts)
 CNR_PW_KERNEL(fine_setup, FineSetup, body_fine_setup)
 CNR_PW_KERNEL(coltop_bwd, ColTopBwd, body_coltop_bwd)
 CNR_PW_KERNEL(pbar_finish, PbarFinish, body_pbar_finish)
+CNR_PW_KERNEL(gen_rays, GenRays, body_gen_rays)
 
 void be_embed_z(const EmbedZ& p, cnr_stream s) { embed_z_launch(p, p.R * p.m, s); }
 void be_embed_pts(const EmbedPts& p, cnr_stream s) { embed_pts_launch(p, p.n, s); }
@@ -1159,6 +1160,41 @@ void be_clip_adam(const AdamArgs& a, cnr_stream s) {
   if (a.max_norm > 0.0f) hipLaunchKernelGGL(clip_norm_kernel, dim3(a.nchunks), dim3(256), 0, s, a);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(a.nchunks), dim3(256), 0, s, a);
   CNR_LAUNCH_CHECK("clip_adam");
+}
+
+void be_gen_rays(const GenRays& p, cnr_stream s) { gen_rays_launch(p, p.n, s); }
+
+// backward of the ray generator: one workgroup per camera folds the contributions of that camera's rays (thread-strided partial
+// sums, then a fixed-order tree: bitwise deterministic, no float atomics); the focal gradient is summed over the cameras in order.
+__global__ __launch_bounds__(256) void gen_rays_bwd_kernel(const GenRaysBwd q) {
+  __shared__ float red[4];
+  const int cam = blockIdx.x, tid = threadIdx.x;
+  float acc[14];
+  for (int k = 0; k < 14; ++k) acc[k] = 0.0f;
+  for (long i = tid; i < q.f.n; i += 256) {
+    int c; float out[14];
+    body_gen_rays_bwd1(q, i, &c, out);
+    if (c == cam) for (int k = 0; k < 14; ++k) acc[k] += out[k];
+  }
+  for (int k = 0; k < 14; ++k) {
+    const float v = block_sum_256(acc[k], red);
+    if (tid == 0) { if (k < 12) q.d_c2w[cam * 16 + k] = v; else q.d_focal_partial[cam * 2 + (k - 12)] = v; }
+    __syncthreads();
+  }
+  if (tid < 4) q.d_c2w[cam * 16 + 12 + tid] = 0.0f;
+}
+__global__ void gen_rays_focal_fold_kernel(const GenRaysBwd q) {
+  if (threadIdx.x < 2) {
+    float s = 0.0f;
+    for (int c = 0; c < q.f.n_cams; ++c) s += q.d_focal_partial[c * 2 + threadIdx.x];
+    q.d_focal[threadIdx.x] = s;
+  }
+}
+void be_gen_rays_bwd(const GenRaysBwd& q, cnr_stream s) {
+  TimingScope ts_("gen_rays_bwd", 2, 0, q.f.n, 0, 0, 0, s);
+  hipLaunchKernelGGL(gen_rays_bwd_kernel, dim3(q.f.n_cams), dim3(256), 0, s, q);
+  hipLaunchKernelGGL(gen_rays_focal_fold_kernel, dim3(1), dim3(64), 0, s, q);
+  CNR_LAUNCH_CHECK("gen_rays_bwd");
 }
 
 void be_grid_points(float*, cnr_stream) {}

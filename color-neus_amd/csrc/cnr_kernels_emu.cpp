@@ -190,6 +190,28 @@ void be_variance_finish(const VarianceFinish& p, cnr_stream) {
   *p.d_variance = (raw >= 1e-6f && raw <= 1e6f) ? a * 10.0f * raw : 0.0f;
 }
 
+void be_gen_rays(const GenRays& p, cnr_stream) {
+  for (long i = 0; i < p.n; ++i) body_gen_rays(p, i);
+}
+void be_gen_rays_bwd(const GenRaysBwd& q, cnr_stream) {
+  for (int cam = 0; cam < q.f.n_cams; ++cam) {
+    double acc[14] = {0};   // (the HIP kernel sums in float in a fixed tree order; the tests compare both with autograd)
+    for (long i = 0; i < q.f.n; ++i) {
+      int c; float out[14];
+      body_gen_rays_bwd1(q, i, &c, out);
+      if (c == cam) for (int k = 0; k < 14; ++k) acc[k] += out[k];
+    }
+    for (int k = 0; k < 12; ++k) q.d_c2w[cam * 16 + k] = (float)acc[k];
+    for (int k = 12; k < 16; ++k) q.d_c2w[cam * 16 + k] = 0.0f;
+    q.d_focal_partial[cam * 2] = (float)acc[12]; q.d_focal_partial[cam * 2 + 1] = (float)acc[13];
+  }
+  for (int j = 0; j < 2; ++j) {
+    float s = 0.0f;
+    for (int c = 0; c < q.f.n_cams; ++c) s += q.d_focal_partial[c * 2 + j];
+    q.d_focal[j] = s;
+  }
+}
+
 void be_clip_adam(const AdamArgs& a, cnr_stream) {
   for (int k = 0; k < a.count; ++k) {
     const AdamTensor& t = a.t[k];

@@ -1067,6 +1067,45 @@ int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const fl
   return check_backend("loss_grads");
 }
 
+static int gen_rays_args(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
+                         int32_t normalize, int32_t opengl, const float* origin, float radius, GenRays& g) {
+  if (!c2w || !focal) return fail("null argument");
+  if (n <= 0 || n_cams <= 0 || H <= 0 || W <= 0) return fail("gen_rays: n, n_cams, H, W must be positive");
+  if (origin && !(radius > 0.0f)) return fail("gen_rays: radius must be positive");
+  static_assert(sizeof(long) == sizeof(int64_t), "int64 pixel indices");
+  g.pix_idx = reinterpret_cast<const long*>(pix_idx); g.n = n; g.c2w = c2w; g.n_cams = n_cams; g.focal = focal; g.H = H; g.W = W;
+  g.normalize = normalize; g.opengl = opengl; g.origin = origin; g.radius = radius;
+  g.image = nullptr; g.mask = nullptr; g.rays_o = nullptr; g.rays_d = nullptr; g.rgb = nullptr; g.mask_sel = nullptr; g.near_ = nullptr; g.far_ = nullptr;
+  return 0;
+}
+
+int cnr_gen_rays(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
+                 int32_t normalize, int32_t opengl, const float* image, const float* mask, const float* origin, float radius,
+                 float* rays_o, float* rays_d, float* rgb, float* mask_sel, float* near_, float* far_, void* stream) {
+  GenRays g;
+  if (gen_rays_args(pix_idx, n, c2w, n_cams, focal, H, W, normalize, opengl, origin, radius, g)) return -1;
+  if (!rays_o || !rays_d) return fail("null argument");
+  if ((rgb && !image) || (mask_sel && !mask)) return fail("gen_rays: rgb / mask_sel need image / mask");
+  if ((near_ != nullptr) != (far_ != nullptr)) return fail("gen_rays: near and far must be given together");
+  g.image = image; g.mask = mask; g.rays_o = rays_o; g.rays_d = rays_d; g.rgb = rgb; g.mask_sel = mask_sel; g.near_ = near_; g.far_ = far_;
+  be_gen_rays(g, (cnr_stream)stream);
+  return check_backend("gen_rays");
+}
+
+int cnr_gen_rays_backward(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
+                          int32_t normalize, int32_t opengl, const float* origin, float radius, const float* d_rays_o, const float* d_rays_d,
+                          const float* d_near, const float* d_far, float* d_c2w, float* d_focal, void* scratch, size_t scratch_bytes, void* stream) {
+  GenRaysBwd q;
+  if (gen_rays_args(pix_idx, n, c2w, n_cams, focal, H, W, normalize, opengl, origin, radius, q.f)) return -1;
+  if (!d_c2w || !d_focal || !scratch) return fail("null argument");
+  if (scratch_bytes < (size_t)n_cams * 2 * sizeof(float)) return fail("gen_rays_backward scratch too small");
+  if ((d_near != nullptr) != (d_far != nullptr)) return fail("gen_rays_backward: d_near and d_far must be given together");
+  q.d_rays_o = d_rays_o; q.d_rays_d = d_rays_d; q.d_near = d_near; q.d_far = d_far; q.d_c2w = d_c2w; q.d_focal = d_focal;
+  q.d_focal_partial = static_cast<float*>(scratch);
+  be_gen_rays_bwd(q, (cnr_stream)stream);
+  return check_backend("gen_rays_backward");
+}
+
 size_t cnr_clip_adam_scratch_bytes(int32_t n_tensors, const int64_t* sizes) {
   if (!sizes || n_tensors <= 0) return 0;
   size_t chunks = 0;

@@ -78,6 +78,24 @@ CNR_HD float upsample_alpha(float s0, float s1, float z0, float z1, float cos_va
   return (pc - nc + 1e-5f) / (pc + 1e-5f);
 }
 
+// One ray of get_rays_multicam / get_rays_at (ray_utils.py:16-119): camera-frame direction of pixel (px, py), optional normalisation,
+// rotation into the world frame, camera centre as origin.  u = unnormalised direction, dirs = (normalised) camera-frame direction.
+struct RayGeom { float u[3], un, dirs[3], d[3], o[3]; };
+CNR_HD RayGeom ray_geometry(const float* c2w /* one [4][4] */, float fx, float fy, int H, int W, int px, int py, int normalize, int opengl) {
+  RayGeom r;
+  const float ys = opengl ? -1.0f : 1.0f, zs = opengl ? -1.0f : 1.0f;
+  r.u[0] = ((float)px - (float)W * 0.5f) / fx;
+  r.u[1] = ys * ((float)py - (float)H * 0.5f) / fy;
+  r.u[2] = zs;
+  r.un = sqrtf(r.u[0] * r.u[0] + r.u[1] * r.u[1] + r.u[2] * r.u[2]);
+  for (int k = 0; k < 3; ++k) r.dirs[k] = normalize ? r.u[k] / r.un : r.u[k];
+  for (int k = 0; k < 3; ++k) {
+    r.d[k] = r.dirs[0] * c2w[k * 4] + r.dirs[1] * c2w[k * 4 + 1] + r.dirs[2] * c2w[k * 4 + 2];
+    r.o[k] = c2w[k * 4 + 3];
+  }
+  return r;
+}
+
 // d/d rgb of inverse_sigmoid (clamp semantics of torch: gradient passes where the clamp is inactive, bounds inclusive)
 CNR_HD float inverse_sigmoid_grad(float rgb) {
   if (rgb < 0.0f || rgb > 1.0f) return 0.0f;

@@ -1,70 +1,150 @@
-"""Ray tools of the caller side of the render path: drop-in counterparts of
-lib/models/tools/ray_utils.py `get_rays_multicam` (:16-87), `get_rays_at` (:90-119), `near_far_from_sphere` (:7-13).
+"""Ray tools of the caller side of the render path: drop-in counterparts of the reference's
+``get_rays_multicam`` / ``get_rays_at`` / ``near_far_from_sphere`` (lib/models/tools/ray_utils.py:7-119) on the device library.
 
-The reference's `get_rays_multicam` materialises directions/origins for ALL N*H*W pixels (~184 MB per step at DTU size) and then
-gathers n_rays of them.  Here the random pixel selection is done first -- with the SAME torch RNG calls in the same order, so a
-seeded run picks identical pixels -- and rays are built only for the selected pixels.  All arithmetic per selected ray is the
-reference's formula, kept in differentiable torch ops (n_rays x 3 elements: negligible work) so that learnable poses / focal
-(config/Color_NeuS_iho.yml:18-20) still receive gradients through rays_o / rays_d."""
+The reference builds directions and origins for ALL N*H*W pixels of the batch (about 184 MB per step at DTU size) and gathers
+n_rays of them.  Here the pixels are chosen first and one kernel (cnr_gen_rays) builds rays, colours and mask values only for
+those; ``rays_for_training`` also folds in what NeuS_Trainer.render does next (origin / radius normalisation, near / far).
+Learnable poses and focal lengths (config/Color_NeuS_iho.yml:18-20) get their gradients from cnr_gen_rays_backward.
+
+Pixel choice consumes the torch CPU generator exactly like the reference (same calls, same order), so a seeded run picks the same
+pixels: that is the only part left in torch -- it IS the reference's random stream."""
+import ctypes as C
+import warnings
+
 import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream_of(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else C.c_void_p(0)
+
+
+def _library(library):
+    return library if isinstance(library, _lib.RenderLibrary) else _lib.load_library(library)
+
+
+def choose_pixels(n_rays, pixels_per_image, device, mask=None, mask_rate=0.9):
+    """Flat pixel indices (camera * H * W + row * W + column) of one training batch.
+
+    Without a mask: uniform draws over ONE image's pixels, as the reference does (its indices never leave camera 0,
+    ray_utils.py:58).  With a mask: a share ``mask_rate`` of the batch from the foreground pixels, the rest from the background,
+    both without replacement, then shuffled.  Random-number consumption: randint | randperm(#fg), randperm(#bg), randperm(n)."""
+    if mask is None:
+        return torch.randint(0, pixels_per_image, (n_rays,)).to(device)
+    flat = mask.reshape(-1)
+    fg = torch.nonzero(flat > 0, as_tuple=True)[0]
+    fg_order = torch.randperm(fg.shape[0])
+    want_fg = int(mask_rate * n_rays)
+    if want_fg > fg.shape[0]:
+        warnings.warn(f"only {fg.shape[0]} foreground pixels for {want_fg} requested rays")
+        want_fg = fg.shape[0]
+    bg = torch.nonzero(flat == 0, as_tuple=True)[0]
+    bg_order = torch.randperm(bg.shape[0])
+    chosen = torch.cat([fg[fg_order[:want_fg]], bg[bg_order[:n_rays - want_fg]]], dim=-1)
+    return chosen[torch.randperm(chosen.shape[0])]
+
+
+class _GenRays(torch.autograd.Function):
+    """autograd edge around cnr_gen_rays / cnr_gen_rays_backward."""
+
+    @staticmethod
+    def forward(ctx, lib, pix_idx, n, c2w, focal, H, W, normalize, opengl, image, mask, origin, radius, want_nearfar):
+        dev = c2w.device
+        c2w_c = c2w.detach().reshape(-1, 4, 4).contiguous().float()
+        focal_c = focal.detach().reshape(-1).contiguous().float().to(dev)
+        img = image.detach().contiguous().float() if image is not None else None
+        msk = mask.detach().contiguous().float() if mask is not None else None
+        org = origin.detach().reshape(-1).contiguous().float().to(dev) if origin is not None else None
+        idx = pix_idx.contiguous().to(torch.int64) if pix_idx is not None else None
+        f32 = dict(dtype=torch.float32, device=dev)
+        rays_o, rays_d = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
+        rgb = torch.empty(n, 3, **f32) if img is not None else None
+        msel = torch.empty(n, **f32) if msk is not None else None
+        near = torch.empty(n, **f32) if want_nearfar else None
+        far = torch.empty(n, **f32) if want_nearfar else None
+        rc = lib.lib.cnr_gen_rays(_ptr(idx), n, _ptr(c2w_c), c2w_c.shape[0], _ptr(focal_c), H, W, int(normalize), int(opengl), _ptr(img), _ptr(msk),
+                                  _ptr(org), float(radius), _ptr(rays_o), _ptr(rays_d), _ptr(rgb), _ptr(msel), _ptr(near), _ptr(far), _stream_of(c2w_c))
+        lib.check(rc, "cnr_gen_rays")
+        ctx.lib, ctx.meta = lib, (n, H, W, int(normalize), int(opengl), float(radius), c2w.shape, focal.shape)
+        ctx.save_for_backward(idx if idx is not None else torch.empty(0, dtype=torch.int64, device=dev), c2w_c, focal_c,
+                              org if org is not None else torch.empty(0, device=dev))
+        outs = [rays_o, rays_d]
+        nd = [t for t in (rgb, msel) if t is not None]
+        ctx.mark_non_differentiable(*nd)
+        ctx.n_extra = (rgb is not None, msel is not None, want_nearfar)
+        return tuple(outs + [rgb if rgb is not None else torch.empty(0, device=dev), msel if msel is not None else torch.empty(0, device=dev),
+                             near if near is not None else torch.empty(0, device=dev), far if far is not None else torch.empty(0, device=dev)])
+
+    @staticmethod
+    def backward(ctx, d_o, d_d, _d_rgb, _d_mask, d_near, d_far):
+        idx, c2w_c, focal_c, org = ctx.saved_tensors
+        n, H, W, normalize, opengl, radius, c2w_shape, focal_shape = ctx.meta
+        dev = c2w_c.device
+        need = ctx.needs_input_grad
+        if not (need[3] or need[4]):
+            return (None,) * 14
+        z3 = lambda g: g.contiguous().float() if g is not None else None
+        d_o, d_d = z3(d_o), z3(d_d)
+        has_nf = ctx.n_extra[2] and d_near is not None and d_far is not None and d_near.numel() == n
+        d_near = z3(d_near) if has_nf else None
+        d_far = z3(d_far) if has_nf else None
+        d_c2w = torch.empty_like(c2w_c)
+        d_focal = torch.empty(2, dtype=torch.float32, device=dev)
+        scratch = torch.empty(c2w_c.shape[0] * 2, dtype=torch.float32, device=dev)
+        rc = ctx.lib.lib.cnr_gen_rays_backward(_ptr(idx if idx.numel() else None), n, _ptr(c2w_c), c2w_c.shape[0], _ptr(focal_c), H, W, normalize, opengl,
+                                               _ptr(org if org.numel() else None), radius, _ptr(d_o), _ptr(d_d), _ptr(d_near), _ptr(d_far),
+                                               _ptr(d_c2w), _ptr(d_focal), _ptr(scratch), scratch.numel() * 4, _stream_of(c2w_c))
+        ctx.lib.check(rc, "cnr_gen_rays_backward")
+        return (None, None, None, d_c2w.reshape(c2w_shape) if need[3] else None, d_focal.reshape(focal_shape) if need[4] else None,
+                None, None, None, None, None, None, None, None, None)
+
+
+def _generate(lib, pix_idx, n, c2w, focal, H, W, normalize, opengl, image=None, mask=None, origin=None, radius=1.0, want_nearfar=False):
+    o, d, rgb, msel, near, far = _GenRays.apply(lib, pix_idx, n, c2w, focal, H, W, normalize, opengl, image, mask, origin, radius, want_nearfar)
+    return o, d, (rgb if image is not None else None), (msel if mask is not None else None), (near if want_nearfar else None), (far if want_nearfar else None)
+
+
+def get_rays_multicam(c2w, focal, image, n_rays, normalize=False, mask=None, mask_rate=0.9, return_mask=False, opengl=False, library=None):
+    """Random n rays in world space from N cameras: the reference's signature and return values (ray_utils.py:16-87)."""
+    assert c2w.dim() == 3 and image.dim() == 4, "c2w [N,4,4] and image [N,H,W,3] expected (multi-camera form)"
+    H, W = image.shape[1], image.shape[2]
+    idx = choose_pixels(n_rays, H * W, c2w.device, mask, mask_rate)
+    if return_mask:
+        assert mask is not None
+    o, d, rgb, msel, _, _ = _generate(_library(library), idx, idx.shape[0], c2w, focal, H, W, normalize, opengl, image=image,
+                                      mask=mask if return_mask else None)
+    return o, d, rgb, msel
+
+
+def get_rays_at(c2w, focal, H, W, normalize=False, opengl=False, library=None):
+    """All rays of one camera, [H, W, 3] each (ray_utils.py:90-119)."""
+    assert c2w.dim() == 2, "c2w [4,4] expected (single-camera form)"
+    o, d, _, _, _, _ = _generate(_library(library), None, H * W, c2w, focal, H, W, normalize, opengl)
+    return o.reshape(H, W, 3), d.reshape(H, W, 3)
+
+
+def rays_for_training(c2w, focal, image, n_rays, origin, radius, normalize=False, mask=None, mask_rate=0.9, return_mask=False, opengl=False,
+                      library=None):
+    """What NeuS_Trainer.render does in front of the renderer call (NeuS_Trainer.py:104-120) in one launch: pixel choice, rays,
+    (rays_o - origin) / radius, near / far from the unit sphere, colours and mask values of the chosen pixels.
+    Returns rays_o, rays_d, near, far, rgb_gt, mask_select (None unless return_mask)."""
+    assert c2w.dim() == 3 and image.dim() == 4
+    H, W = image.shape[1], image.shape[2]
+    idx = choose_pixels(n_rays, H * W, c2w.device, mask, mask_rate)
+    o, d, rgb, msel, near, far = _generate(_library(library), idx, idx.shape[0], c2w, focal, H, W, normalize, opengl, image=image,
+                                           mask=mask if return_mask else None, origin=torch.as_tensor(origin, dtype=torch.float32), radius=float(radius),
+                                           want_nearfar=True)
+    return o, d, near, far, rgb, msel
 
 
 def near_far_from_sphere(rays_o, rays_d):
-    a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)
-    b = 2.0 * torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
-    mid = 0.5 * (-b) / a
-    return (mid - 1.0).squeeze(), (mid + 1.0).squeeze()
-
-
-def _pixel_dirs(px, py, focal, H, W, normalize, opengl):
-    y, z = (-1, -1) if opengl else (1, 1)
-    dirs = torch.stack([(px - W * 0.5) / focal[0], y * (py - H * 0.5) / focal[1], z * torch.ones_like(px)], -1)
-    if normalize:
-        dirs = dirs / torch.norm(dirs, dim=-1).unsqueeze(-1)
-    return dirs
-
-
-def get_rays_multicam(c2w, focal, image, n_rays, normalize=False, mask=None, mask_rate=0.9, return_mask=False, opengl=False):
-    """Random n rays in world space from N cameras; same signature, return values and RNG consumption as the reference."""
-    assert c2w.dim() == 3 and image.dim() == 4, "this is a multicam implementation"
-    device = c2w.device
-    H, W = image.shape[1], image.shape[2]
-    if mask is None:
-        rays_idx_raw = torch.randint(0, H * W, (n_rays,)).to(device)
-        mask_all = None
-    else:
-        mask_all = mask.reshape(-1)
-        valide_index = torch.where(mask_all > 0)[0]
-        rand_valid_index = torch.randperm(valide_index.shape[0])
-        n_rays_in_mask = int(mask_rate * n_rays)
-        if n_rays_in_mask > valide_index.shape[0]:
-            n_rays_in_mask = valide_index.shape[0]
-        n_rays_in_bkg = n_rays - n_rays_in_mask
-        invalid_index = torch.where(mask_all == 0)[0]
-        rand_invalid_index = torch.randperm(invalid_index.shape[0])
-        rays_idx_raw = torch.cat([valide_index[rand_valid_index[:n_rays_in_mask]], invalid_index[rand_invalid_index[:n_rays_in_bkg]]], dim=-1)
-        rays_idx_raw = rays_idx_raw[torch.randperm(rays_idx_raw.shape[0])]
-    cam = torch.div(rays_idx_raw, H * W, rounding_mode="floor")
-    pix = rays_idx_raw - cam * (H * W)
-    py = torch.div(pix, W, rounding_mode="floor").to(torch.float32)
-    px = (pix - torch.div(pix, W, rounding_mode="floor") * W).to(torch.float32)
-    dirs = _pixel_dirs(px, py, focal, H, W, normalize, opengl)                       # [n_rays, 3]
-    rot = c2w[cam, :3, :3]                                                            # [n_rays, 3, 3]
-    rays_d = torch.sum(dirs[:, None, :] * rot, -1)
-    rays_o = c2w[cam, :3, -1]
-    rgb = image.reshape(-1, 3)[rays_idx_raw]
-    if return_mask:
-        assert mask is not None
-        return rays_o, rays_d, rgb, mask_all[rays_idx_raw]
-    return rays_o, rays_d, rgb, None
-
-
-def get_rays_at(c2w, focal, H, W, normalize=False, opengl=False):
-    """All rays of one camera, [H, W, 3] each (reference ray_utils.py:90-119)."""
-    assert c2w.dim() == 2, "this is a sigle camera implementation"
-    device = c2w.device
-    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="xy")
-    dirs = _pixel_dirs(i.to(device), j.to(device), focal, H, W, normalize, opengl)
-    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
-    rays_o = c2w[:3, -1].expand(rays_d.shape)
-    return rays_o, rays_d
+    """near / far of the unit sphere along each ray (ray_utils.py:7-13); differentiable torch ops on [n, 3] tensors (callers that
+    already hold rays; rays_for_training gets the same values from the ray kernel)."""
+    a = (rays_d * rays_d).sum(-1)
+    mid = -(rays_o * rays_d).sum(-1) / a
+    return mid - 1.0, mid + 1.0

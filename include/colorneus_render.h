@@ -125,6 +125,21 @@ int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const fl
                    int64_t n_rays, int32_t n_samples, const float* coef /* device [4] */, float* d_color_fine, float* d_weight_sum,
                    float* d_delta_relight /* or NULL */, void* stream);
 
+/* ---- ray generation for the selected pixels, the producer right in front of the path (NeuS_Trainer.render, NeuS_Trainer.py:104-120):
+ * get_rays_multicam / get_rays_at (lib/models/tools/ray_utils.py:16-119) evaluated ONLY for the chosen pixels (the reference builds the
+ * rays of all N*H*W pixels and gathers), with the trainer's (rays_o - origin) / radius normalisation and near_far_from_sphere
+ * (ray_utils.py:7-13) folded in.  pix_idx: device int64 [n], flat index cam*H*W + row*W + col (NULL: pixel i of camera 0, i.e.
+ * get_rays_at over a whole H x W image when n = H*W); c2w [n_cams][4][4]; focal device [2]; image [n_cams][H][W][3] / mask
+ * [n_cams][H][W] may be NULL together with rgb / mask_sel; origin (device [3]) may be NULL; near_ / far_ may be NULL.
+ * cnr_gen_rays_backward: d c2w [n_cams][4][4] and d focal [2] from d rays_o, d rays_d (and d near / d far when given) for learnable
+ * poses / focal (config/Color_NeuS_iho.yml:18-20); scratch: n_cams * 2 floats. */
+int cnr_gen_rays(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
+                 int32_t normalize, int32_t opengl, const float* image, const float* mask, const float* origin, float radius,
+                 float* rays_o, float* rays_d, float* rgb, float* mask_sel, float* near_, float* far_, void* stream);
+int cnr_gen_rays_backward(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
+                          int32_t normalize, int32_t opengl, const float* origin, float radius, const float* d_rays_o, const float* d_rays_d,
+                          const float* d_near, const float* d_far, float* d_c2w, float* d_focal, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- optimiser step of the training loop (the consumer after loss.backward(), train.py:72-77): per-parameter gradient clipping
  * (clip_gradient -> torch.nn.utils.clip_grad_norm_ on EACH parameter tensor, lib/utils/net_utils.py:174-184) followed by
  * torch.optim.Adam (net_utils.py:88: betas (0.9, 0.99), eps 1e-8, no weight decay) in ONE launch over all tensors.
