@@ -28,7 +28,7 @@ class CnrInputs(C.Structure):
 OUTPUT_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
                  "inside_sphere", "depth", "global_color", "delta_relight", "z_vals", "eik_sums"]
 OUT_GRAD_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
-                   "depth", "global_color", "delta_relight"]
+                   "depth", "global_color", "delta_relight", "delta_relight_per_ray"]
 
 
 class CnrOutputs(C.Structure):

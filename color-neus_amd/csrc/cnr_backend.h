@@ -115,7 +115,7 @@ struct CompositeBwd {
   // upstream gradients (any may be null)
   const float* d_color_fine; const float* d_s_val; const float* d_cdf; const float* d_weight_sum; const float* d_weight_max;
   const float* d_gradients; const float* d_weights; const float* d_gradient_error; const float* d_depth;
-  const float* d_global_color; const float* d_delta_relight;
+  const float* d_global_color; const float* d_delta_relight; const float* d_delta_relight_ray /* [R] or null, see cnr_render_out_grads */;
   // per-point cotangents
   float* ztop; int ldztop; int ztop_col;   // ztop[pt][ztop_col] = d sdf / scale (the sdf row is the LAST internal row of the top layer)
   float* gbar;                 // [P][4] d loss / d g through alpha, eikonal and the 'gradients' output

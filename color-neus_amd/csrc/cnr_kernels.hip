@@ -857,6 +857,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
   const float dwmax = p.d_weight_max ? p.d_weight_max[ray] : 0.0f;
   const float dge = p.d_gradient_error ? p.d_gradient_error[0] : 0.0f;
   const float eik_den = p.eik_sums[1] + 1e-5f;
+  const float ddrel_ray = p.d_delta_relight_ray ? p.d_delta_relight_ray[ray] : 0.0f;
 
   // d loss / d w_j and the suffix sums S_j = sum_{k>j} wbar_k w_k (reverse scan, chunks from the back)
   float wbar[kRayChunks], S[kRayChunks];
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
                 tbar = cbar * pass * sg * (1.0f - sg);
                 gca += cbar * pass;
               }
-              p.dtop[pt * kTop + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f);
+              p.dtop[pt * kTop + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f) + ddrel_ray;
               p.gc_a[pt * kTop + k] = gca;
             } else {
               p.gc_a[pt * kTop + k] = cbar;

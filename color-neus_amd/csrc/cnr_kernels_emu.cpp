@@ -412,7 +412,7 @@ void be_composite_bwd(const CompositeBwd& p, cnr_stream) {
             tbar = cbar * pass * sg * (1.0f - sg);
             gca += cbar * pass;
           }
-          p.dtop[pt * kTop + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f);
+          p.dtop[pt * kTop + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f) + (p.d_delta_relight_ray ? p.d_delta_relight_ray[ray] : 0.0f);
           p.gc_a[pt * kTop + k] = gca;
         } else {
           p.gc_a[pt * kTop + k] = cbar;

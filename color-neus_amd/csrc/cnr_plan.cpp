@@ -743,6 +743,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   cb.d_weight_max = go->weight_max; cb.d_gradients = go->gradients; cb.d_weights = go->weights;
   cb.d_gradient_error = go->gradient_error; cb.d_depth = go->depth; cb.d_global_color = m.has_relight ? go->global_color : nullptr;
   cb.d_delta_relight = m.has_relight ? go->delta_relight : nullptr;
+  cb.d_delta_relight_ray = m.has_relight ? go->delta_relight_per_ray : nullptr;
   cb.ztop = b.ZTOP; cb.ldztop = x.ldztop; cb.ztop_col = m.F; cb.gbar = b.gbar_a; cb.dtop = b.dtop; cb.gc_a = b.gc_a; cb.dinvs_partial = b.dinvs;
   cb.d_rays_d = rays_grad ? b.drd_alpha : nullptr; cb.d_z = nf_live ? b.dzparts : nullptr;
   be_composite_bwd(cb, s);

@@ -125,9 +125,14 @@ class _FusedLoss(torch.autograd.Function):
         coef = torch.stack([g * c_rgb, g * c_bce, g * c_rel * mean_rel, g * 0.0])
         d_color = torch.empty_like(color_c)
         d_wsum = torch.empty(R, dtype=torch.float32, device=dev)
-        d_drel = torch.empty(ctx.shapes[2], dtype=torch.float32, device=dev) if (has_rel and ctx.shapes[2] is not None) else None
         lib.check(lib.lib.cnr_loss_grads(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(gt_c), _p(mask_t if has_mask or lcfg.include_mask else None),
-                                         R, M, _p(coef), _p(d_color), _p(d_wsum), _p(d_drel), _stream(color_c)), "cnr_loss_grads")
+                                         R, M, _p(coef), _p(d_color), _p(d_wsum), _p(None), _stream(color_c)), "cnr_loss_grads")
+        d_drel = None
+        if has_rel and ctx.shapes[2] is not None:
+            # d mean(delta_relight * mask)^2 / d delta_relight[r, j, c] = 2 mean / n * mask[r]: one value per ray.  Handed to the renderer's
+            # backward as an expanded (stride-0) view -- its compositor backward takes the per-ray vector, no [R][M][3] buffer is written
+            per_ray = coef[2] * mask_t if (lcfg.include_mask and mask_t is not None) else coef[2].expand(R)
+            d_drel = per_ray.reshape(R, 1, 1).expand(ctx.shapes[2])
         d_gerr = g_loss * lam_e * eik_factor
         return (None, None, None, None, None, d_color.reshape(ctx.shapes[0]), d_wsum.reshape(ctx.shapes[1]), d_gerr, None, d_drel, None, None)
 

@@ -99,6 +99,11 @@ class _RenderFunction(torch.autograd.Function):
         names = [k for k in _OUT_DIFF if color or k not in ("global_color", "delta_relight")]
         gmap = {}
         for k, g in zip(names, gouts[:len(names)]):
+            if k == "delta_relight" and g is not None and g.dim() == 3 and g.stride(1) == 0 and g.stride(2) == 0:
+                # a gradient that is constant along each ray and over rgb (what the relight loss term produces, loss.compute_loss_fused
+                # hands it over as an expanded view): pass the per-ray vector, never materialise [R][M][3]
+                gmap["delta_relight_per_ray"] = g[:, 0, 0].contiguous().float()
+                continue
             gmap[k] = g.contiguous().float() if g is not None else None
         cg = _lib.CnrOutGrads(**{k: _ptr(gmap.get(k)) for k in _lib.OUT_GRAD_FIELDS})
         # every parameter gradient is a view into ONE flat buffer (canonical parameter order): a ray-sharded run all-reduces it as is and

@@ -81,6 +81,10 @@ typedef struct cnr_render_out_grads {
   const float* color_fine; const float* s_val; const float* cdf_fine; const float* weight_sum; const float* weight_max;
   const float* gradients; const float* weights; const float* gradient_error; const float* depth;
   const float* global_color; const float* delta_relight;
+  const float* delta_relight_per_ray;   /* [R] or NULL: the gradient of delta_relight when it is constant along a ray and over rgb -- the
+                                           relight term of the training loss, mean(delta_relight * mask)^2 (NeuS_Trainer.py:153), yields
+                                           exactly that; lets the loss seed the backward pass without an [R][M][3] buffer.  Added to
+                                           delta_relight when both are given. */
 } cnr_render_out_grads;
 
 typedef struct cnr_render_in_grads {

@@ -70,3 +70,40 @@ def test_fused_loss_end_to_end_gradients_match():
     assert abs(res[0][0] - res[1][0]) < 1e-6 * abs(res[0][0])
     for k, g in res[0][1].items():
         assert float((g - res[1][1][k]).abs().max()) <= 1e-4 * float(g.abs().max()), k   # own scale per tensor
+
+
+def _loss_goldens(device, library):
+    """compute_loss_fused directly against the loss:* vectors captured from the reference's objective (NeuS_Trainer.py:129-171),
+    mask on and off, values and the gradients of every input."""
+    import _golden as G
+    import color_neus_amd as cn
+    fx = G.load("functions")
+    t = lambda k: torch.from_numpy(fx["loss:" + k]).to(device)
+    for with_mask, key in ((True, "l_on"), (False, "l_off")):
+        leaves = {k: t(k).clone().requires_grad_(True) for k in ("cf", "ws", "dr", "ge")}
+        rd = {"color_fine": leaves["cf"], "weight_sum": leaves["ws"], "delta_relight": leaves["dr"], "gradient_error": leaves["ge"]}
+        mask = t("m") if with_mask else None
+        loss, parts = cn.compute_loss_fused(rd, t("gt"), mask, library=library)
+        assert abs(float(loss.detach()) - float(fx["loss:" + key])) < 1e-6 * abs(float(fx["loss:" + key])), key
+        loss.backward()
+        ref = {k: t(k).clone().requires_grad_(True) for k in ("cf", "ws", "dr", "ge")}
+        rl, _ = cn.compute_loss({"color_fine": ref["cf"], "weight_sum": ref["ws"], "delta_relight": ref["dr"], "gradient_error": ref["ge"]}, t("gt"), mask)
+        rl.backward()
+        for k in leaves:
+            if ref[k].grad is None:
+                continue
+            assert leaves[k].grad is not None, k
+            assert float((leaves[k].grad - ref[k].grad).abs().max()) <= 1e-6 * max(float(ref[k].grad.abs().max()), 1e-12), (key, k)
+
+
+@pytest.mark.gpu
+def test_fused_loss_against_reference_goldens_hip():
+    _loss_goldens("cuda:0", None)
+
+
+def test_fused_loss_against_reference_goldens_emu():
+    import os
+    if not os.path.isfile(N.EMU_LIB):
+        pytest.skip("emulation library not built")
+    import color_neus_amd as cn
+    _loss_goldens("cpu", cn.load_library(N.EMU_LIB))
