@@ -26,9 +26,11 @@ class CnrInputs(C.Structure):
 
 
 OUTPUT_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
-                 "inside_sphere", "depth", "global_color", "delta_relight", "z_vals", "eik_sums"]
+                 "inside_sphere", "depth", "global_color", "delta_relight", "z_vals", "eik_sums", "sdf_samples", "color_samples",
+                 "global_color_samples"]
 OUT_GRAD_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
-                   "depth", "global_color", "delta_relight", "delta_relight_per_ray"]
+                   "depth", "global_color", "delta_relight", "sdf_samples", "color_samples", "global_color_samples",
+                   "delta_relight_per_ray"]
 
 
 class CnrOutputs(C.Structure):
@@ -80,7 +82,7 @@ EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_c
            "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
            "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_grads",
-           "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward"]
+           "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward", "cnr_sample_z"]
 
 
 class RenderLibrary:
@@ -124,6 +126,7 @@ class RenderLibrary:
                                    _FP, _FP, _FP, _FP, _FP, _FP, _FP]
         L.cnr_gen_rays_backward.argtypes = [_FP, C.c_int64, _FP, C.c_int32, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, C.c_float,
                                             _FP, _FP, _FP, _FP, _FP, _FP, _FP, C.c_size_t, _FP]
+        L.cnr_sample_z.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(CnrInputs), _FP, _FP, C.c_size_t, _FP]
         L.cnr_timing_enable.argtypes = [C.c_int]
         L.cnr_timing_enable.restype = None
         L.cnr_timing_collect.argtypes = [C.POINTER(CnrKernelTiming), C.c_int]

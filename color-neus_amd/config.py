@@ -65,8 +65,8 @@ class RenderConfig:
             raise ValueError(f"unknown renderer TYPE {self.type!r}")
         if self.type == "Color_NeuS" and self.col_mode != "no_view_dir":
             raise AssertionError("Color_NeuS requires COLOR.MODE == 'no_view_dir'")  # Color_NeuS.py:14
-        if self.n_outside > 0:
-            raise NotImplementedError("N_OUTSIDE > 0 (NeRF++ background, NeuS.py:95-134) is outside the accelerated path")
+        if self.n_outside < 0 or self.n_samples + self.n_importance + self.n_outside > 256:
+            raise ValueError("N_OUTSIDE must be >= 0 and N_SAMPLES + N_IMPORTANCE + N_OUTSIDE <= 256")
         if self.sdf_d_in != 3 or self.col_d_out != 3 or self.rel_d_out != 3:
             raise NotImplementedError("only 3-D points / RGB outputs are supported")
         if self.col_mode not in ("idr", "no_view_dir", "no_normal"):

@@ -87,6 +87,8 @@ struct CompositeFwd {   // Color_NeuS.py:66-123, NeuS.py:382-399
   float* color_fine; float* s_val; float* cdf_fine; float* weight_sum; float* weight_max; float* weights;
   float* inside_sphere; float* depth; float* global_color;
   float* eik_partial;    // [R][2]
+  // optional per-sample copies of the network outputs for callers that composite themselves (N_OUTSIDE > 0 background mixing)
+  float* sdf_s; float* color_s; float* gcolor_s;   // [P], [P][3], [P][3] or null
 };
 
 // inference-only early-termination compaction: samples whose compositing weight is below eps contribute < eps to the pixel,
@@ -116,6 +118,7 @@ struct CompositeBwd {
   const float* d_color_fine; const float* d_s_val; const float* d_cdf; const float* d_weight_sum; const float* d_weight_max;
   const float* d_gradients; const float* d_weights; const float* d_gradient_error; const float* d_depth;
   const float* d_global_color; const float* d_delta_relight; const float* d_delta_relight_ray /* [R] or null, see cnr_render_out_grads */;
+  const float* d_sdf_s; const float* d_color_s; const float* d_gcolor_s;   // per-sample cotangents of CompositeFwd::sdf_s / color_s / gcolor_s (or null)
   // per-point cotangents
   float* ztop; int ldztop; int ztop_col;   // ztop[pt][ztop_col] = d sdf / scale (the sdf row is the LAST internal row of the top layer)
   float* gbar;                 // [P][4] d loss / d g through alpha, eikonal and the 'gradients' output

@@ -779,6 +779,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeFwd p
           p.weights[pt] = w;
           p.cdf_fine[pt] = q.a.pc;
           p.inside_sphere[pt] = q.inside;
+          if (p.sdf_s) p.sdf_s[pt] = p.sdf[pt];
+          if (p.color_s) for (int k = 0; k < 3; ++k) p.color_s[pt * 3 + k] = p.color[pt * p.ldcolor + k];
+          if (p.gcolor_s && p.gcolor) for (int k = 0; k < 3; ++k) p.gcolor_s[pt * 3 + k] = p.gcolor[pt * p.ldg + k];
         }
       }
     }
@@ -903,15 +906,15 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
         }
         if (active) {
           if (p.d_z) { p.d_z[pt * 2] = ddepth * w[c]; p.d_z[pt * 2 + 1] = ag.d_dist; }
-          p.ztop[pt * p.ldztop + p.ztop_col] = ag.d_sdf / p.sdf_scale;
+          p.ztop[pt * p.ldztop + p.ztop_col] = (ag.d_sdf + (p.d_sdf_s ? p.d_sdf_s[pt] : 0.0f)) / p.sdf_scale;
           for (int k = 0; k < 3; ++k) p.gbar[pt * 4 + k] = gb[k];
           p.gbar[pt * 4 + 3] = 0.0f;
           for (int k = 0; k < 3; ++k) {
-            const float cbar = dcol[k] * w[c];                 // cotangent of the composited (relit) colour sample
+            const float cbar = dcol[k] * w[c] + (p.d_color_s ? p.d_color_s[pt * 3 + k] : 0.0f);   // cotangent of the composited (relit) colour sample
             if (p.has_relight) {
               const float relit = p.color[pt * p.ldcolor + k];
               const float gc = p.gcolor[pt * p.ldg + k];
-              float tbar, gca = dglob[k] * w[c];
+              float tbar, gca = dglob[k] * w[c] + (p.d_gcolor_s ? p.d_gcolor_s[pt * 3 + k] : 0.0f);
               if (p.inv_sigmoid) {
                 tbar = cbar * relit * (1.0f - relit);
                 gca += tbar * inverse_sigmoid_grad(gc);

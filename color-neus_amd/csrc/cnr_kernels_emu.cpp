@@ -334,6 +334,9 @@ void be_composite_fwd(const CompositeFwd& p, cnr_stream) {
       if (p.gcolor) for (int k = 0; k < 3; ++k) gcl[k] += w * p.gcolor[pt * p.ldg + k];
       e0 += q.relax * (q.gn - 1.0f) * (q.gn - 1.0f); e1 += q.relax;
       p.weights[pt] = w; p.cdf_fine[pt] = q.a.pc; p.inside_sphere[pt] = q.inside;
+      if (p.sdf_s) p.sdf_s[pt] = p.sdf[pt];
+      if (p.color_s) for (int k = 0; k < 3; ++k) p.color_s[pt * 3 + k] = p.color[pt * p.ldcolor + k];
+      if (p.gcolor_s && p.gcolor) for (int k = 0; k < 3; ++k) p.gcolor_s[pt * 3 + k] = p.gcolor[pt * p.ldg + k];
     }
     for (int k = 0; k < 3; ++k) {
       float cc = col[k];
@@ -397,12 +400,12 @@ void be_composite_bwd(const CompositeBwd& p, cnr_stream) {
       }
       p.gbar[pt * 4 + 3] = 0.0f;
       if (p.d_z) { p.d_z[pt * 2] = ddepth * w[j]; p.d_z[pt * 2 + 1] = ag.d_dist; }
-      p.ztop[pt * p.ldztop + p.ztop_col] = ag.d_sdf / p.sdf_scale;
+      p.ztop[pt * p.ldztop + p.ztop_col] = (ag.d_sdf + (p.d_sdf_s ? p.d_sdf_s[pt] : 0.0f)) / p.sdf_scale;
       for (int k = 0; k < 3; ++k) {
-        float cbar = dcol[k] * w[j];
+        float cbar = dcol[k] * w[j] + (p.d_color_s ? p.d_color_s[pt * 3 + k] : 0.0f);
         if (p.has_relight) {
           float relit = p.color[pt * p.ldcolor + k], gc = p.gcolor[pt * p.ldg + k];
-          float tbar, gca = dglob[k] * w[j];
+          float tbar, gca = dglob[k] * w[j] + (p.d_gcolor_s ? p.d_gcolor_s[pt * 3 + k] : 0.0f);
           if (p.inv_sigmoid) {
             tbar = cbar * relit * (1.0f - relit);
             gca += tbar * inverse_sigmoid_grad(gc);

@@ -630,6 +630,7 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   cf.color_fine = out->color_fine; cf.s_val = out->s_val; cf.cdf_fine = out->cdf_fine; cf.weight_sum = out->weight_sum;
   cf.weight_max = out->weight_max; cf.weights = out->weights; cf.inside_sphere = out->inside_sphere; cf.depth = out->depth;
   cf.global_color = m.has_relight ? out->global_color : nullptr; cf.eik_partial = x.eik_partial;
+  cf.sdf_s = out->sdf_samples; cf.color_s = out->color_samples; cf.gcolor_s = m.has_relight ? out->global_color_samples : nullptr;
 
   if (in->prune_eps > 0.0f) {
     // inference-only early termination: weights first (they need only sdf and its gradient), then the colour / relight networks
@@ -744,6 +745,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   cb.d_gradient_error = go->gradient_error; cb.d_depth = go->depth; cb.d_global_color = m.has_relight ? go->global_color : nullptr;
   cb.d_delta_relight = m.has_relight ? go->delta_relight : nullptr;
   cb.d_delta_relight_ray = m.has_relight ? go->delta_relight_per_ray : nullptr;
+  cb.d_sdf_s = go->sdf_samples; cb.d_color_s = go->color_samples; cb.d_gcolor_s = m.has_relight ? go->global_color_samples : nullptr;
   cb.ztop = b.ZTOP; cb.ldztop = x.ldztop; cb.ztop_col = m.F; cb.gbar = b.gbar_a; cb.dtop = b.dtop; cb.gc_a = b.gc_a; cb.dinvs_partial = b.dinvs;
   cb.d_rays_d = rays_grad ? b.drd_alpha : nullptr; cb.d_z = nf_live ? b.dzparts : nullptr;
   be_composite_bwd(cb, s);
@@ -1025,6 +1027,21 @@ size_t cnr_bwd_scratch_bytes(const cnr_config* cfg, int64_t n_rays) {
 int cnr_render_forward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
                        const cnr_render_outputs* out, void* ctx, size_t ctx_bytes, void* stream) {
   return render_forward(cfg, params, in, out, ctx, ctx_bytes, (cnr_stream)stream);
+}
+
+int cnr_sample_z(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in, float* z_vals, void* ctx, size_t ctx_bytes,
+                 void* stream) {
+  Model m;
+  if (build_model(cfg, m)) return -1;
+  if (!params || !in || !z_vals || !ctx) return fail("null argument");
+  if (in->n_rays <= 0) return fail("n_rays must be positive");
+  Arena a(ctx);
+  Ctx x;
+  layout_ctx(m, in->n_rays, a, x);
+  if (a.off > ctx_bytes) return fail("context buffer too small: need %zu bytes, got %zu", a.off, ctx_bytes);
+  prep_all(m, params, (cnr_stream)stream);
+  run_sampler(m, in, z_vals, x, (cnr_stream)stream);
+  return check_backend("sample_z");
 }
 
 int cnr_render_backward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,

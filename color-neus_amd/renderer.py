@@ -16,6 +16,7 @@ from .config import RenderConfig, config_from_node
 
 _OUT_DIFF = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error", "depth",
              "global_color", "delta_relight"]
+_SAMPLE_OUT = ["sdf_samples", "color_samples", "global_color_samples"]   # per-sample network outputs (only with want_samples)
 
 
 def _ptr(t):
@@ -32,7 +33,7 @@ class _RenderFunction(torch.autograd.Function):
     """autograd edge around cnr_render_forward / cnr_render_backward."""
 
     @staticmethod
-    def forward(ctx, owner, rays_o, rays_d, near, far, t_rand, z_override, background_rgb, cos_anneal_ratio, prune_eps, *params):
+    def forward(ctx, owner, rays_o, rays_d, near, far, t_rand, z_override, background_rgb, cos_anneal_ratio, prune_eps, want_samples, *params):
         lib, ccfg, cfg = owner._lib, owner._ccfg, owner.rcfg
         dev = rays_o.device
         R, M = rays_o.shape[0], cfg.n_total
@@ -46,7 +47,10 @@ class _RenderFunction(torch.autograd.Function):
                    gradient_error=torch.empty((), **f32), inside_sphere=torch.empty(R, M, **f32), depth=torch.empty(R, **f32),
                    global_color=torch.empty(R, 3, **f32) if color else None,
                    delta_relight=torch.empty(R, M, 3, **f32) if color else None,
-                   z_vals=torch.empty(R, M, **f32), eik_sums=torch.empty(2, **f32))
+                   z_vals=torch.empty(R, M, **f32), eik_sums=torch.empty(2, **f32),
+                   sdf_samples=torch.empty(R, M, **f32) if want_samples else None,
+                   color_samples=torch.empty(R, M, 3, **f32) if want_samples else None,
+                   global_color_samples=torch.empty(R, M, 3, **f32) if (want_samples and color) else None)
         if z_override is not None:
             out["z_vals"].copy_(z_override.detach().reshape(R, M))
         plist = [p.detach().contiguous() for p in params]
@@ -76,7 +80,9 @@ class _RenderFunction(torch.autograd.Function):
         ctx.nearfar_need_grad = (near.requires_grad or far.requires_grad) and cfg.n_importance == 0 and z_override is None
         ctx.nearfar_shapes = (near.shape, far.shape)
         ctx.mark_non_differentiable(out["inside_sphere"], out["z_vals"], out["eik_sums"])
-        res = [out[k] for k in _OUT_DIFF if out[k] is not None] + [out["inside_sphere"], out["z_vals"], out["eik_sums"]]
+        ctx.sample_names = [k for k in _SAMPLE_OUT if out[k] is not None]
+        res = [out[k] for k in _OUT_DIFF if out[k] is not None] + [out[k] for k in ctx.sample_names] + \
+              [out["inside_sphere"], out["z_vals"], out["eik_sums"]]
         return tuple(res)
 
     @staticmethod
@@ -96,7 +102,7 @@ class _RenderFunction(torch.autograd.Function):
         plist = sv[pos:pos + nparams]
         R = rays_o.shape[0]
         color = cfg.type == "Color_NeuS"
-        names = [k for k in _OUT_DIFF if color or k not in ("global_color", "delta_relight")]
+        names = [k for k in _OUT_DIFF if color or k not in ("global_color", "delta_relight")] + ctx.sample_names
         gmap = {}
         for k, g in zip(names, gouts[:len(names)]):
             if k == "delta_relight" and g is not None and g.dim() == 3 and g.stride(1) == 0 and g.stride(2) == 0:
@@ -134,7 +140,7 @@ class _RenderFunction(torch.autograd.Function):
             d_near, d_far = d_near.reshape(ctx.nearfar_shapes[0]), d_far.reshape(ctx.nearfar_shapes[1])
         # hand the views over without keeping a second reference: autograd then installs them as p.grad as they are (it clones a
         # gradient that something else still references), so p.grad aliases the flat buffer
-        res = (None, d_o, d_d, d_near, d_far, None, None, None, None, None) + tuple(dparams)
+        res = (None, d_o, d_d, d_near, d_far, None, None, None, None, None, None) + tuple(dparams)
         del dparams, flat
         return res
 
@@ -276,6 +282,9 @@ class NeuSRenderer(nn.Module):
         self.color_network = _ColorNet(rcfg)
         self.n_samples, self.n_importance = rcfg.n_samples, rcfg.n_importance
         self.n_outside, self.up_sample_steps, self.perturb, self.N = rcfg.n_outside, rcfg.up_sample_steps, rcfg.perturb, rcfg.N
+        if self.n_outside > 0:   # NeRF++ background (NeuS.py:87-91): torch fallback, see background.py
+            from .background import NeRF
+            self.nerf = NeRF()
         self._library_arg = library
         self._lib_obj = None
         self._ccfg = _lib.c_config(rcfg)
@@ -301,8 +310,9 @@ class NeuSRenderer(nn.Module):
                 if named[name].numel() != rows * cols:
                     raise RuntimeError(f"parameter {name}: expected {rows}x{cols}, have {tuple(named[name].shape)}")
                 order.append(name)
-            if len(order) != len(named):
-                raise RuntimeError("parameter inventory mismatch between module and library")
+            extra = [k for k in named if k not in order and not k.startswith("nerf.")]   # nerf.*: background network, torch side only
+            if extra:
+                raise RuntimeError(f"parameter inventory mismatch between module and library: {extra[:3]}")
             self._order = order
         named = dict(self.named_parameters())
         return [named[k] for k in self._order]
@@ -341,13 +351,17 @@ class NeuSRenderer(nn.Module):
         if perturb_overwrite >= 0:
             perturb = perturb_overwrite
         t_rand = None
-        if perturb > 0 and z_vals is None:
-            t_rand = self._jitter_to_device(torch.rand([n_rays, 1]), dev)   # CPU generator, exactly like NeuS.py:325
+        if perturb > 0 and (z_vals is None or self.n_outside > 0):
+            t_cpu = torch.rand([n_rays, 1])   # CPU generator, exactly like NeuS.py:325 (drawn even under a z override when the
+            if z_vals is None:                # background draw follows, so that the stream stays the reference's)
+                t_rand = self._jitter_to_device(t_cpu, dev)
         bg = None
         if background_rgb is not None:
             bg = torch.as_tensor(background_rgb, dtype=torch.float32, device=dev).reshape(-1)[:3].contiguous()
         params = self._ordered_params()
-        res = _RenderFunction.apply(self, rays_o, rays_d, near, far, t_rand, z_vals, bg, cos_anneal_ratio, prune_eps, *params)
+        if self.n_outside > 0:
+            return self._forward_with_background(rays_o, rays_d, near, far, perturb, t_rand, bg, cos_anneal_ratio, params, z_vals)
+        res = _RenderFunction.apply(self, rays_o, rays_d, near, far, t_rand, z_vals, bg, cos_anneal_ratio, prune_eps, False, *params)
         names = [k for k in _OUT_DIFF if not (k in ("global_color", "delta_relight") and self.rcfg.type != "Color_NeuS")]
         out = dict(zip(names + ["inside_sphere", "z_vals", "eik_sums"], res))
         ret = {k: out[k] for k in ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",
@@ -369,6 +383,46 @@ class NeuSRenderer(nn.Module):
                                          _ptr(out), _stream_of(z))
         self._lib.check(rc, "cnr_up_sample")
         return out
+
+    # -- N_OUTSIDE > 0 (NeuS.py:313-369): foreground fields from the library, background + mixing in torch (background.py) ----------
+    def _forward_with_background(self, rays_o, rays_d, near, far, perturb, t_rand, bg, cos_anneal_ratio, params, z_override):
+        from . import background as B
+        rc = self.rcfg
+        R = len(rays_o)
+        z_out = B.outside_samples(far.reshape(-1), self.n_outside, self.n_samples, perturb)   # second draw of the CPU generator, like NeuS.py:335
+        if z_override is None:
+            z_vals = self._sample_z(rays_o, rays_d, near, far, t_rand)
+        else:
+            z_vals = z_override.detach().reshape(R, rc.n_total).float()
+        z_feed, _ = torch.sort(torch.cat([z_vals, z_out], dim=-1), dim=-1)
+        sample_dist = 2.0 / self.n_samples
+        bg_alpha, bg_color = B.render_outside(self.nerf, rays_o, rays_d, z_feed, sample_dist)
+        res = _RenderFunction.apply(self, rays_o, rays_d, near, far, None, z_vals, None, 0.0, 0.0, True, *params)
+        color = rc.type == "Color_NeuS"
+        names = [k for k in _OUT_DIFF if color or k not in ("global_color", "delta_relight")] + \
+                [k for k in _SAMPLE_OUT if color or k != "global_color_samples"] + ["inside_sphere", "z_vals", "eik_sums"]
+        f = dict(zip(names, res))
+        inv_s = torch.exp(self.deviation_network.variance * 10.0).clip(1e-6, 1e6)
+        out = B.composite_with_background(rc.type, rays_o, rays_d, z_vals, sample_dist, inv_s, f["sdf_samples"], f["gradients"],
+                                          f["color_samples"], f.get("global_color_samples"), f.get("delta_relight"), bg_alpha, bg_color,
+                                          z_feed, cos_anneal_ratio, bg)
+        out["z_vals"] = z_vals
+        return out
+
+    def _sample_z(self, rays_o, rays_d, near, far, t_rand):
+        """The hierarchical sampler on its own (cnr_sample_z): final z_vals [R, M], no gradient (NeuS.py:343)."""
+        rc, dev = self.rcfg, rays_o.device
+        R = len(rays_o)
+        o, d = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+        nr, fr = near.detach().reshape(-1).contiguous().float(), far.detach().reshape(-1).contiguous().float()
+        z = torch.empty(R, rc.n_total, dtype=torch.float32, device=dev)
+        plist, parr = self._param_array()
+        cin = _lib.CnrInputs(rays_o=_ptr(o), rays_d=_ptr(d), near_=_ptr(nr), far_=_ptr(fr), t_rand=_ptr(t_rand), n_rays=R)
+        nb = self._lib.lib.cnr_ctx_bytes(C.byref(self._ccfg), R)
+        buf = torch.empty(nb, dtype=torch.uint8, device=dev)
+        rcode = self._lib.lib.cnr_sample_z(C.byref(self._ccfg), parr, C.byref(cin), _ptr(z), _ptr(buf), nb, _stream_of(o))
+        self._lib.check(rcode, "cnr_sample_z")
+        return z
 
     # -- evaluation paths (NeuS.py:14-64, 410-420) ---------------------------------------------------------------------
     def _param_array(self):

@@ -74,6 +74,11 @@ typedef struct cnr_render_outputs {
   float* delta_relight;  /* [R][M][3] (Color_NeuS only, else NULL) */
   float* z_vals;         /* [R][M]    */
   float* eik_sums;       /* [2] or NULL: {sum relax*(|g|-1)^2, sum relax} of this call's rays -- lets a ray-sharded run rebuild the global eikonal ratio */
+  /* optional per-sample network outputs, for callers that do their own alpha / compositing (the N_OUTSIDE > 0 background mixing of
+     NeuS.py:262-268 / Color_NeuS.py:97-102 runs above the ABI): */
+  float* sdf_samples;           /* [R][M]    or NULL: sdf at the section midpoints */
+  float* color_samples;         /* [R][M][3] or NULL: the colour that is composited (relit colour for Color_NeuS) */
+  float* global_color_samples;  /* [R][M][3] or NULL: colour-network output before relighting (Color_NeuS only) */
 } cnr_render_outputs;
 
 /* upstream gradients of the outputs; any member may be NULL (= zero) */
@@ -81,6 +86,7 @@ typedef struct cnr_render_out_grads {
   const float* color_fine; const float* s_val; const float* cdf_fine; const float* weight_sum; const float* weight_max;
   const float* gradients; const float* weights; const float* gradient_error; const float* depth;
   const float* global_color; const float* delta_relight;
+  const float* sdf_samples; const float* color_samples; const float* global_color_samples;   /* gradients of the per-sample outputs, or NULL */
   const float* delta_relight_per_ray;   /* [R] or NULL: the gradient of delta_relight when it is constant along a ray and over rgb -- the
                                            relight term of the training loss, mean(delta_relight * mask)^2 (NeuS_Trainer.py:153), yields
                                            exactly that; lets the loss seed the backward pass without an [R][M][3] buffer.  Added to
@@ -173,6 +179,11 @@ size_t cnr_bwd_scratch_bytes(const cnr_config* cfg, int64_t n_rays);
 /* renderer(rays_o, rays_d, near, far) -- NeuS.forward / Color_NeuS.render_core */
 int cnr_render_forward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
                        const cnr_render_outputs* out, void* ctx, size_t ctx_bytes, void* stream);
+
+/* the hierarchical sampler on its own (NeuS.forward up to the render_core call, NeuS.py:309-356): writes the final z_vals [R][M];
+ * ctx is a buffer of cnr_ctx_bytes(cfg, n_rays) bytes used as scratch */
+int cnr_sample_z(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in, float* z_vals, void* ctx, size_t ctx_bytes,
+                 void* stream);
 
 /* autograd backward of cnr_render_forward (loss.backward(), train.py:70): parameter gradients incl. the
  * second-order terms through grad_x SDF, and optionally d rays_o / d rays_d */

@@ -236,6 +236,28 @@ def init_params(cfg: RenderConfig, seed: int = 0, dtype=torch.float32, trained_l
     return {k: v.to(dtype) for k, v in P.items()}
 
 
+def init_nerf_params(seed: int = 0, D=8, W=256, multires=10, multires_view=4, skips=(4,), dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Deterministic synthetic weights of the NeRF++ background network (fields.py:192-274 built with its defaults, NeuS.py:87-91),
+    keyed by the reference's state_dict names ``nerf.*``.  Own recipe (uniform +-1/sqrt(fan_in) from a torch CPU generator), so that
+    fixtures need a seed and a checksum instead of 600 k stored floats."""
+    g = torch.Generator().manual_seed(seed)
+    ch, ch_view = 4 * (1 + 2 * multires), 3 * (1 + 2 * multires_view)
+    P = {}
+
+    def lin(name, i, o):
+        b = 1.0 / math.sqrt(i)
+        P[f"nerf.{name}.weight"] = ((torch.rand(o, i, generator=g, dtype=torch.float64) * 2 - 1) * b).to(dtype)
+        P[f"nerf.{name}.bias"] = ((torch.rand(o, generator=g, dtype=torch.float64) * 2 - 1) * b).to(dtype)
+    lin("pts_linears.0", ch, W)
+    for i in range(D - 1):
+        lin(f"pts_linears.{i + 1}", W + ch if i in skips else W, W)
+    lin("views_linears.0", ch_view + W, W // 2)
+    lin("feature_linear", W, W)
+    lin("alpha_linear", W, 1)
+    lin("rgb_linear", W // 2, 3)
+    return P
+
+
 def params_checksum(P: Dict[str, torch.Tensor]) -> float:
     s = 0.0
     for k in sorted(P):

@@ -16,11 +16,18 @@ CONFIGS = {
         type="NeuS", n_samples=16, n_importance=16,
         sdf=O.SDFConfig(d_out=65, d_hidden=64, n_layers=2, skip_in=[]),
         color=O.ColorConfig(d_feature=64, mode="idr", d_in=9, d_hidden=64, n_layers=2, multires_view=4), relight=None),
+    "tiny_outside": lambda: _outside(O.tiny_config()),
+    "tiny_neus_outside": lambda: _outside(CONFIGS["tiny_neus_sharp"]()),
     "dtu_init": lambda: O.dtu_config(),
     "dtu_sharp": lambda: O.dtu_config(),
     "dtu_noimp_sharp": lambda: _noimp_dtu(),
     "neus_dtu_sharp": lambda: O.RenderConfig(type="NeuS", relight=None),
 }
+
+
+def _outside(c, n=8):
+    c.n_outside = n
+    return c
 
 
 def _noimp():
@@ -51,6 +58,11 @@ def weights_of(name, fx, dtype=torch.float32):
     cfg = CONFIGS[name]()
     stored = {k[2:]: torch.from_numpy(v).to(dtype) for k, v in fx.items() if k.startswith("w:")}
     if stored:
+        if "nerf_seed" in fx:   # NeRF++ background weights: recipe + checksum
+            nerf = O.init_nerf_params(seed=int(fx["nerf_seed"]))
+            cs = O.params_checksum(nerf)
+            assert abs(cs - float(fx["nerf_checksum"])) <= 1e-9 * abs(cs), "nerf weight recipe drifted from the fixture"
+            stored.update({k: v.to(dtype) for k, v in nerf.items()})
         return cfg, stored
     P = O.init_params(cfg, seed=int(fx["weight_seed"]), dtype=torch.float32, trained_like=bool(fx["trained_like"]))
     cs = O.params_checksum(P)

@@ -12,7 +12,7 @@ EMU_LIB = os.path.join(ROOT, "tests", "_build", "libcolorneus_emu.so")
 
 def render_config_from_oracle(ocfg) -> cn.RenderConfig:
     s, c, r = ocfg.sdf, ocfg.color, ocfg.relight
-    kw = dict(type=ocfg.type, n_samples=ocfg.n_samples, n_importance=ocfg.n_importance, up_sample_steps=ocfg.up_sample_steps,
+    kw = dict(type=ocfg.type, n_samples=ocfg.n_samples, n_importance=ocfg.n_importance, n_outside=ocfg.n_outside, up_sample_steps=ocfg.up_sample_steps,
               perturb=ocfg.perturb, sdf_d_out=s.d_out, sdf_d_hidden=s.d_hidden, sdf_n_layers=s.n_layers,
               sdf_skip_in=list(s.skip_in), sdf_multires=s.multires, sdf_bias=s.bias, sdf_scale=s.scale,
               sdf_weight_norm=s.weight_norm, col_d_feature=c.d_feature, col_mode=c.mode, col_d_in=c.d_in,
@@ -43,7 +43,15 @@ def run_native(name, tag, library, device, fixed_z=True, rays_grad=True, nearfar
         near.requires_grad_(True)
         far.requires_grad_(True)
     z = torch.from_numpy(fx[f"{tag}:z_vals"]).to(device) if fixed_z else None
-    if fixed_z:
+    if ocfg.n_outside > 0:
+        # N_OUTSIDE > 0: the background samples take a second draw from the CPU generator (NeuS.py:335) -- replay the fixture's seed
+        # (tools/gen_golden.py: jitter seed 2) instead of patching torch.rand
+        if tag == "jit":
+            torch.manual_seed(2)
+            out = r(o, d, near, far, z_vals=z)
+        else:
+            out = r(o, d, near, far, z_vals=z, perturb_overwrite=0)
+    elif fixed_z:
         out = r(o, d, near, far, z_vals=z)
     elif f"{tag}:t_rand" in fx:
         # feed the fixture's jitter draw through the same CPU-generator call the module makes

@@ -71,8 +71,8 @@ def test_module_mirrors_reference_interface():
     with pytest.raises(AssertionError):           # Color_NeuS.py:14
         bad = dict(cfg); bad["COLOR"] = dict(cfg["COLOR"], MODE="idr")
         cn.ColorNeuSRenderer(wrap(bad))
-    with pytest.raises(NotImplementedError):      # N_OUTSIDE > 0 is outside the accelerated path
-        cn.ColorNeuSRenderer(wrap(dict(cfg, N_OUTSIDE=4)))
+    bgr = cn.ColorNeuSRenderer(wrap(dict(cfg, N_OUTSIDE=4)))      # NeRF++ background: torch fallback with the reference's parameter names
+    assert "nerf.pts_linears.0.weight" in dict(bgr.named_parameters()) and "nerf.rgb_linear.bias" in dict(bgr.named_parameters())
 
 
 def test_register_into_reference_style_registry():

@@ -51,6 +51,20 @@ def test_g2_render_core_forward_backward(name, tag):
         assert G.check_input_grad(fx, tag, key, got) is None, G.check_input_grad(fx, tag, key, got)
 
 
+@pytest.mark.parametrize("name", ["tiny_outside", "tiny_neus_outside"])
+@pytest.mark.parametrize("tag", ["det", "jit"])
+def test_nerfpp_background_fallback(name, tag):
+    """N_OUTSIDE = 8 (a19, fallback form): foreground on the HIP library, NeRF++ background + mixing in torch (background.py)."""
+    fx, r, out, loss, grads, o, d = N.run_native(name, tag, None, DEV, fixed_z=True)
+    for k in G.OUTPUT_KEYS:
+        if f"{tag}:out_{k}" in fx:
+            ref = fx[f"{tag}:out_{k}"]
+            assert G.relerr(out[k].detach().cpu().reshape(ref.shape), ref) < TOL, k
+    assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
+    bad = G.check_param_grads(fx, tag, grads)
+    assert not bad, bad
+
+
 def test_param_grad_error_table():
     """The per-tensor error table of the HIP path on the DTU-size fixtures (what the gate above condenses); written to
     gpurun_out/ so that it can be committed under profiles/."""

@@ -75,6 +75,15 @@ def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0
         return orig(rays_o, rays_d, z_vals, *a, **k)
 
     r.render_core = wrapped
+    if z_override is not None:   # ... and where the background samples are merged in (N_OUTSIDE > 0: z_vals_feed, NeuS.py:360-361)
+        orig_cat = r.cat_z_vals
+
+        def cat(rays_o_, rays_d_, z_vals_, new_z_vals_, sdf_, last=False):
+            zc, sc = orig_cat(rays_o_, rays_d_, z_vals_, new_z_vals_, sdf_, last=last)
+            if last:
+                zc = torch.from_numpy(z_override).to(zc.dtype)
+            return zc, sc
+        r.cat_z_vals = cat
     o = o.to(dtype).clone().requires_grad_(rays_grad)
     d = d.to(dtype).clone().requires_grad_(rays_grad)
     gt, mask = gt.to(dtype), mask.to(dtype)
@@ -85,10 +94,12 @@ def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0
     if jitter_seed is None:
         out = r(o, d, near, far, perturb_overwrite=0)
     elif t_rand is not None:
-        # float64 twin of a jittered run: replay the float32 draw (torch.rand would produce a different, float64, stream)
+        # float64 twin of a jittered run: replay the float32 draws of the same seed, cast (the default dtype stays float32, so the
+        # generator stream -- per-ray jitter, then the background samples when N_OUTSIDE > 0 -- is the float32 run's)
         orig_rand = torch.rand
         try:
-            torch.rand = lambda *a, **k: torch.from_numpy(t_rand).to(dtype).clone()
+            torch.rand = lambda *a, **k: orig_rand(*a, **k).to(dtype)
+            torch.manual_seed(jitter_seed)
             out = r(o, d, near, far)
         finally:
             torch.rand = orig_rand
@@ -125,16 +136,24 @@ def tensor_stride(numel, grad_stride):
     return 1 if numel <= FULL_TENSOR_LIMIT else grad_stride
 
 
-def e2e_fixture(name, cfg, cls, CN, mods, R, weight_seed, trained_like, store_weights, grad_stride):
+def e2e_fixture(name, cfg, cls, CN, mods, R, weight_seed, trained_like, store_weights, grad_stride, n_outside=0):
     node = node_from_config(cfg, CN)
     P = O.init_params(cfg, seed=weight_seed, dtype=torch.float32, trained_like=trained_like)
+    if n_outside > 0:   # NeRF++ background (NeuS.py:87-91): weights from the oracle's recipe (seed + checksum in the fixture)
+        node["N_OUTSIDE"] = n_outside
+        P.update(O.init_nerf_params(seed=weight_seed + 100))
     o, d, gt, mask = make_rays(R, seed=1)
     fx = dict(rays_o=o.numpy(), rays_d=d.numpy(), rgb_gt=gt.numpy(), mask=mask.numpy(),
               weight_seed=np.int64(weight_seed), trained_like=np.int64(trained_like),
-              weight_checksum=np.float64(O.params_checksum(P)), grad_stride=np.int64(grad_stride))
+              weight_checksum=np.float64(O.params_checksum({k: v for k, v in P.items() if not k.startswith("nerf.")})),
+              grad_stride=np.int64(grad_stride), n_outside=np.int64(n_outside))
+    if n_outside > 0:
+        fx["nerf_seed"] = np.int64(weight_seed + 100)
+        fx["nerf_checksum"] = np.float64(O.params_checksum({k: v for k, v in P.items() if k.startswith("nerf.")}))
     if store_weights:
         for k, v in P.items():
-            fx["w:" + k] = v.numpy()
+            if not k.startswith("nerf."):
+                fx["w:" + k] = v.numpy()
     for tag, js in (("det", None), ("jit", 2)):
         res, grads = run_reference(cls, node, P, o, d, gt, mask, js, mods)
         # the same reference code in float64 at the float32 run's sample positions (same jitter draw): per-tensor truth
@@ -303,6 +322,9 @@ def main():
                                color=O.ColorConfig(d_feature=64, mode="idr", d_in=9, d_hidden=64, n_layers=2, multires_view=4),
                                relight=None)
     e2e_fixture("tiny_neus_sharp", tiny_neus, NeuS, CN, mods, R=32, weight_seed=0, trained_like=True, store_weights=True, grad_stride=1)
+    # N_OUTSIDE > 0 (a19): NeRF++ background on the tiny networks, both renderer types
+    e2e_fixture("tiny_outside", O.tiny_config(), Color_NeuS, CN, mods, R=12, weight_seed=0, trained_like=True, store_weights=True, grad_stride=97, n_outside=8)
+    e2e_fixture("tiny_neus_outside", tiny_neus, NeuS, CN, mods, R=12, weight_seed=0, trained_like=True, store_weights=True, grad_stride=97, n_outside=8)
     # C2-like: no importance sampling (z differentiable path not exercised: near/far detached by the harness)
     tiny_noimp = O.tiny_config(); tiny_noimp.n_importance = 0
     e2e_fixture("tiny_noimp_sharp", tiny_noimp, Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=True, store_weights=True, grad_stride=1)
