@@ -268,6 +268,37 @@ struct GenRaysBwd {
 void be_gen_rays(const GenRays& p, cnr_stream s);
 void be_gen_rays_bwd(const GenRaysBwd& p, cnr_stream s);
 
+// ---- iso-surface extraction on the device-resident SDF lattice (replaces the CPU mcubes.marching_cubes call of extract_geometry,
+// NeuS.py:31-40): cell classification + edge ownership, two exclusive scans, vertex / triangle emission
+struct McVolume {
+  const float* u; int res; float thr;      // u[x][y][z], surface where u crosses thr, "inside" = u > thr
+  unsigned char* flags;                    // [res^3] bit a: the edge from this voxel along +axis a crosses the level
+  int* counts;                             // [res^3][2] -> exclusive offsets {vertex, triangle} after mc_scan
+  int* block_sums;                         // [nblocks][2]
+  int* totals;                             // [2] device: number of vertices, number of triangles
+};
+constexpr int kMcScanBlock = 2048;
+void be_mc_count(const McVolume& v, cnr_stream s);    // flags + per-voxel {vertex, triangle} counts, scanned into offsets; totals written
+void be_mc_emit(const McVolume& v, const float* bmin, const float* bmax, float* verts, int* tris, cnr_stream s);
+// shared per-voxel logic (host + device)
+CNR_HD int mc_cell(const float* u, int res, float thr, int x, int y, int z, unsigned char* flags_out) {   // returns the cube index or -1 (no cell)
+  const long r2 = (long)res * res, v = ((long)x * res + y) * res + z;
+  const bool f0 = u[v] > thr;
+  unsigned char fl = 0;
+  if (x + 1 < res && (u[v + r2] > thr) != f0) fl |= 1;
+  if (y + 1 < res && (u[v + res] > thr) != f0) fl |= 2;
+  if (z + 1 < res && (u[v + 1] > thr) != f0) fl |= 4;
+  *flags_out = fl;
+  if (x + 1 >= res || y + 1 >= res || z + 1 >= res) return -1;
+  int idx = 0;
+  for (int c = 0; c < 8; ++c) {
+    const long vc = v + (c & 1) * r2 + ((c >> 1) & 1) * res + ((c >> 2) & 1);
+    idx |= (u[vc] > thr ? 1 : 0) << c;
+  }
+  return idx;
+}
+CNR_HD int mc_popcount3(unsigned x) { return (int)((x & 1) + ((x >> 1) & 1) + ((x >> 2) & 1)); }
+
 // p[row][c] = 0 for c in [c0, c1), row < rows: zero the pad columns a GEMM reads without touching the rest of a wide buffer
 void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream s);
 void be_grid_points(float* pts /*unused*/, cnr_stream s);

@@ -1201,6 +1201,147 @@ void be_gen_rays_bwd(const GenRaysBwd& q, cnr_stream s) {
   CNR_LAUNCH_CHECK("gen_rays_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// marching cubes on the device lattice: the 512^3 volume never leaves HBM between extract_fields and the mesh
+// ------------------------------------------------------------------------------------------------
+}  // namespace cnr
+#define CNR_MC_QUAL static __constant__ const
+#include "cnr_mc_table.h"
+namespace cnr {
+
+__global__ __launch_bounds__(256) void mc_count_kernel(const McVolume m) {
+  const long n = (long)m.res * m.res * m.res;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long)gridDim.x * 256) {
+    const int z = (int)(v % m.res), y = (int)((v / m.res) % m.res), x = (int)(v / ((long)m.res * m.res));
+    unsigned char fl;
+    const int idx = mc_cell(m.u, m.res, m.thr, x, y, z, &fl);
+    m.flags[v] = fl;
+    m.counts[v * 2] = mc_popcount3(fl);
+    m.counts[v * 2 + 1] = idx >= 0 ? kMcNumTris[idx] : 0;
+  }
+}
+// exclusive scan of the two count channels: per-block sums, one workgroup scans the block sums, blocks rescan with their offset
+__global__ __launch_bounds__(256) void mc_block_sum_kernel(const McVolume m, long n) {
+  __shared__ int red[2][4];
+  const long base = (long)blockIdx.x * kMcScanBlock;
+  int a = 0, b = 0;
+  for (int j = threadIdx.x; j < kMcScanBlock; j += 256) { const long v = base + j; if (v < n) { a += m.counts[v * 2]; b += m.counts[v * 2 + 1]; } }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m.block_sums[blockIdx.x * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    m.block_sums[blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+__global__ __launch_bounds__(1024) void mc_scan_sums_kernel(const McVolume m, int nblocks) {
+  __shared__ int wsum[2][16];
+  __shared__ int carry[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 2) carry[tid] = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + tid;
+    int x[2] = {i < nblocks ? m.block_sums[i * 2] : 0, i < nblocks ? m.block_sums[i * 2 + 1] : 0};
+    int incl[2] = {x[0], x[1]};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y0 = __shfl_up(incl[0], d), y1 = __shfl_up(incl[1], d);
+      if (lane >= d) { incl[0] += y0; incl[1] += y1; }
+    }
+    if (lane == 63) { wsum[0][wave] = incl[0]; wsum[1][wave] = incl[1]; }
+    __syncthreads();
+    int woff[2] = {0, 0};
+    for (int w = 0; w < wave; ++w) { woff[0] += wsum[0][w]; woff[1] += wsum[1][w]; }
+    const int c0 = carry[0], c1 = carry[1];
+    if (i < nblocks) { m.block_sums[i * 2] = c0 + woff[0] + incl[0] - x[0]; m.block_sums[i * 2 + 1] = c1 + woff[1] + incl[1] - x[1]; }
+    __syncthreads();
+    if (tid == 1023) { carry[0] = c0 + woff[0] + incl[0]; carry[1] = c1 + woff[1] + incl[1]; }
+    __syncthreads();
+  }
+  if (tid == 0) { m.totals[0] = carry[0]; m.totals[1] = carry[1]; }
+}
+__global__ __launch_bounds__(256) void mc_scan_apply_kernel(const McVolume m, long n) {
+  // one workgroup rescans its 2048-element chunk: 8 elements per thread, wave scan, wave offsets through LDS
+  __shared__ int wsum[2][4];
+  const long base = (long)blockIdx.x * kMcScanBlock + (long)threadIdx.x * 8;
+  int a[8], b[8], sa = 0, sb = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const long v = base + j; a[j] = v < n ? m.counts[v * 2] : 0; b[j] = v < n ? m.counts[v * 2 + 1] : 0; sa += a[j]; sb += b[j]; }
+  int ia = sa, ib = sb;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int ya = __shfl_up(ia, d), yb = __shfl_up(ib, d); if (lane >= d) { ia += ya; ib += yb; } }
+  if (lane == 63) { wsum[0][wave] = ia; wsum[1][wave] = ib; }
+  __syncthreads();
+  int oa = m.block_sums[blockIdx.x * 2] + ia - sa, ob = m.block_sums[blockIdx.x * 2 + 1] + ib - sb;
+  for (int w = 0; w < wave; ++w) { oa += wsum[0][w]; ob += wsum[1][w]; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const long v = base + j; if (v < n) { m.counts[v * 2] = oa; m.counts[v * 2 + 1] = ob; } oa += a[j]; ob += b[j]; }
+}
+void be_mc_count(const McVolume& m, cnr_stream s) {
+  const long n = (long)m.res * m.res * m.res;
+  const int nblocks = (int)((n + kMcScanBlock - 1) / kMcScanBlock);
+  TimingScope ts_("mc_count_scan", 2, 0, n, 0, 0, 0, s, (double)n * (4.0 * 4.0 + 1.0 + 8.0 * 3.0));
+  long cb = (n + 255) / 256; if (cb > 65535 * 4) cb = 65535 * 4;
+  hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)cb), dim3(256), 0, s, m);
+  hipLaunchKernelGGL(mc_block_sum_kernel, dim3(nblocks), dim3(256), 0, s, m, n);
+  hipLaunchKernelGGL(mc_scan_sums_kernel, dim3(1), dim3(1024), 0, s, m, nblocks);
+  hipLaunchKernelGGL(mc_scan_apply_kernel, dim3(nblocks), dim3(256), 0, s, m, n);
+  CNR_LAUNCH_CHECK("mc_count");
+}
+
+struct McEmit { McVolume m; float bmin[3], bmax[3]; float* verts; int* tris; };
+__global__ __launch_bounds__(256) void mc_emit_kernel(const McEmit e) {
+  const McVolume& m = e.m;
+  const int res = m.res;
+  const long r2 = (long)res * res, n = r2 * res;
+  const long stride[3] = {r2, (long)res, 1};
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long)gridDim.x * 256) {
+    const unsigned fl = m.flags[v];
+    const int xyz[3] = {(int)(v / r2), (int)((v / res) % res), (int)(v % res)};
+    if (fl) {   // the vertices on the (up to three) level-crossing edges this voxel owns
+      int k = m.counts[v * 2];
+      const float u0 = m.u[v];
+      for (int a = 0; a < 3; ++a) {
+        if (!((fl >> a) & 1)) continue;
+        const float u1 = m.u[v + stride[a]];
+        const float t = (m.thr - u0) / (u1 - u0);
+        for (int c = 0; c < 3; ++c) {
+          const float g = (float)xyz[c] + (c == a ? t : 0.0f);      // lattice index coordinates, like mcubes' vertices
+          e.verts[(long)k * 3 + c] = g / ((float)res - 1.0f) * (e.bmax[c] - e.bmin[c]) + e.bmin[c];   // NeuS.py:36-39
+        }
+        ++k;
+      }
+    }
+    if (xyz[0] + 1 < res && xyz[1] + 1 < res && xyz[2] + 1 < res) {
+      int idx = 0;
+      for (int c = 0; c < 8; ++c) idx |= (m.u[v + (c & 1) * r2 + ((c >> 1) & 1) * res + ((c >> 2) & 1)] > m.thr ? 1 : 0) << c;
+      const int nt = kMcNumTris[idx];
+      int t0 = m.counts[v * 2 + 1];
+      for (int t = 0; t < nt; ++t) {
+        for (int q = 0; q < 3; ++q) {
+          const int ed = kMcTris[idx][t * 3 + q], a = ed >> 2, kk = ed & 3;
+          const int o0 = a == 0 ? 1 : 0, o1 = a == 2 ? 1 : 2;       // the two other axes in increasing order
+          const long vo = v + (kk & 1) * stride[o0] + (kk >> 1) * stride[o1];
+          e.tris[(long)(t0 + t) * 3 + q] = m.counts[vo * 2] + mc_popcount3(m.flags[vo] & ((1u << a) - 1u));
+        }
+      }
+    }
+  }
+}
+void be_mc_emit(const McVolume& m, const float* bmin, const float* bmax, float* verts, int* tris, cnr_stream s) {
+  McEmit e;
+  e.m = m; e.verts = verts; e.tris = tris;
+  for (int c = 0; c < 3; ++c) { e.bmin[c] = bmin[c]; e.bmax[c] = bmax[c]; }
+  const long n = (long)m.res * m.res * m.res;
+  TimingScope ts_("mc_emit", 2, 0, n, 0, 0, 0, s);
+  long cb = (n + 255) / 256; if (cb > 65535 * 4) cb = 65535 * 4;
+  hipLaunchKernelGGL(mc_emit_kernel, dim3((unsigned)cb), dim3(256), 0, s, e);
+  CNR_LAUNCH_CHECK("mc_emit");
+}
+
 void be_grid_points(float*, cnr_stream) {}
 
 }  // namespace cnr

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "cnr_backend.h"
+#include "cnr_mc_table.h"
 #include "cnr_loss.h"
 #include "cnr_bodies.h"
 
@@ -188,6 +189,53 @@ void be_variance_finish(const VarianceFinish& p, cnr_stream) {
   for (long r = 0; r < p.R; ++r) a += p.partial[r];
   float raw = expf(p.variance[0] * 10.0f);
   *p.d_variance = (raw >= 1e-6f && raw <= 1e6f) ? a * 10.0f * raw : 0.0f;
+}
+
+void be_mc_count(const McVolume& m, cnr_stream) {
+  const int res = m.res;
+  const long n = (long)res * res * res;
+  int vo = 0, to = 0;
+  for (long v = 0; v < n; ++v) {
+    const int z = (int)(v % res), y = (int)((v / res) % res), x = (int)(v / ((long)res * res));
+    unsigned char fl;
+    const int idx = mc_cell(m.u, res, m.thr, x, y, z, &fl);
+    m.flags[v] = fl;
+    m.counts[v * 2] = vo; m.counts[v * 2 + 1] = to;
+    vo += mc_popcount3(fl);
+    to += idx >= 0 ? kMcNumTris[idx] : 0;
+  }
+  m.totals[0] = vo; m.totals[1] = to;
+}
+void be_mc_emit(const McVolume& m, const float* bmin, const float* bmax, float* verts, int* tris, cnr_stream) {
+  const int res = m.res;
+  const long r2 = (long)res * res, n = r2 * res;
+  const long stride[3] = {r2, (long)res, 1};
+  for (long v = 0; v < n; ++v) {
+    const unsigned fl = m.flags[v];
+    const int xyz[3] = {(int)(v / r2), (int)((v / res) % res), (int)(v % res)};
+    int k = m.counts[v * 2];
+    for (int a = 0; a < 3; ++a) {
+      if (!((fl >> a) & 1)) continue;
+      const float u0 = m.u[v], u1 = m.u[v + stride[a]];
+      const float t = (m.thr - u0) / (u1 - u0);
+      for (int c = 0; c < 3; ++c) {
+        const float g = (float)xyz[c] + (c == a ? t : 0.0f);
+        verts[(long)k * 3 + c] = g / ((float)res - 1.0f) * (bmax[c] - bmin[c]) + bmin[c];
+      }
+      ++k;
+    }
+    unsigned char dummy;
+    const int idx = mc_cell(m.u, res, m.thr, xyz[0], xyz[1], xyz[2], &dummy);
+    if (idx < 0) continue;
+    const int t0 = m.counts[v * 2 + 1];
+    for (int t = 0; t < kMcNumTris[idx]; ++t)
+      for (int q = 0; q < 3; ++q) {
+        const int ed = kMcTris[idx][t * 3 + q], a = ed >> 2, kk = ed & 3;
+        const int o0 = a == 0 ? 1 : 0, o1 = a == 2 ? 1 : 2;
+        const long vo = v + (kk & 1) * stride[o0] + (kk >> 1) * stride[o1];
+        tris[(long)(t0 + t) * 3 + q] = m.counts[vo * 2] + mc_popcount3(m.flags[vo] & ((1u << a) - 1u));
+      }
+  }
 }
 
 void be_gen_rays(const GenRays& p, cnr_stream) {

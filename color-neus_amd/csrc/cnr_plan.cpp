@@ -1204,6 +1204,46 @@ int cnr_sdf_grid(const cnr_config* cfg, const float* const* params, const float*
   return sdf_eval_impl(cfg, params, nullptr, bound_min, bound_max, resolution, n, -1.0f, u, scratch, scratch_bytes, (cnr_stream)stream);
 }
 
+static int mc_layout(int32_t res, float thr, const float* u, void* scratch, size_t scratch_bytes, McVolume& v) {
+  if (!u || !scratch) return fail("null argument");
+  if (res < 2 || res > 1290) return fail("marching cubes: resolution must be in [2, 1290]");   // res^3 voxel ids and 2 * res^3 counts stay below 2^31
+  if (scratch_bytes < cnr_mc_scratch_bytes(res)) return fail("marching cubes scratch too small");
+  const size_t n = (size_t)res * res * res;
+  const size_t nblocks = (n + kMcScanBlock - 1) / kMcScanBlock;
+  char* p = static_cast<char*>(scratch);
+  v.u = u; v.res = res; v.thr = thr;
+  v.counts = reinterpret_cast<int*>(p); p += round_up_sz(n * 2 * sizeof(int), 256);
+  v.block_sums = reinterpret_cast<int*>(p); p += round_up_sz(nblocks * 2 * sizeof(int), 256);
+  v.flags = reinterpret_cast<unsigned char*>(p);
+  v.totals = nullptr;
+  return 0;
+}
+
+size_t cnr_mc_scratch_bytes(int32_t resolution) {
+  if (resolution < 2) return 0;
+  const size_t n = (size_t)resolution * resolution * resolution;
+  const size_t nblocks = (n + kMcScanBlock - 1) / kMcScanBlock;
+  return round_up_sz(n * 2 * sizeof(int), 256) + round_up_sz(nblocks * 2 * sizeof(int), 256) + round_up_sz(n, 256);
+}
+
+int cnr_mc_count(const float* u, int32_t resolution, float threshold, void* scratch, size_t scratch_bytes, int32_t* totals, void* stream) {
+  McVolume v;
+  if (mc_layout(resolution, threshold, u, scratch, scratch_bytes, v)) return -1;
+  if (!totals) return fail("null argument");
+  v.totals = totals;
+  be_mc_count(v, (cnr_stream)stream);
+  return check_backend("mc_count");
+}
+
+int cnr_mc_emit(const float* u, int32_t resolution, float threshold, const float* bound_min, const float* bound_max, void* scratch,
+                size_t scratch_bytes, float* vertices, int32_t* triangles, void* stream) {
+  McVolume v;
+  if (mc_layout(resolution, threshold, u, scratch, scratch_bytes, v)) return -1;
+  if (!bound_min || !bound_max || !vertices || !triangles) return fail("null argument");
+  be_mc_emit(v, bound_min, bound_max, vertices, triangles, (cnr_stream)stream);
+  return check_backend("mc_emit");
+}
+
 size_t cnr_vertex_color_scratch_bytes(const cnr_config* cfg, int64_t n_points) {
   Model m;
   if (build_model(cfg, m) || n_points <= 0) return 0;

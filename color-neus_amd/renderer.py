@@ -455,18 +455,31 @@ class NeuSRenderer(nn.Module):
         self._lib.check(rc, "cnr_sdf_grid")
         return u
 
+    def marching_cubes(self, u, bound_min, bound_max, threshold=0.0):
+        """Iso-surface of a device-resident lattice u[x][y][z] (cnr_mc_count / cnr_mc_emit): returns device tensors
+        (vertices [V, 3] float32 in world coordinates, triangles [F, 3] int32)."""
+        u = u.detach().contiguous().float()
+        res = u.shape[0]
+        assert u.shape == (res, res, res)
+        lib = self._lib
+        nb = lib.lib.cnr_mc_scratch_bytes(res)
+        scratch = torch.empty(nb, dtype=torch.uint8, device=u.device)
+        totals = torch.empty(2, dtype=torch.int32, device=u.device)
+        lib.check(lib.lib.cnr_mc_count(_ptr(u), res, float(threshold), _ptr(scratch), nb, _ptr(totals), _stream_of(u)), "cnr_mc_count")
+        nv, nt = (int(x) for x in totals.tolist())     # the one host round trip: the caller owns the output buffers
+        verts = torch.empty(max(nv, 1), 3, dtype=torch.float32, device=u.device)
+        tris = torch.empty(max(nt, 1), 3, dtype=torch.int32, device=u.device)
+        bmin = (C.c_float * 3)(*[float(x) for x in bound_min])
+        bmax = (C.c_float * 3)(*[float(x) for x in bound_max])
+        lib.check(lib.lib.cnr_mc_emit(_ptr(u), res, float(threshold), bmin, bmax, _ptr(scratch), nb, _ptr(verts), _ptr(tris), _stream_of(u)), "cnr_mc_emit")
+        return verts[:nv], tris[:nt]
+
     def extract_geometry(self, bound_min, bound_max, device, resolution, threshold=0.0):
-        u = self.extract_fields(bound_min, bound_max, device, resolution).cpu().numpy()
-        try:
-            import mcubes  # third-party PyMCubes, exactly what the reference calls (NeuS.py:35)
-        except ImportError as e:
-            raise RuntimeError("extract_geometry needs PyMCubes (mcubes.marching_cubes) for the CPU marching-cubes step; "
-                               "use extract_fields() for the device-resident SDF volume") from e
-        vertices, triangles = mcubes.marching_cubes(u, threshold)
-        b_max = np.asarray([float(x) for x in bound_max], dtype=np.float32)
-        b_min = np.asarray([float(x) for x in bound_min], dtype=np.float32)
-        vertices = vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :]
-        return vertices, triangles
+        """NeuS.extract_geometry (NeuS.py:31-40): -sdf on the lattice, iso-surface at ``threshold``; (vertices np (V,3), triangles np (F,3)).
+        The lattice stays in HBM and the surface is extracted there (the reference copies 512 MiB to the host for PyMCubes)."""
+        u = self.extract_fields(bound_min, bound_max, device, resolution)
+        verts, tris = self.marching_cubes(u, bound_min, bound_max, threshold)
+        return verts.cpu().numpy().astype(np.float64), tris.cpu().numpy().astype(np.int64)
 
     def extract_color(self, vertices, device):
         """Per-vertex colour = color_network(pts, g, -g, feat) (NeuS.py:44-64); returns np (V,3)."""

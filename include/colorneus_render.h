@@ -212,6 +212,19 @@ size_t cnr_sdf_grid_scratch_bytes(const cnr_config* cfg, int32_t resolution);
 int cnr_sdf_grid(const cnr_config* cfg, const float* const* params, const float* bound_min, const float* bound_max,
                  int32_t resolution, float* u, void* scratch, size_t scratch_bytes, void* stream);
 
+/* extract_geometry's iso-surface step on the device-resident lattice (NeuS.py:31-40 calls the third-party CPU mcubes.marching_cubes on
+ * a host copy of u): marching cubes over u[x][y][z] at `threshold`, "inside" = u > threshold, vertices on the lattice edges by linear
+ * interpolation, shared between neighbouring cells, already mapped to world coordinates (v / (res - 1) * (bmax - bmin) + bmin,
+ * NeuS.py:36-39), triangle normals pointing out of the u > threshold region.  Triangle table: built by tools/gen_mc_table.py
+ * (no mcubes fixture exists: vertex / triangle ORDER and the resolution of ambiguous faces are this library's own; the surface is
+ * the same piecewise-linear level set).
+ * Two phases because the caller owns the output buffers: cnr_mc_count classifies, scans and leaves {n_vertices, n_triangles} in the
+ * device int32 pair `totals`; after reading them the caller allocates and calls cnr_mc_emit with the same scratch. */
+size_t cnr_mc_scratch_bytes(int32_t resolution);
+int cnr_mc_count(const float* u, int32_t resolution, float threshold, void* scratch, size_t scratch_bytes, int32_t* totals, void* stream);
+int cnr_mc_emit(const float* u, int32_t resolution, float threshold, const float* bound_min /* host [3] */, const float* bound_max /* host [3] */,
+                void* scratch, size_t scratch_bytes, float* vertices /* [V][3] */, int32_t* triangles /* [F][3] */, void* stream);
+
 /* extract_color: rgb = color_network(pts, g, -g, feat) per vertex (NeuS.py:44-64) */
 size_t cnr_vertex_color_scratch_bytes(const cnr_config* cfg, int64_t n_points);
 int cnr_vertex_color(const cnr_config* cfg, const float* const* params, const float* verts, int64_t n_points,
