@@ -90,9 +90,11 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two elements per VALU issue).  On this chip the VALU work of
-// a SIMD does not hide behind its MFMA work -- neither across its two waves nor inside one wave's stream
-// (tools/probes/overlap_probe.hip: 12 MFMAs 223 ns, 192 VALU 307 ns, both 459 ns) -- so the epilogue's instruction count is wall time.
+// Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two elements per VALU issue).  The epilogue of a layer runs
+// with every wave of the workgroup in the same phase (the barriers keep MFMA and epilogue phases in lockstep), so its VALU
+// instruction count is wall time: measured on 2 M points, 6.57 ms = 3.44 ms of MFMA + 3.13 ms of everything else.
+// (tools/probes/overlap_probe.hip: VALU work of one wave does hide behind the MFMAs of the OTHER wave of its SIMD -- 12 MFMAs 223 ns,
+// 96 VALU 334 ns, both 386 ns -- but two workgroups per CU running the same phases at the same time gain nothing from it.)
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -139,8 +141,8 @@ __device__ __forceinline__ void chain_put16(const f32x16& a, float sc, unsigned 
 //   <4, 1>  512 threads, 128 points, one workgroup per CU: least weight traffic (2 KB per point and layer from L2), but MFMA and
 //           epilogue phases of the whole CU alternate in lockstep;
 //   <2, 2>  256 threads, 64 points, two workgroups per CU (74 KB of LDS each) at 4 KB of L2 weight reads per point and layer.
-//           Measured equal to <4, 1> (6.5 ms for 2 M points): MFMA and VALU time of a SIMD add up whichever wave issues them
-//           (tools/probes/overlap_probe.hip), so running one workgroup's epilogue beside the other's MFMAs buys nothing;
+//           Measured equal to <4, 1> (6.5 ms for 2 M points): the two workgroups start together, do identical work and stay in phase
+//           (both in the MFMA phase, then both in the epilogue), also when half of them are started a few microseconds late;
 //   <1, 2>  32-point tiles for small point counts (fills the chip from 8192 points).
 // ------------------------------------------------------------------------------------------------
 template <int RT, int CB>

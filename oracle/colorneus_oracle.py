@@ -12,7 +12,7 @@ dtype, CPU or GPU tensors) of the algorithm the reference implements in
 
 Parity status: PINNED.  tests/test_oracle_golden.py checks every function below
 against golden vectors captured from the imported reference (tools/gen_golden.py,
-fixtures under tests/golden/), and tests/test_oracle_vs_reference.py re-checks
+fixtures under tests/golden/), and tests/test_reference_dropin.py re-checks the drop-in
 live against /root/reference when that checkout is present.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import

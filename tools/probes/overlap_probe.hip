@@ -1,4 +1,5 @@
 // Does VALU work of one wave overlap MFMA work of the other wave on the same SIMD (gfx950)?
+// MI355X: mode 1 223 ns, mode 2 334 ns, mode 3 386 ns (mostly overlapped), mode 4 422 ns per iteration.
 // 512-thread workgroups, one per CU: waves 0..3 = one per SIMD ("M"), waves 4..7 = their SIMD partners ("V").
 //   mode 1: M waves issue MFMAs, V waves idle      mode 2: M idle, V waves issue VALU      mode 3: both
 //   mode 4: every wave interleaves MFMA and VALU in its own stream (half the MFMAs / VALU each)
@@ -28,13 +29,13 @@ __global__ __launch_bounds__(512, 1) void probe(float* out, int iters, int mode,
         for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
     }
     if (do_v) {
-      // 96 VALU instructions per iteration (same count as 12 MFMAs x 32 cycles / 4 cycles)
+      // 96 VALU instructions per iteration: 96 x 4 cycles = the 12 MFMAs x 32 cycles of the M waves
 #pragma unroll
       for (int q = 0; q < 6; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           if (transc && q == 0) v[i] = __builtin_amdgcn_exp2f(v[i]) ;
-          else v[i] = v[i] * 1.0001f + 0.5f;
+          else v[i] = v[i] * 1.0001f;
         }
     }
   }
