@@ -1147,10 +1147,18 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const AdamArgs a) {
   const AdamTensor t = a.t[adam_find_tensor(a, chunk)];
   float coef = 1.0f;
   if (a.max_norm > 0.0f) {
+    // the tensor's chunk sums (<= 17 for the largest layer): one load per lane, folded in a fixed order that is the same in every
+    // workgroup of the tensor (a serial loop of dependent loads costs one L2 round trip per chunk)
+    __shared__ float coef_s;
     const int nch = (int)((t.n + kAdamChunk - 1) / kAdamChunk);
-    float tot = 0.0f;
-    for (int c = 0; c < nch; ++c) tot += a.partial[t.chunk0 + c];   // fixed order, the same in every workgroup of the tensor
-    coef = adam_clip_coef(tot, a.max_norm);
+    if (threadIdx.x < 64) {
+      float part = 0.0f;
+      for (int c = threadIdx.x; c < nch; c += 64) part += a.partial[t.chunk0 + c];
+      part = wave_sum(part);
+      if (threadIdx.x == 0) coef_s = adam_clip_coef(part, a.max_norm);
+    }
+    __syncthreads();
+    coef = coef_s;
   }
   const long i0 = (long)(chunk - t.chunk0) * kAdamChunk;
   for (int j = threadIdx.x; j < kAdamChunk; j += 256) {

@@ -265,7 +265,7 @@ void be_clip_adam(const AdamArgs& a, cnr_stream) {
     const AdamTensor& t = a.t[k];
     float coef = 1.0f;
     if (a.max_norm > 0.0f) {
-      float tot = 0.0f;   // chunk sums in chunk order, like the HIP kernels (the order inside a chunk differs: plain loop here)
+      float tot = 0.0f;   // per-chunk sums, then the chunks (the summation order differs from the HIP kernels': round-off level)
       for (long c0 = 0; c0 < t.n; c0 += kAdamChunk) {
         float ss = 0.0f;
         for (long i = c0; i < t.n && i < c0 + kAdamChunk; ++i) ss += t.g[i] * t.g[i];
