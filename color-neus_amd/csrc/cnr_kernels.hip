@@ -1128,9 +1128,12 @@ void be_rays_grad_finish(const RaysGradFinish& p, cnr_stream s) {
 //   2. every chunk's workgroup folds its OWN tensor's chunk sums in chunk order (<= 17 values) -> clip coefficient -> Adam update.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int adam_find_tensor(const AdamArgs& a, int chunk) {
-  int k = 0;
-  while (k + 1 < a.count && chunk >= a.t[k + 1].chunk0) ++k;
-  return k;
+  int lo = 0, hi = a.count - 1;     // last tensor whose first chunk is <= chunk (binary search: 6 dependent scalar loads, not 53)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.t[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
+  }
+  return lo;
 }
 __global__ __launch_bounds__(256) void clip_norm_kernel(const AdamArgs a) {
   __shared__ float red[4];
