@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, i
     DH_STORE_SLAB(0)
     if (is_y && nslab > 1) DH_LOAD_SLAB(1)
   }
-  __syncthreads();
+  cnr_lds_barrier();
   const int ln = lane & 31, lh = lane >> 5;
   const int xoff = lh * DX_HALF + (ln & 3) * DX_JREG + (wr * 16 + (ln >> 2)) * 16;
   const int yoff = DH_OPER + lh * DX_HALF + (ln & 3) * DX_JREG + (wc * 32 + (ln >> 2)) * 16;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, i
       acc[0][j] = c0; acc[1][j] = c1;
     }
     if (!is_y && s + 1 < nslab) DH_STORE_SLAB(buf ^ 1)
-    __syncthreads();
+    cnr_lds_barrier();
   }
 #undef DH_LOAD_SLAB
 #undef DH_STORE_SLAB
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, i
   if (want_colsum) {
     float* cs = reinterpret_cast<float*>(smem_d);
     if (!is_y) *reinterpret_cast<f4*>(cs + q * 256 + c4 * 4) = csum;
-    __syncthreads();
+    cnr_lds_barrier();
     if (tid < 256 && n0 + tid < g.Npad) g.colsum[chunk * g.Npad + n0 + tid] = ((cs[tid] + cs[256 + tid]) + cs[512 + tid]) + cs[768 + tid];
   }
 }

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     WS_FETCH_TILE(t0)
     WS_PUT_TILE(0, t0)
     if (late && t0 + 1 < t1) WS_FETCH_TILE(t0 + 1)
-    __syncthreads();
+    cnr_lds_barrier();
     for (long t = t0; t < t1; ++t) {
       const int buf = (int)((t - t0) & 1);
       const bool more = t + 1 < t1;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       }
       compute(t, buf);
       if (!late && more) WS_PUT_TILE(buf ^ 1, t + 1)
-      __syncthreads();
+      cnr_lds_barrier();
     }
   } else {
     // two staging sets: tile t0 + j lives in set a for even j, set b for odd j.  Early waves keep tiles t+1 and t+2 in flight,
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     WS_PUT_SET(0, t0, a)
     if (t0 + 1 < t1) WS_FETCH_SET(t0 + 1, b)
     if (late && t0 + 2 < t1) WS_FETCH_SET(t0 + 2, a)
-    __syncthreads();
+    cnr_lds_barrier();
     for (long t = t0; t < t1; t += 2) {
       {   // even tile t (LDS buffer 0): the next tile waits in set b, set a is free
         const bool more = t + 1 < t1;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
         }
         compute(t, 0);
         if (!late && more) WS_PUT_SET(1, t + 1, b)
-        __syncthreads();
+        cnr_lds_barrier();
       }
       if (t + 1 < t1) {   // odd tile t + 1 (LDS buffer 1): the next tile waits in set a, set b is free
         const bool more = t + 2 < t1;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
         }
         compute(t + 1, 1);
         if (!late && more) WS_PUT_SET(0, t + 2, a)
-        __syncthreads();
+        cnr_lds_barrier();
       }
     }
   }

@@ -27,6 +27,15 @@ struct TimingScope {
   ~TimingScope() { timing_end(s); }
 };
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global access of the wave
+// (s_waitcnt vmcnt(0) in front of s_barrier): in the streaming GEMM kernels that makes the tile prefetched for a later iteration
+// land before EVERY barrier, i.e. the prefetch distance can never exceed one iteration.  Those kernels exchange data between waves
+// through LDS only (global data written by a wave is never read by another wave of the same launch), so no global ordering is needed.
+__device__ __forceinline__ void cnr_lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 #define CNR_LAUNCH_CHECK(where)                                   \
   do {                                                            \
     hipError_t e_ = hipGetLastError();                            \
