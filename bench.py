@@ -301,7 +301,7 @@ def main():
         P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in renderer.state_dict().items()}
         ncpu = os.cpu_count() or 1
 
-        def cpu_rate(threads, rays, budget_s, min_it):
+        def cpu_rate(threads, rays, budget_s, min_it, warm=True):
             torch.set_num_threads(threads)
             o, d, near, far, gt, mask = [x[:rays].cpu() for x in batch(0, max(R, rays))]
 
@@ -312,7 +312,8 @@ def main():
                 for p in P.values():
                     p.grad = None
                 l.backward()
-            cstep()
+            if warm:
+                cstep()
             t1 = time.perf_counter()
             n_it = 0
             while n_it < min_it or (time.perf_counter() - t1 < budget_s and n_it < 40):
@@ -328,9 +329,10 @@ def main():
         v1, n1 = cpu_rate(1, 32, 8.0, 1)
         result["cpu_baseline_1thread"] = {"value": round(v1, 2), "unit": "rays/s", "cores": 1, "kind": "port",
                                           "sample": "%d iterations of 32 rays x (64+64) samples, one thread (the reference pins OMP/MKL to 1, train.py:4-8)" % n1}
-        va, na = cpu_rate(ncpu, 64, 0.0, 1)   # (oversubscribed torch CPU ops are slow: one small iteration bounds the run)
+        # torch CPU ops oversubscribe badly on this many threads (0.5 rays/s on 256): one small iteration without warm-up bounds the run
+        va, na = cpu_rate(ncpu, 8, 0.0, 1, warm=False)
         result["cpu_baseline_allcores"] = {"value": round(va, 2), "unit": "rays/s", "cores": ncpu, "kind": "port",
-                                           "sample": "%d iteration of 64 rays x (64+64) samples, torch threads = all %d logical CPUs" % (na, ncpu)}
+                                           "sample": "%d iteration of 8 rays x (64+64) samples, no warm-up, torch threads = all %d logical CPUs" % (na, ncpu)}
 
     if rank == 0:
         print(json.dumps(result))
