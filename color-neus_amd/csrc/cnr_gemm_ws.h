@@ -44,7 +44,7 @@ __device__ __forceinline__ void ws_put4(const f4& v, float sc, unsigned char* ds
 // FULLK promises K > (NKB - 1) * 16, i.e. every k16 block is live: the per-block guards fold away and the LDS fragment reads of the
 // next block can be scheduled across the MFMAs of the current one.
 template <int VK, int EK, bool PLAIN, bool K17 = false, bool FULLK = false>
-__global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const LayerGemm g_in, int tiles_per_wg, int wrows) {
+__global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const LayerGemm g_in, int tiles_per_wg, int wrows, int rev) {
   constexpr int NKB = K17 ? 17 : 16;
   LayerGemm g = g_in;
   if (VK >= 0) g.A.kind = VK;
@@ -58,6 +58,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   if (t0 >= ntiles) return;
   long t1 = t0 + tiles_per_wg;
   if (t1 > ntiles) t1 = ntiles;
+  // rev: this workgroup walks its tile range downwards (WS_TILE maps the loop counter to the tile): consecutive launches of a
+  // chain alternate, so a launch starts on the rows its producer wrote last (still in L2 / MALL)
+  const long tflip = t0 + t1 - 1;
+#define WS_TILE(t_) (rev ? tflip - (t_) : (t_))
   const int nkb = FULLK ? NKB : (g.K + 15) >> 4;   // 1..NKB k16 blocks
   const int kpad = nkb * 16;
   const int ald = kpad * 2 + 16;                // bytes per LDS row of one plane (+16: conflict-free ds_read_b128)
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   r0b = r0a; r1b = r0a; r2b = r0a; r3b = r0a; r4b = r0a;
 #define WS_FETCH_SET(tile_, S_)                                                   \
   {                                                                               \
-    long row_ = (tile_) * WS_TP + srow; if (row_ >= Pn) row_ = Pn - 1;            \
+    long row_ = WS_TILE(tile_) * WS_TP + srow; if (row_ >= Pn) row_ = Pn - 1;            \
     if (pv0) r0##S_ = view_fetch4(g.A, row_, scol);                               \
     if (pv1) r1##S_ = view_fetch4(g.A, row_, 64 + scol);                          \
     if (pv2) r2##S_ = view_fetch4(g.A, row_, 128 + scol);                         \
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     if (K17 && pv4) ws_put4(v4, sc, dst + 512, aplane);                           \
     if ((tid & 15) == 0) {                                                        \
       reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
-      const long prow_ = (tile_) * WS_TP + srow;                                  \
+      const long prow_ = WS_TILE(tile_) * WS_TP + srow;                                  \
       if (g.rs_out && prow_ < Pn) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); /* 0: all-zero row, NaN: non-finite row (must keep poisoning the weight gradient) */ \
     }                                                                             \
   }
@@ -147,7 +151,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   // matrix pipe while the other does prologue math / LDS stores / epilogue.  One barrier per tile.
   const bool late = wave >= 4;
   // MFMAs + epilogue of tile t from LDS buffer buf
-  auto compute = [&](const long t, const int buf) {
+  auto compute = [&](const long tc, const int buf) {
+    const long t = WS_TILE(tc);
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -252,7 +257,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
 #undef WS_FETCH_SET
 #undef WS_PUT_SET
 #undef WS_MFMA
+#undef WS_TILE
 }
+
+inline int ws_next_rev() { static unsigned parity = 0; return (int)(parity++ & 1u); }
 
 template <int VK, int EK, bool PLAIN, bool K17, bool FULLK>
 static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
@@ -270,8 +278,10 @@ static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
   if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN, K17, FULLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
+  static const int ws_serp = getenv("CNR_WS_SERP") ? atoi(getenv("CNR_WS_SERP")) : 1;   // alternate walk direction: +0.35 % (A/B, the last rows of a producer are still in L2)
+  const int rev = ws_serp ? ws_next_rev() : 0;
   TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
-  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN, K17, FULLK>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows);
+  hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN, K17, FULLK>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows, rev);
 }
 
 template <int VK, int EK, bool PLAIN, bool K17 = false>
