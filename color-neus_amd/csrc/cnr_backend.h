@@ -180,8 +180,6 @@ bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s);   // false: not h
 
 void be_layer_gemm(const LayerGemm& g, cnr_stream s);
 void be_dw_gemm(const DwGemm& g, cnr_stream s);
-// common exponent of the split-f16 weight-gradient tiles from the per-point row scales in g.sx / g.sy (see DwGemm); writes *gexp
-void be_dw_scale(const DwGemm& g, int* gexp, cnr_stream s);
 void be_prep_weight(const PrepWeight& p, cnr_stream s);
 // fp32 matrix [rows][ld] -> two f16 planes of the row-scaled matrix (x * 2^e = hi + lo, 22 significand bits) + 1/2^e per row,
 // for the weight-stationary f16-split GEMM (cnr_gemm.hip)

@@ -30,7 +30,6 @@
 
 namespace cnr {
 
-constexpr int CH_THREADS = 512;
 constexpr int CH_ALD = 256 * 2 + 16;   // bytes per LDS row of one plane (+16: conflict-free ds_read_b128 of the fragments)
 
 // ------------------------------------------------------------------------------------------------

@@ -391,8 +391,8 @@ static void launch_dw_bx(const DwGemm& g, int n0, int k0, cnr_stream s) {
 //
 // Along the contraction (points) a scale can only be used if it cancels per point: X'[pt] = X[pt] * sx[pt] (the power of
 // two that lifts the row into the top f16 binade -- emitted for free by the layer GEMM that consumed the same operand,
-// LayerGemm::rs_out) and Y'[pt] = Y[pt] * 2^G / sx[pt], so X'^T Y' = 2^G X^T Y exactly.  G = 1 + min over points of
-// log2(sx * sy) (be_dw_scale) keeps every Y' row below 2^15; points whose product is far below the largest one lose relative
+// LayerGemm::rs_out) and Y'[pt] = Y[pt] * 2^G / sx[pt], so X'^T Y' = 2^G X^T Y exactly.  G = 1 + min over the workgroup's points of
+// log2(sx * sy) keeps every Y' row below 2^15; points whose product is far below the largest one lose relative
 // precision in Y' but their absolute error stays below 2^-40 of the largest term.  Both operands are split hi + lo
 // (11 + 11 bits) and x1 y2 + x2 y1 + x1 y1 is accumulated in fp32; the result is scaled back by 2^-G (exact).
 // Structure, LDS layout and wave phase shift as dw_gemm_bx_kernel (two planes per operand instead of three).
@@ -423,8 +423,34 @@ __global__ __launch_bounds__(512, 1) void dw_gemm_hx_kernel(const DwGemm g_in, i
   const long total_slabs = (g.P + 15) / 16;
   const int nslab_pair = chunk < total_slabs ? (int)((total_slabs - chunk + g.nchunk - 1) / g.nchunk) : 0;
   const int nslab = nslab_pair * g.npairs;
-  int G = *g.gexp;
-  if (G > 250 || G < -250) G = 0;                         // no point with two non-zero rows: everything is zero anyway
+  // exponent of this workgroup's slice of the point range: G = 1 + min log2(sx * sy) over its own points (both pairs, all-zero rows
+  // excluded): no separate reduction launch, and a slice of small-magnitude points keeps its own dynamic range
+  int G = 0x7f7f7f7f;
+  {
+    const int npts = nslab_pair * 16;
+    auto scan = [&](const float* sxp, const float* syp) {   // (no run-time index into g: the struct must stay in registers)
+      for (int i = tid; i < npts; i += 512) {
+        const long pt = ((long)(i >> 4) * g.nchunk + chunk) * 16 + (i & 15);
+        if (pt < p_end) {
+          const float a = sxp[pt], b = syp[pt];   // powers of two (or 0 / NaN): exponent = biased exponent field - 127
+          const int e = (int)((__float_as_uint(a) >> 23) & 0xff) + (int)((__float_as_uint(b) >> 23) & 0xff) - 254 + 1;
+          if (a > 0.0f && b > 0.0f && e < G) G = e;
+        }
+      }
+    };
+    scan(g.sx[0], g.sy[0]);
+    if (g.npairs > 1) scan(g.sx[1], g.sy[1]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(G, d); G = o < G ? o : G; }
+    int* red = reinterpret_cast<int*>(smem_d);
+    if (lane == 0) red[wave] = G;
+    cnr_lds_barrier();
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { const int o = red[w]; G = o < G ? o : G; }
+    cnr_lds_barrier();
+    G = __builtin_amdgcn_readfirstlane(G);                // (uniform: keep it in a scalar register)
+    if (G > 250 || G < -250) G = 0;                       // no point with two non-zero rows: everything is zero anyway
+  }
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -584,47 +610,6 @@ static void launch_dw_hx(const DwGemm& g, int n0, int k0, cnr_stream s) {
   launch_dw_hx_t<-1, -1, -1, -1>(g, n0, k0, s);
 }
 
-// G = 1 + min over points (both pairs) of log2(sx * sy), rows with a zero scale (all-zero rows) excluded.  *gexp must hold a large
-// value on entry (be_dw_scale fills it with 0x7f bytes).  min is order independent, so the atomic keeps results deterministic.
-__device__ __forceinline__ int dw_scale_exp4(const f4& a, const f4& b, int best) {
-  // the scales are powers of two (or 0): exponent = biased exponent field - 127
-  const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ea = (int)((__float_as_uint(av[i]) >> 23) & 0xff), eb = (int)((__float_as_uint(bv[i]) >> 23) & 0xff);
-    const int e = ea + eb - 254 + 1;
-    if (av[i] > 0.0f && bv[i] > 0.0f && e < best) best = e;
-  }
-  return best;
-}
-__global__ void dw_scale_kernel(const float* sx0, const float* sy0, const float* sx1, const float* sy1, long P, int* gexp) {
-  int best = 0x7f7f7f7f;
-  const long P4 = P >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P4; i += (long)gridDim.x * blockDim.x) {
-    best = dw_scale_exp4(reinterpret_cast<const f4*>(sx0)[i], reinterpret_cast<const f4*>(sy0)[i], best);
-    if (sx1) best = dw_scale_exp4(reinterpret_cast<const f4*>(sx1)[i], reinterpret_cast<const f4*>(sy1)[i], best);
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (P & 3)) {   // last 1..3 points
-    const long pt = (P4 << 2) + threadIdx.x;
-    const f4 z = {0.f, 0.f, 0.f, 0.f};
-    f4 a = z, b = z;
-    a.x = sx0[pt]; b.x = sy0[pt];
-    best = dw_scale_exp4(a, b, best);
-    if (sx1) { a.x = sx1[pt]; b.x = sy1[pt]; best = dw_scale_exp4(a, b, best); }
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(best, d); best = o < best ? o : best; }
-  if ((threadIdx.x & 63) == 0 && best != 0x7f7f7f7f) atomicMin(gexp, best);
-}
-
-void be_dw_scale(const DwGemm& g, int* gexp, cnr_stream s) {
-  (void)hipMemsetAsync(gexp, 0x7f, sizeof(int), s);
-  TimingScope ts_("dw_scale", 2, 0, g.P, 0, 0, 0, s);
-  hipLaunchKernelGGL(dw_scale_kernel, dim3(256), dim3(256), 0, s, g.sx[0], g.sy[0], g.npairs > 1 ? g.sx[1] : nullptr,
-                     g.npairs > 1 ? g.sy[1] : nullptr, g.P, gexp);
-  CNR_LAUNCH_CHECK("dw_scale");
-}
-
 // ================================================================================================
 // weight-gradient strips with one very narrow side (<= 8 columns): the 3 / 6 extra input columns of the colour and
 // relight nets, the rgb / sdf output rows.  Pure HBM streams (<= 12 FLOP per loaded byte): no matrix cores, no LDS
@@ -774,7 +759,7 @@ void be_dw_gemm(const DwGemm& g, cnr_stream s) {
             const int hot = gm.X[1].math_split == (1 << 30) ? 0 : gm.X[1].math_split;
             if (hot < n0 || hot >= n0 + 256) gm.npairs = 1;
           }
-          bool scaled = !dw_bf16 && gm.gexp != nullptr;
+          bool scaled = !dw_bf16 && gm.split_f16;
           for (int i = 0; i < gm.npairs; ++i) scaled = scaled && gm.sx[i] != nullptr && gm.sy[i] != nullptr;
           if (dw_fp32) launch_dw<4, 2, 2, 4>(g, n0, k0, s);
           else if (scaled) launch_dw_hx(gm, n0, k0, s);

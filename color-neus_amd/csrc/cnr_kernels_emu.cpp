@@ -45,7 +45,6 @@ void be_loss_grads(const LossArgs& a, const float* coef, float* d_color, float* 
 void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream) {
   for (long r = 0; r < rows; ++r) for (int c = c0; c < c1; ++c) p[r * ld + c] = 0.0f;
 }
-void be_dw_scale(const DwGemm&, int*, cnr_stream) {}   // the emulation accumulates in plain fp32: no operand scaling
 void be_grid_points(float*, cnr_stream) {}
 
 void be_layer_gemm(const LayerGemm& g0, cnr_stream) {

@@ -310,7 +310,6 @@ struct Bwd {   // backward scratch
   std::vector<float*> D, DC, VB, Z2;
   std::vector<float*> rsX0, rsY1;   // row scales of the SDF cotangents z-bar_l (value pair) and q-bar_l (gradient-chain pair)
   float* rsD;                       // row scales of the colour / relight cotangent consumed right after its layer GEMM
-  int* gexp;                        // common exponent of the current split-f16 weight-gradient GEMM
   float* partial;                     // pool of per-layer weight-gradient partial sums
   size_t partial_floats, partial_off;
   std::vector<FinishWeight> pending;  // reductions queued by run_dw, issued as one launch by flush_dw
@@ -360,7 +359,6 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   for (int l = 1; l <= m.L; ++l) b.rsX0[l] = a.f(P);
   for (int l = 1; l < m.L; ++l) b.rsY1[l] = a.f(P);
   b.rsD = a.f(P);
-  b.gexp = reinterpret_cast<int*>(a.f(16));
   a.f(1024);   // slack (see layout_ctx)
 }
 
@@ -679,12 +677,7 @@ static void run_dw(const Model& m, const Lin& q, DwGemm& g, Bwd& b, const float*
   const int need = (g.npairs == 2 && g.X[1].kind == VK_CONST_COL0) ? 1 : g.npairs;
   bool scaled = q.n > 32 && q.k_int > 64;
   for (int i = 0; i < need; ++i) scaled = scaled && g.sx[i] && g.sy[i];
-  if (scaled) {
-    DwGemm t = g;
-    t.npairs = need;
-    be_dw_scale(t, b.gexp, s);
-    g.gexp = b.gexp;
-  }
+  g.split_f16 = scaled;
   be_dw_gemm(g, s);
   FinishWeight f;
   f.partial = part; f.nchunk = b.nchunk; f.npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? csum : nullptr;

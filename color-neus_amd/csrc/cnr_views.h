@@ -366,11 +366,11 @@ struct DwGemm {
   float* partial = nullptr;   // [nchunk][Npad][ldk]
   int Npad = 0, ldk = 0;
   float* colsum = nullptr;    // optional [nchunk][Npad]: column sums of X[0] (bias gradient)
-  // optional per-point row scales of the operands (LayerGemm::rs_out of the launch that consumed the same view) and the common
-  // exponent G = 1 + min over points of log2(sx * sy) (be_dw_scale): with all of them present the 256 x 256 tiles run as f16 x 3
+  // optional per-point row scales of the operands (LayerGemm::rs_out of the launch that consumed the same view).  With all of them
+  // present (split_f16) the 256 x 256 tiles run as f16 x 3; every workgroup takes the exponent G = 1 + min log2(sx * sy) over its own points
   const float* sx[2] = {nullptr, nullptr};
   const float* sy[2] = {nullptr, nullptr};
-  const int* gexp = nullptr;
+  bool split_f16 = false;
 };
 
 // Algorithmic HBM bytes of one launch: every operand matrix read once, every output written once (weights and bias are

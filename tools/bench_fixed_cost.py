@@ -7,4 +7,4 @@ for rays in (32, 128, 512, 2048):
     d = json.loads(out)
     kb = {k["kernel"]: k for k in d["kernel_breakdown"]}
     print("rays %5d  step %.3f ms  kernels %.3f ms  launches %d | " % (rays, d["ms_per_step"], d["kernel_ms_per_step"], d["launches_per_step"]) +
-          "  ".join("%s %.1f us x%d" % (n, 1e3 * kb[n]["ms_per_step"] / kb[n]["launches"], kb[n]["launches"]) for n in ("layer_gemm_ws", "dw_gemm_hx", "layer_gemm", "chain_sdf_value", "dw_scale", "finish_weight", "clip_adam") if n in kb))
+          "  ".join("%s %.1f us x%d" % (n, 1e3 * kb[n]["ms_per_step"] / kb[n]["launches"], kb[n]["launches"]) for n in ("layer_gemm_ws", "dw_gemm_hx", "layer_gemm", "chain_sdf_value", "finish_weight", "clip_adam") if n in kb))
