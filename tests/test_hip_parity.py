@@ -171,11 +171,12 @@ def test_results_do_not_depend_on_scratch_contents():
         assert torch.equal(ref[4][k], got[4][k]), k
 
 
-@pytest.mark.parametrize("switch", ["CNR_DISABLE_WS", "CNR_WS_GENERIC", "CNR_DW_BF16", "CNR_DW_FP32"])
+@pytest.mark.parametrize("switch", ["CNR_DISABLE_WS", "CNR_WS_GENERIC", "CNR_DW_BF16", "CNR_DW_FP32", "CNR_WS_SERP=0"])
 def test_fallback_kernels_keep_parity(switch):
     """The debugging switches select the fallback kernels (FP32-MFMA layer GEMM, interpreted weight-stationary kernel, split-bf16 and
-    FP32-MFMA weight-gradient tiles).  They are read once per process, so the G2 gate runs in a child process."""
-    env = dict(os.environ, **{switch: "1"})
+    FP32-MFMA weight-gradient tiles, one walk direction for every layer launch).  They are read once per process, so the G2 gate runs in a child process."""
+    name, _, val = switch.partition("=")
+    env = dict(os.environ, **{name: val or "1"})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-x", "-m", "gpu",
                         "-k", "test_g2_render_core_forward_backward and sharp and det"], env=env, cwd=root,
