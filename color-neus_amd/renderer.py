@@ -347,6 +347,8 @@ class NeuSRenderer(nn.Module):
         consumes only color_fine and depth, :244-245)."""
         n_rays = len(rays_o)
         dev = rays_d.device
+        if n_rays == 0:
+            return self._empty_batch(dev, background_rgb, cos_anneal_ratio)
         perturb = self.perturb
         if perturb_overwrite >= 0:
             perturb = perturb_overwrite
@@ -372,6 +374,16 @@ class NeuSRenderer(nn.Module):
         ret["z_vals"] = out["z_vals"]       # extra keys (not in the reference dict)
         ret["eik_sums"] = out["eik_sums"]   # {sum relax*(|g|-1)^2, sum relax}: needed by ray-sharded training
         return ret
+
+    def _empty_batch(self, dev, background_rgb, cos_anneal_ratio):
+        """No rays (the reference runs its torch ops on empty tensors): the C ABI takes n_rays > 0, so one dummy ray is rendered without
+        jitter and every output is cut to zero rows -- right shapes and dtypes, gradient_error = 0 / 1e-5 = 0, and exactly-zero gradients for
+        every parameter (the CPU generator is not consumed, as torch.rand([0, 1]) consumes nothing)."""
+        o = torch.tensor([[0.0, 0.0, -3.0]], device=dev)
+        d = torch.tensor([[0.0, 0.0, 1.0]], device=dev)
+        one = self.forward(o, d, torch.full((1, 1), 2.0, device=dev), torch.full((1, 1), 4.0, device=dev), perturb_overwrite=0,
+                           background_rgb=background_rgb, cos_anneal_ratio=cos_anneal_ratio)
+        return {k: (v * 0.0 if v.dim() == 0 or k == "eik_sums" else v[:0]) for k, v in one.items()}
 
     def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
         """NeuS.up_sample (NeuS.py:136-181): n_importance new sample positions per ray from the current z / sdf."""
