@@ -446,6 +446,8 @@ class NeuSRenderer(nn.Module):
         pts = pts.detach().reshape(-1, 3).contiguous().float()
         n = pts.shape[0]
         out = torch.empty(n, 1, dtype=torch.float32, device=pts.device)
+        if n == 0:   # (the C ABI takes n_points > 0)
+            return out
         plist, parr = self._param_array()
         nb = self._lib.lib.cnr_sdf_eval_scratch_bytes(C.byref(self._ccfg), n)
         scratch = torch.empty(nb, dtype=torch.uint8, device=pts.device)
@@ -498,6 +500,8 @@ class NeuSRenderer(nn.Module):
         pts = torch.as_tensor(np.asarray(vertices), dtype=torch.float32, device=torch.device(device)).reshape(-1, 3).contiguous()
         n = pts.shape[0]
         rgb = torch.empty(n, 3, dtype=torch.float32, device=pts.device)
+        if n == 0:
+            return rgb.cpu().numpy()
         plist, parr = self._param_array()
         nb = self._lib.lib.cnr_vertex_color_scratch_bytes(C.byref(self._ccfg), n)
         scratch = torch.empty(nb, dtype=torch.uint8, device=pts.device)

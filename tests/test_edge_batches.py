@@ -62,7 +62,7 @@ def _check(R, library, device, cfg_name):
     for k in G.OUTPUT_KEYS:
         e = G.relerr(out[k].detach().cpu().reshape(oo[k].shape), oo[k].detach())
         assert e < loose.get(k, TOL), (R, k, e)
-    assert abs(float(loss.detach()) - float(l64)) < TOL * max(1.0, abs(float(l64)))
+    assert abs(float(loss.detach()) - float(l64.detach())) < TOL * max(1.0, abs(float(l64.detach())))
     # parameter gradients at each tensor's own scale against float64 (the golden gate's rule: hard cap 1e-3, bulk within
     # max(1e-4, 3 x the reference's own float32 round-off))
     for n_, p in r.named_parameters():
@@ -92,3 +92,37 @@ def test_edge_batches_emu(R):
 @pytest.mark.parametrize("R", [0, 1, 3, 33, 130])
 def test_edge_batches_hip(R):
     _check(R, None, torch.device("cuda:0"), "dtu")
+
+
+def _check_eval_sizes(library, device, cfg_name, sizes):
+    """sdf() / extract_color() at point counts that do not fill a tile, a chain group or a chunk: every prefix of the largest query gives the
+    same values as the full query (rows are independent; the chain kernel picks its tile shape by the point count, so sdf agrees to
+    round-off, 4e-7 measured, not to the bit), the full query matches the oracle, and an empty query returns empty arrays."""
+    from oracle import colorneus_oracle as O
+    ocfg = O.dtu_config() if cfg_name == "dtu" else O.tiny_config()
+    P = O.init_params(ocfg, seed=0, trained_like=True)
+    r = N.make_renderer(ocfg, P, library, device)
+    g = torch.Generator().manual_seed(3)
+    nmax = max(sizes)
+    pts = (torch.rand(nmax, 3, generator=g) * 2.0 - 1.0)
+    full_s = r.sdf(pts.to(device)).cpu()
+    full_c = torch.from_numpy(r.extract_color(pts.numpy(), device))
+    ref_s = O.sdf_value(P, ocfg.sdf, pts[:512])
+    assert G.relerr(full_s[:512], ref_s.reshape(-1, 1)) < TOL
+    for n in sizes:
+        s = r.sdf(pts[:n].to(device)).cpu()
+        c = torch.from_numpy(r.extract_color(pts[:n].numpy(), device))
+        assert s.shape == (n, 1) and c.shape == (n, 3)
+        if n:
+            ds, dc = float((s - full_s[:n]).abs().max()), float((c - full_c[:n]).abs().max())
+            assert ds < 1e-5 and dc < 1e-5, (n, ds, dc)
+
+
+def test_eval_edge_sizes_emu():
+    _check_eval_sizes(N.EMU_LIB, torch.device("cpu"), "tiny", [0, 1, 31, 33, 129, 600])
+
+
+@pytest.mark.gpu
+def test_eval_edge_sizes_hip():
+    # 262144 = one evaluation chunk (cnr_plan.cpp kEvalChunk): one point more starts a second pass
+    _check_eval_sizes(None, torch.device("cuda:0"), "dtu", [0, 1, 31, 33, 127, 129, 4097, 262144, 262145])
