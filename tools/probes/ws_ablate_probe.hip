@@ -67,10 +67,24 @@ __global__ __launch_bounds__(512, 1) void ws_gemm(const float* __restrict__ A, c
 #else
 #define STORE_COND(v) true
 #endif
+#ifdef ABL_TWOACC
+#define COMPUTE(t_, buf_) { f32x16 acc, accx; _Pragma("unroll") for (int j = 0; j < 16; ++j) { acc[j] = 0.f; accx[j] = 0.f; } \
+    const unsigned char* Ab = smem + (buf_) * ABUF + (lane & 31) * ALD + (lane >> 5) * 16; \
+    _Pragma("unroll") for (int kb = 0; kb < KB; kb += 2) { const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + kb * 32); const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + APLANE + kb * 32); \
+      const f16x8 b1 = *reinterpret_cast<const f16x8*>(Ab + (kb + 1) * 32); const f16x8 b2 = *reinterpret_cast<const f16x8*>(Ab + APLANE + (kb + 1) * 32); \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb], acc, 0, 0, 0); accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, w2[kb + 1], accx, 0, 0, 0); \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb], acc, 0, 0, 0); accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2, w1[kb + 1], accx, 0, 0, 0); \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb], acc, 0, 0, 0); accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, w1[kb + 1], accx, 0, 0, 0); } \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) acc[j] += accx[j]; \
+    COMPUTE_TAIL(t_, buf_) }
+#else
 #define COMPUTE(t_, buf_) { f32x16 acc; _Pragma("unroll") for (int j = 0; j < 16; ++j) acc[j] = 0.f; \
     const unsigned char* Ab = smem + (buf_) * ABUF + (lane & 31) * ALD + (lane >> 5) * 16; \
     _Pragma("unroll") for (int kb = 0; kb < KB; ++kb) { const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + kb * 32); const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + APLANE + kb * 32); \
       MFMA3(a1, a2, kb) } \
+    COMPUTE_TAIL(t_, buf_) }
+#endif
+#define COMPUTE_TAIL(t_, buf_) \
     const float* rs = reinterpret_cast<const float*>(smem + (buf_) * ABUF + 2 * APLANE); const int hi = lane >> 5, cl = lane & 31; \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + cl] = acc[r]; \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(512, 1) void ws_gemm(const float* __restrict__ A, c
       f4 v = *reinterpret_cast<const f4*>(T + rr * 36 + cc * 4); \
       v.x = fmaxf(v.x * (rsc * ws4.x) + bias4.x, 0.f); v.y = fmaxf(v.y * (rsc * ws4.y) + bias4.y, 0.f); v.z = fmaxf(v.z * (rsc * ws4.z) + bias4.z, 0.f); v.w = fmaxf(v.w * (rsc * ws4.w) + bias4.w, 0.f); \
       if (row < P && STORE_COND(v)) *reinterpret_cast<f4*>(C + row * 256 + wave * 32 + cc * 4) = v; } \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
   float* T = reinterpret_cast<float*>(smem + 2 * ABUF) + wave * (32 * 36);
   const long t1 = tile0 + tpw;
   LOADT(ra, tile0) STORET(ra, 0)
