@@ -262,6 +262,308 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
 
 inline int ws_next_rev() { static unsigned parity = 0; return (int)(parity++ & 1u); }
 
+// ================================================================================================
+// "Stream" form of the same kernel for the launches that need none of its special cases: K in (240, 256], 256 live output columns
+// whose epilogue takes the 16-byte path in every lane, no tail fill, no split point, a point count that is a multiple of the tile
+// height and known on the host (ws_stream_ok).
+// Same tiles, same arithmetic, same order of operations per output element -- what changes is the control flow around the memory
+// operations: one loop per wave group (early / late), prefetches issued unconditionally (tile index clamped to the range), first
+// iterations peeled.  Every path through a loop then issues the same memory operations in the same order, and the compiler's
+// s_waitcnt bookkeeping stays exact: where a staging register set is consumed it waits for THAT set (vmcnt(8..15)) instead of falling back
+// to vmcnt(0), which made every wave wait once per tile for its just-issued epilogue stores and for the deeper prefetch
+// (tools/probes/ws_depth_probe.hip -> ws_depth3_probe.hip: 0.313 -> 0.280 ms on a plain layer).
+// ================================================================================================
+// Branch-free forms of epi_fetch4 / epi_finish4 for an epilogue without split point and tail fill (the stream kernel's promise): a branch
+// between two memory operations costs the compiler its count of what is still in flight.
+template <int EK>
+__device__ __forceinline__ EpiRaw4 epi_fetch4_plain(const Epi& e, long row, int col) {
+  EpiRaw4 r;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  r.a = zero; r.b = zero;
+  if constexpr (EK == EK_SWEEP) {
+    r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
+    r.b = *reinterpret_cast<const f4*>(e.v + row * e.ldv + col);   // ldv == 0: the broadcast row
+  } else if constexpr (EK == EK_VBACK) {
+    r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
+    r.b = *reinterpret_cast<const f4*>(e.o1 + row * e.ld1 + col);
+  } else if constexpr (EK == EK_RELU_MASK) {
+    r.a = *reinterpret_cast<const f4*>(e.aux + row * e.ldaux + col);
+  }
+  return r;
+}
+template <int EK>
+__device__ __forceinline__ void epi_finish4_plain(const Epi& e, long row, int col, const f4& acc, const f4& b, const EpiRaw4& raw) {
+  if constexpr (EK == EK_SWEEP) {
+    const f4 zz = raw.a, vv = raw.b;
+    f4 o1, o2;
+    o1.x = softplus100_d2(zz.x) * (vv.x * e.vscale) * acc.x; o2.x = softplus100_d1(zz.x) * acc.x;
+    o1.y = softplus100_d2(zz.y) * (vv.y * e.vscale) * acc.y; o2.y = softplus100_d1(zz.y) * acc.y;
+    o1.z = softplus100_d2(zz.z) * (vv.z * e.vscale) * acc.z; o2.z = softplus100_d1(zz.z) * acc.z;
+    o1.w = softplus100_d2(zz.w) * (vv.w * e.vscale) * acc.w; o2.w = softplus100_d1(zz.w) * acc.w;
+    *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o1;
+    *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + col) = o2;
+  } else if constexpr (EK == EK_VBACK) {
+    const f4 zz = raw.a;
+    f4 o = raw.b;
+    o.x = softplus100_d1(zz.x) * (acc.x * e.scale) + o.x;
+    o.y = softplus100_d1(zz.y) * (acc.y * e.scale) + o.y;
+    o.z = softplus100_d1(zz.z) * (acc.z * e.scale) + o.z;
+    o.w = softplus100_d1(zz.w) * (acc.w * e.scale) + o.w;
+    *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
+  } else {
+    epi_finish4(e, row, col, acc, b, raw);
+  }
+}
+
+template <int VK, int EK>
+__global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(const LayerGemm g_in, int tiles_per_wg, int rev) {
+  constexpr int NKB = 16;
+  LayerGemm g = g_in;
+  g.A.kind = VK; g.E.kind = EK;
+  g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long Pn = g.P;                                  // a multiple of the tile height, known on the host (ws_stream_ok)
+  const long ntiles = Pn / WS_TP;
+  const long t0 = (long)blockIdx.x * tiles_per_wg;
+  if (t0 >= ntiles) return;
+  long t1 = t0 + tiles_per_wg;
+  if (t1 > ntiles) t1 = ntiles;
+  const long tflip = t0 + t1 - 1, tlast = t1 - 1;
+#define WSS_TILE(t_) (rev ? tflip - (t_) : (t_))
+  constexpr int kpad = NKB * 16;
+  constexpr int ald = kpad * 2 + 16;
+  constexpr int aplane = WS_TP * ald;
+  constexpr int abuf = 2 * aplane + 128;
+  float* T = reinterpret_cast<float*>(smem_b + 2 * abuf) + wave * (32 * WS_TLD);
+  const int c0 = g.col0 + wave * 32;
+
+  f16x8 w1[NKB], w2[NKB];
+  {
+    const unsigned short* wp = g.Wp + (long)(c0 + (lane & 31)) * g.ldw + (lane >> 5) * 8;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      w1[kb] = *reinterpret_cast<const f16x8*>(wp + kb * 16);
+      w2[kb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 16);
+    }
+  }
+  const f4 wsc = *reinterpret_cast<const f4*>(g.wscale + c0 + (lane & 7) * 4);
+  const int ecol = c0 + (lane & 7) * 4;
+  const f4 bias4 = epi_bias4(g.E, ecol);
+  const int srow = tid >> 4, scol = (tid & 15) * 4;
+  // second staging set (tiles fetched two ahead) where the registers allow it without spilling: the softplus prologue needs the room
+  constexpr bool DEEP = VK == VK_DIRECT && (EK == EK_STORE || EK == EK_RELU || EK == EK_SDF_TOP);
+  Raw4 r0a, r1a, r2a, r3a, r0b, r1b, r2b, r3b;
+  const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+  r0a.a = z4; r0a.b = z4; r1a = r0a; r2a = r0a; r3a = r0a;
+  r0b = r0a; r1b = r0a; r2b = r0a; r3b = r0a;
+  // (tile_ may run past the range: clamped, the redundant fetch / LDS tile of the last iterations is never used)
+#define WSS_FETCH(tile_, S_)                                                      \
+  {                                                                               \
+    const long tq_ = (tile_) < tlast ? (tile_) : tlast;                           \
+    const long row_ = WSS_TILE(tq_) * WS_TP + srow;                               \
+    r0##S_ = view_fetch4(g.A, row_, scol);                                        \
+    r1##S_ = view_fetch4(g.A, row_, 64 + scol);                                   \
+    r2##S_ = view_fetch4(g.A, row_, 128 + scol);                                  \
+    r3##S_ = view_fetch4(g.A, row_, 192 + scol);                                  \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  }
+#define WSS_PUT(buf_, tile_, S_)                                                  \
+  {                                                                               \
+    const f4 v0 = view_finish4(g.A, r0##S_, scol);                                \
+    const f4 v1 = view_finish4(g.A, r1##S_, 64 + scol);                           \
+    const f4 v2 = view_finish4(g.A, r2##S_, 128 + scol);                          \
+    const f4 v3 = view_finish4(g.A, r3##S_, 192 + scol);                          \
+    float mx = fmaxf(fmaxf(ws_absmax4(v0), ws_absmax4(v1)), fmaxf(ws_absmax4(v2), ws_absmax4(v3))); \
+    _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16)); \
+    float sc = 1.0f;                                                              \
+    if (mx > 0.0f && mx < 3.0e38f) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); } \
+    unsigned char* dst = smem_b + (buf_) * abuf + srow * ald + scol * 2;          \
+    ws_put4(v0, sc, dst, aplane);                                                 \
+    ws_put4(v1, sc, dst + 128, aplane);                                           \
+    ws_put4(v2, sc, dst + 256, aplane);                                           \
+    ws_put4(v3, sc, dst + 384, aplane);                                           \
+    if ((tid & 15) == 0) {                                                        \
+      reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
+      const long prow_ = WSS_TILE((tile_) < tlast ? (tile_) : tlast) * WS_TP + srow; \
+      if (g.rs_out) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); \
+    }                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  }
+  const bool late = wave >= 4;
+  constexpr bool EPRE = EK == EK_VBACK || EK == EK_RELU_MASK || EK == EK_SWEEP;
+  EpiRaw4 ern[4];
+  if (EPRE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ern[i] = epi_fetch4_plain<EK>(g.E, WSS_TILE(t0) * WS_TP + (lane >> 3) + 8 * i, ecol);
+  }
+  auto compute = [&](const long tc, const int buf) {
+    const long t = WSS_TILE(tc < tlast ? tc : tlast);
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    const unsigned char* Ab = smem_b + buf * abuf + (lane & 31) * ald + (lane >> 5) * 16;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + kb * 32);
+      const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + aplane + kb * 32);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb], acc, 0, 0, 0);
+    }
+    // (scheduling fences between the phases: the blocks are branch-free now, and an unconstrained scheduler hoists the next phase's loads
+    // across the MFMA block until the register file spills)
+    __builtin_amdgcn_sched_barrier(0);
+    const float* rs = reinterpret_cast<const float*>(smem_b + buf * abuf + 2 * aplane);
+    const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * WS_TLD + cl] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (EPRE) {
+      // side inputs requested one tile ahead (ern): when they are consumed here they are the OLDEST loads in flight, so the wait
+      // leaves the prefetched activation tile and the stores of the previous tiles alone (a load consumed right after its issue is the
+      // youngest one, and the in-order counter then drains everything before it: twice per tile in the general kernel)
+      const long tn = WSS_TILE(tc + 1 < tlast ? tc + 1 : tlast);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = (lane >> 3) + 8 * i, cc = (lane & 7) * 4;
+        const long row = t * WS_TP + rr;
+        const float rsc = rs[rr];
+        f4 v = *reinterpret_cast<const f4*>(T + rr * WS_TLD + cc);
+        v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
+        epi_finish4_plain<EK>(g.E, row, ecol, v, bias4, ern[i]);
+        ern[i] = epi_fetch4_plain<EK>(g.E, tn * WS_TP + rr, ecol);
+      }
+    } else {
+    constexpr int EG = (EK == EK_SWEEP || EK == EK_VBACK) ? 2 : 4;
+#pragma unroll
+    for (int i0 = 0; i0 < 4; i0 += EG) {
+      EpiRaw4 er[EG];
+#pragma unroll
+      for (int i = 0; i < EG; ++i) {
+        er[i] = epi_fetch4_plain<EK>(g.E, t * WS_TP + (lane >> 3) + 8 * (i0 + i), ecol);
+      }
+#pragma unroll
+      for (int i = 0; i < EG; ++i) {
+        const int rr = (lane >> 3) + 8 * (i0 + i), cc = (lane & 7) * 4;
+        const long row = t * WS_TP + rr;
+        const float rsc = rs[rr];
+        f4 v = *reinterpret_cast<const f4*>(T + rr * WS_TLD + cc);
+        v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
+        epi_finish4_plain<EK>(g.E, row, ecol, v, bias4, er[i]);   // (no row test: every tile is full, so no branch sits between the memory operations)
+      }
+    }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // LDS buffer of relative tile j is j & 1.  All waves execute one barrier before the loops and one per tile.
+  if (!DEEP) {
+    WSS_FETCH(t0, a)
+    WSS_PUT(0, t0, a)
+    if (!late) {
+      cnr_lds_barrier();
+      for (long t = t0; t < t1; ++t) {
+        const int buf = (int)((t - t0) & 1);
+        WSS_FETCH(t + 1, a)
+        compute(t, buf);
+        WSS_PUT(buf ^ 1, t + 1, a)
+        cnr_lds_barrier();
+      }
+    } else {
+      WSS_FETCH(t0 + 1, a)
+      cnr_lds_barrier();
+#define WSS_LATE1(t_)                                                             \
+      {                                                                           \
+        const int buf = (int)(((t_) - t0) & 1);                                   \
+        WSS_PUT(buf ^ 1, (t_) + 1, a)                                             \
+        WSS_FETCH((t_) + 2, a)                                                    \
+        compute((t_), buf);                                                       \
+        cnr_lds_barrier();                                                        \
+      }
+      WSS_LATE1(t0)   // peeled: the loop header then only sees the steady state
+      for (long t = t0 + 1; t < t1; ++t) WSS_LATE1(t)
+#undef WSS_LATE1
+    }
+  } else {
+    // two staging sets: relative tile j lives in set a for even j, set b for odd j; early waves keep tiles t + 1 and t + 2 in flight,
+    // late waves t + 2 and t + 3.  Two tiles per trip without a branch in between: the trailing half-trip of an odd range repeats the
+    // last tile (clamped index; these epilogues are plain stores, so writing the same values twice is harmless).
+    WSS_FETCH(t0, a)
+    WSS_PUT(0, t0, a)
+    WSS_FETCH(t0 + 1, b)
+    if (!late) {
+      cnr_lds_barrier();
+#define WSS_EARLY2(t_)                                                            \
+      {                                                                           \
+        WSS_FETCH((t_) + 2, a)                                                    \
+        compute((t_), 0);                                                         \
+        WSS_PUT(1, (t_) + 1, b)                                                   \
+        cnr_lds_barrier();                                                        \
+        WSS_FETCH((t_) + 3, b)                                                    \
+        compute((t_) + 1, 1);                                                     \
+        WSS_PUT(0, (t_) + 2, a)                                                   \
+        cnr_lds_barrier();                                                        \
+      }
+      WSS_EARLY2(t0)
+      for (long t = t0 + 2; t < t1; t += 2) WSS_EARLY2(t)
+#undef WSS_EARLY2
+    } else {
+      WSS_FETCH(t0 + 2, a)
+      cnr_lds_barrier();
+#define WSS_LATE2(t_)                                                             \
+      {                                                                           \
+        WSS_PUT(1, (t_) + 1, b)                                                   \
+        WSS_FETCH((t_) + 3, b)                                                    \
+        compute((t_), 0);                                                         \
+        cnr_lds_barrier();                                                        \
+        WSS_PUT(0, (t_) + 2, a)                                                   \
+        WSS_FETCH((t_) + 4, a)                                                    \
+        compute((t_) + 1, 1);                                                     \
+        cnr_lds_barrier();                                                        \
+      }
+      WSS_LATE2(t0)
+      for (long t = t0 + 2; t < t1; t += 2) WSS_LATE2(t)
+#undef WSS_LATE2
+    }
+  }
+#undef WSS_FETCH
+#undef WSS_PUT
+#undef WSS_TILE
+}
+
+// host-side test for the stream form: every wave has weights and a live 32-column epilogue block, every lane the 16-byte epilogue path
+inline bool ws_stream_ok(const LayerGemm& g, int wrows) {
+  static const bool off = getenv("CNR_WS_NOSTREAM") != nullptr;   // debugging aid: the general kernel for every launch
+  if (off || g.K <= 240 || g.K > 256 || g.P_dev != nullptr || (g.P % WS_TP) != 0) return false;
+  if (g.E.tail_src != nullptr || g.E.split != (1 << 30)) return false;
+  if (g.col0 + 256 > wrows || g.col0 + 256 > g.E.n_out) return false;
+  for (int c = g.col0; c < g.col0 + 256; c += 4) if (!epi_fast4(g.E, c)) return false;
+  return true;
+}
+
+template <int VK, int EK>
+static void launch_ws_stream(const LayerGemm& g, cnr_stream s) {
+  constexpr int abuf = 2 * WS_TP * (16 * 32 + 16) + 128;
+  const size_t lds = (size_t)2 * abuf + (size_t)8 * 32 * WS_TLD * sizeof(float);
+  const long ntiles = (g.P + WS_TP - 1) / WS_TP;
+  if (ntiles == 0) return;
+  static const int ws_wgs = getenv("CNR_WS_WGS") ? atoi(getenv("CNR_WS_WGS")) : 256;
+  long tpw = (ntiles + ws_wgs - 1) / ws_wgs;
+  if (tpw < 1) tpw = 1;
+  const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
+  static DeviceOnce attr_once;   // the opt-in is per device
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_stream_kernel<VK, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  static const int ws_serp = getenv("CNR_WS_SERP") ? atoi(getenv("CNR_WS_SERP")) : 1;
+  const int rev = ws_serp ? ws_next_rev() : 0;
+  TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
+  hipLaunchKernelGGL((layer_gemm_ws_stream_kernel<VK, EK>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, rev);
+}
+
 template <int VK, int EK, bool PLAIN, bool K17, bool FULLK>
 static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
   const int nkb = (g.K + 15) / 16;
@@ -287,6 +589,9 @@ static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
 template <int VK, int EK, bool PLAIN, bool K17 = false>
 static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
   const int nkb = (g.K + 15) / 16;
+  if constexpr (PLAIN && !K17 && VK >= 0 && EK >= 0) {
+    if (ws_stream_ok(g, wrows)) { launch_ws_stream<VK, EK>(g, s); return; }
+  }
   if (nkb == (K17 ? 17 : 16)) launch_ws_tk<VK, EK, PLAIN, K17, true>(g, wrows, s);
   else launch_ws_tk<VK, EK, PLAIN, K17, false>(g, wrows, s);
 }
