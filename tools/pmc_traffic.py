@@ -26,6 +26,12 @@ for k in fetch:
     n = fetch[k][0]
     out[k] = {"launches": n, "fetch_bytes_per_launch": round(2.0 * fetch[k][1] / n), "write_bytes_per_launch": round(write[k][1] / max(write[k][0], 1)),
               "hbm_bytes_per_launch": round(2.0 * fetch[k][1] / n + write[k][1] / max(write[k][0], 1))}
+if "layer_gemm_ws" in out and "layer_gemm_ws_stream" in out:   # one family for bench.py (its timing records do not tell the two forms apart)
+    g, st = out["layer_gemm_ws"], out["layer_gemm_ws_stream"]
+    n = g["launches"] + st["launches"]
+    out["layer_gemm_ws_general"] = g
+    out["layer_gemm_ws"] = {"launches": n, **{f: round((g[f] * g["launches"] + st[f] * st["launches"]) / n)
+                                               for f in ("fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch")}}
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-small-batch --no-torch-gpu-baseline` "
                    "(4096 rays/step); FETCH_SIZE doubled per the gfx950 correction", "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
