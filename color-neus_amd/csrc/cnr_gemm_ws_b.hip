@@ -10,7 +10,15 @@ bool ws_k17_supported(const LayerGemm& g) {
   return plain && g.A.kind == VK_DIRECT && (g.E.kind == EK_RELU || g.E.kind == EK_VBACK);
 }
 
-void launch_layer_gemm_ws(const LayerGemm& g, int wrows, cnr_stream s) {
+void launch_layer_gemm_ws(const LayerGemm& g_in, int wrows, cnr_stream s) {
+  // a launch whose 256 columns all lie below the split point never touches o2: it is a plain launch (the columns at and beyond the split
+  // belong to the narrow launch that follows) and can take the specialised / stream instantiations
+  LayerGemm g = g_in;
+  if (g.E.tail_src == nullptr && g.E.split != (1 << 30) && g.col0 + 256 <= g.E.split &&
+      (g.E.kind == EK_SPLIT || g.E.kind == EK_SDF_TOP || g.E.kind == EK_RELU_MASK || g.E.kind == EK_VBACK)) {
+    g.E.split = 1 << 30;
+    g.E.o2 = nullptr;
+  }
   static const bool generic_only = getenv("CNR_WS_GENERIC") != nullptr;   // debugging aid: interpreted kernel for every combination
   const int vk = g.A.kind, ek = g.E.kind;
   const bool plain = g.E.tail_src == nullptr && g.E.split == (1 << 30);
