@@ -51,7 +51,8 @@ typedef struct cnr_render_inputs {
   const float* t_rand;          /* [R] uniform [0,1) jitter draw (the reference's torch.rand([R,1]), NeuS.py:325) or NULL = no perturb */
   const float* z_vals_override; /* [R][M] or NULL: skip the sampler and render at these z (parity gate G2) */
   const float* background_rgb;  /* [3] or NULL */
-  int64_t n_rays;
+  int64_t n_rays;               /* > 0 (an empty batch is the host layer's business: renderer.py renders it like the reference, as empty
+                                   outputs with zero gradients; the entry points reject n_rays <= 0 with an error) */
   float cos_anneal_ratio;
   float prune_eps;              /* > 0: INFERENCE ONLY early-termination compaction -- the colour / relight networks run only on samples
                                    whose compositing weight is >= prune_eps (pixel error < prune_eps per skipped sample); per-sample
