@@ -62,6 +62,11 @@ __global__ __launch_bounds__(512, 1) void ws_gemm(const float* __restrict__ A, c
 #else
 #define MFMA3(a1, a2, kb) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb], acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb], acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb], acc, 0, 0, 0);
 #endif
+#ifdef ABL_NOFRAG
+#define FRAGKB(kb) ((kb) & 1)
+#else
+#define FRAGKB(kb) (kb)
+#endif
 #ifdef ABL_NOSTORE
 #define STORE_COND(v) ((v).x == 12345.678f)
 #else
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(512, 1) void ws_gemm(const float* __restrict__ A, c
 #else
 #define COMPUTE(t_, buf_) { f32x16 acc; _Pragma("unroll") for (int j = 0; j < 16; ++j) acc[j] = 0.f; \
     const unsigned char* Ab = smem + (buf_) * ABUF + (lane & 31) * ALD + (lane >> 5) * 16; \
-    _Pragma("unroll") for (int kb = 0; kb < KB; ++kb) { const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + kb * 32); const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + APLANE + kb * 32); \
+    _Pragma("unroll") for (int kb = 0; kb < KB; ++kb) { const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + FRAGKB(kb) * 32); const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + APLANE + FRAGKB(kb) * 32); \
       MFMA3(a1, a2, kb) } \
     COMPUTE_TAIL(t_, buf_) }
 #endif
