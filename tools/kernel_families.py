@@ -14,6 +14,11 @@ lines = [sys.argv[3]] if len(sys.argv) > 3 else []
 lines.append("%-24s %8s %14s %12s %7s" % ("family", "calls", "total_ms", "avg_us", "share"))
 for k, (c, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     lines.append("%-24s %8d %14.3f %12.2f %6.1f%%" % (k, c, ns / 1e6, ns / c / 1e3, 100.0 * ns / tot))
+if "layer_gemm_ws" in agg and "layer_gemm_ws_stream" in agg:   # bench.py times both forms of the layer kernel as one family
+    c = agg["layer_gemm_ws"][0] + agg["layer_gemm_ws_stream"][0]
+    ns = agg["layer_gemm_ws"][1] + agg["layer_gemm_ws_stream"][1]
+    lines.append("%-24s %8d %14.3f %12.2f %6.1f%%   (layer_gemm_ws + layer_gemm_ws_stream: the family of bench.py's roofline)" %
+                 ("layer_gemm_ws (both)", c, ns / 1e6, ns / c / 1e3, 100.0 * ns / tot))
 out = "\n".join(lines)
 print(out)
 if len(sys.argv) > 2:
