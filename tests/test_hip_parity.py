@@ -422,3 +422,33 @@ def test_fused_sdf_chain_matches_per_layer_kernels(tmp_path):
         if n <= 20001:
             ref = O.sdf_value(P64, ocfg.sdf, pts.double()).numpy().reshape(-1)
             assert float(np.abs(a.reshape(-1) - ref).max()) < 2e-5 * scale, n
+
+
+_STREAM_CHILD = r"""
+import sys, os
+root, out = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np, torch
+import _native as N
+fx, r, o_, loss, grads, o, d = N.run_native("dtu_sharp", "det", None, torch.device("cuda:0"), fixed_z=True)
+res = {"out:" + k: v.detach().cpu().numpy() for k, v in o_.items() if torch.is_tensor(v)}
+res.update({"g:" + k: v.detach().cpu().numpy() for k, v in grads.items()})
+res["d_o"] = o.grad.cpu().numpy(); res["d_d"] = d.grad.cpu().numpy()
+np.savez(out, **res)
+"""
+
+
+def test_stream_form_of_the_layer_kernel_is_bit_identical(tmp_path):
+    """layer_gemm_ws_stream_kernel (per-wave-group loops, prefetched epilogue inputs; most layer launches of a step) against the general
+    kernel (CNR_WS_NOSTREAM=1, child processes): same tiles, same MFMA order, same epilogue arithmetic -> every output and every gradient
+    of a forward + backward pass must agree to the bit."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("stream", {}), ("general", {"CNR_WS_NOSTREAM": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _STREAM_CHILD, root, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = dict(np.load(path))
+    assert set(res["stream"]) == set(res["general"])
+    for k in sorted(res["stream"]):
+        assert np.array_equal(res["stream"][k], res["general"][k], equal_nan=True), k
