@@ -315,12 +315,22 @@ __device__ __forceinline__ void epi_finish4_plain(const Epi& e, long row, int co
   }
 }
 
-template <int VK, int EK>
+template <int EK, bool GEN>
+__device__ __forceinline__ EpiRaw4 epi_fetch4_sel(const Epi& e, long row, int col) {
+  if constexpr (GEN) return epi_fetch4(e, row, col); else return epi_fetch4_plain<EK>(e, row, col);
+}
+template <int EK, bool GEN>
+__device__ __forceinline__ void epi_finish4_sel(const Epi& e, long row, int col, const f4& acc, const f4& b, const EpiRaw4& raw) {
+  if constexpr (GEN) epi_finish4(e, row, col, acc, b, raw); else epi_finish4_plain<EK>(e, row, col, acc, b, raw);
+}
+
+// GEN: the epilogue keeps its tail fill / split point (skip-connection layers); it then runs the general 16-byte epilogue code per lane.
+template <int VK, int EK, bool GEN = false>
 __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(const LayerGemm g_in, int tiles_per_wg, int rev) {
   constexpr int NKB = 16;
   LayerGemm g = g_in;
   g.A.kind = VK; g.E.kind = EK;
-  g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30;
+  if (!GEN) { g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30; }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long Pn = g.P;                                  // a multiple of the tile height, known on the host (ws_stream_ok)
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
   EpiRaw4 ern[4];
   if (EPRE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ern[i] = epi_fetch4_plain<EK>(g.E, WSS_TILE(t0) * WS_TP + (lane >> 3) + 8 * i, ecol);
+    for (int i = 0; i < 4; ++i) ern[i] = epi_fetch4_sel<EK, GEN>(g.E, WSS_TILE(t0) * WS_TP + (lane >> 3) + 8 * i, ecol);
   }
   auto compute = [&](const long tc, const int buf) {
     const long t = WSS_TILE(tc < tlast ? tc : tlast);
@@ -432,8 +442,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
         const float rsc = rs[rr];
         f4 v = *reinterpret_cast<const f4*>(T + rr * WS_TLD + cc);
         v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
-        epi_finish4_plain<EK>(g.E, row, ecol, v, bias4, ern[i]);
-        ern[i] = epi_fetch4_plain<EK>(g.E, tn * WS_TP + rr, ecol);
+        epi_finish4_sel<EK, GEN>(g.E, row, ecol, v, bias4, ern[i]);
+        ern[i] = epi_fetch4_sel<EK, GEN>(g.E, tn * WS_TP + rr, ecol);
       }
     } else {
     constexpr int EG = (EK == EK_SWEEP || EK == EK_VBACK) ? 2 : 4;
@@ -442,7 +452,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
       EpiRaw4 er[EG];
 #pragma unroll
       for (int i = 0; i < EG; ++i) {
-        er[i] = epi_fetch4_plain<EK>(g.E, t * WS_TP + (lane >> 3) + 8 * (i0 + i), ecol);
+        er[i] = epi_fetch4_sel<EK, GEN>(g.E, t * WS_TP + (lane >> 3) + 8 * (i0 + i), ecol);
       }
 #pragma unroll
       for (int i = 0; i < EG; ++i) {
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
         const float rsc = rs[rr];
         f4 v = *reinterpret_cast<const f4*>(T + rr * WS_TLD + cc);
         v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
-        epi_finish4_plain<EK>(g.E, row, ecol, v, bias4, er[i]);   // (no row test: every tile is full, so no branch sits between the memory operations)
+        epi_finish4_sel<EK, GEN>(g.E, row, ecol, v, bias4, er[i]);   // (no row test: every tile is full, so no branch sits between the memory operations)
       }
     }
     }
@@ -538,13 +548,14 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
 inline bool ws_stream_ok(const LayerGemm& g, int wrows) {
   static const bool off = getenv("CNR_WS_NOSTREAM") != nullptr;   // debugging aid: the general kernel for every launch
   if (off || g.K <= 240 || g.K > 256 || g.P_dev != nullptr || (g.P % WS_TP) != 0) return false;
-  if (g.E.tail_src != nullptr || g.E.split != (1 << 30)) return false;
-  if (g.col0 + 256 > wrows || g.col0 + 256 > g.E.n_out) return false;
+  const int live = g.E.n_out + (g.E.tail_src ? g.E.tail_n : 0);
+  if (g.col0 + 256 > wrows || g.col0 + 256 > live) return false;
   for (int c = g.col0; c < g.col0 + 256; c += 4) if (!epi_fast4(g.E, c)) return false;
   return true;
 }
+inline bool ws_stream_plain(const LayerGemm& g) { return g.E.tail_src == nullptr && g.E.split == (1 << 30); }
 
-template <int VK, int EK>
+template <int VK, int EK, bool GEN>
 static void launch_ws_stream(const LayerGemm& g, cnr_stream s) {
   constexpr int abuf = 2 * WS_TP * (16 * 32 + 16) + 128;
   const size_t lds = (size_t)2 * abuf + (size_t)8 * 32 * WS_TLD * sizeof(float);
@@ -556,12 +567,12 @@ static void launch_ws_stream(const LayerGemm& g, cnr_stream s) {
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
   static DeviceOnce attr_once;   // the opt-in is per device
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_stream_kernel<VK, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_stream_kernel<VK, EK, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   static const int ws_serp = getenv("CNR_WS_SERP") ? atoi(getenv("CNR_WS_SERP")) : 1;
   const int rev = ws_serp ? ws_next_rev() : 0;
   TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
-  hipLaunchKernelGGL((layer_gemm_ws_stream_kernel<VK, EK>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, rev);
+  hipLaunchKernelGGL((layer_gemm_ws_stream_kernel<VK, EK, GEN>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, rev);
 }
 
 template <int VK, int EK, bool PLAIN, bool K17, bool FULLK>
@@ -589,8 +600,8 @@ static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
 template <int VK, int EK, bool PLAIN, bool K17 = false>
 static void launch_ws_t(const LayerGemm& g, int wrows, cnr_stream s) {
   const int nkb = (g.K + 15) / 16;
-  if constexpr (PLAIN && !K17 && VK >= 0 && EK >= 0) {
-    if (ws_stream_ok(g, wrows)) { launch_ws_stream<VK, EK>(g, s); return; }
+  if constexpr (!K17 && VK >= 0 && EK >= 0) {
+    if (ws_stream_ok(g, wrows) && ws_stream_plain(g) == PLAIN) { launch_ws_stream<VK, EK, !PLAIN>(g, s); return; }
   }
   if (nkb == (K17 ? 17 : 16)) launch_ws_tk<VK, EK, PLAIN, K17, true>(g, wrows, s);
   else launch_ws_tk<VK, EK, PLAIN, K17, false>(g, wrows, s);
