@@ -112,6 +112,11 @@ __global__ __launch_bounds__(512, 1) void ws_gemm(const float* __restrict__ A, c
 #else
 #define SPMF(a1, a2, kb) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb], acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb], acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb], acc, 0, 0, 0);
 #endif
+#ifdef ABL_NOFRAG
+#define SPFK(kb) 0
+#else
+#define SPFK(kb) (kb)
+#endif
 constexpr int SP_TBUF = 8 * 32 * 36 * 4;
 __global__ __launch_bounds__(768, 1) void ws_gemm_spec(const float* __restrict__ A, const _Float16* __restrict__ W1, const _Float16* __restrict__ W2,
                                                        const float* __restrict__ wsi, const float* __restrict__ bias, float* __restrict__ C, long P, int tpw) {
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(768, 1) void ws_gemm_spec(const float* __restrict__
       const unsigned char* Ab = smem + (j & 1) * ABUF + (lane & 31) * ALD + (lane >> 5) * 16;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + kb * 32); const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + APLANE + kb * 32);
+        const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + SPFK(kb) * 32); const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + APLANE + SPFK(kb) * 32);
         SPMF(a1, a2, kb)
       }
       float* T = Tb + (j & 1) * (8 * 32 * 36) + wave * (32 * 36);
@@ -164,6 +169,10 @@ __global__ __launch_bounds__(768, 1) void ws_gemm_spec(const float* __restrict__
 #endif
 #define SP_LOAD(R_, t_) if (SPLD(t_)) { const long tq = (t_) < tl ? (t_) : tl; const float* ap = A + (tq * TP + hrow) * 256 + hc; \
       _Pragma("unroll") for (int i = 0; i < 8; ++i) R_[i] = *reinterpret_cast<const f4*>(ap + i * 32); }
+#ifdef ABL_NOHELP
+#define SP_SPLIT(R_, buf_, rsinv_) { rsinv_ = R_[0].x; }
+#define SP_EPI(tb_, t_, rsinv_) { if (rsinv_ == 12345.f) C[0] = rsinv_; }
+#else
 #define SP_SPLIT(R_, buf_, rsinv_) { float mx = 0.f; \
       _Pragma("unroll") for (int i = 0; i < 8; ++i) mx = fmaxf(fmaxf(fmaxf(fabsf(R_[i].x), fabsf(R_[i].y)), fmaxf(fabsf(R_[i].z), fabsf(R_[i].w))), mx); \
       _Pragma("unroll") for (int d = 4; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 8)); \
@@ -177,6 +186,7 @@ __global__ __launch_bounds__(768, 1) void ws_gemm_spec(const float* __restrict__
         v.x = fmaxf(v.x * (rsinv_ * wsc[i].x) + bs[i].x, 0.f); v.y = fmaxf(v.y * (rsinv_ * wsc[i].y) + bs[i].y, 0.f); \
         v.z = fmaxf(v.z * (rsinv_ * wsc[i].z) + bs[i].z, 0.f); v.w = fmaxf(v.w * (rsinv_ * wsc[i].w) + bs[i].w, 0.f); \
         if (SPST(v)) *reinterpret_cast<f4*>(cp + i * 32) = v; } }
+#endif
     float rs0, rs1, rs2 = 1.f;   // 1 / row scale of the tiles in flight (rs_k: relative tile index mod 3 == k)
     SP_LOAD(ra, tile0) SP_LOAD(rb, tile0 + 1)
     SP_SPLIT(ra, 0, rs0)
