@@ -224,7 +224,9 @@ def main():
                 "mfma_peak_tflops": F16_MFMA_PEAK_TFLOPS if f16_tfl else FP32_MFMA_PEAK_TFLOPS,
                 "mfma_note": "f16 MFMA FLOP/s actually issued (3 per fp32-equivalent product) against the 2.5 PFLOP/s dense f16 peak" if f16_tfl
                              else "FP32 MFMA FLOP/s against the FP32 matrix peak",
-                "fp32_equiv_tflops": round(tfl, 2)}
+                "fp32_equiv_tflops": round(tfl, 2),
+                "hbm_note": "peak = 8 TB/s spec; a copy kernel reaches 6.3 TB/s on this chip and the layer kernel's own access pattern (1 KB rows in "
+                            "16-byte pieces, reads and writes mixed) 5.2 TB/s with its MFMAs removed (tools/probes/ws_spec_ablate.hip, DESIGN.md 4.1)"}
         # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed summary
         # of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py)
         traffic, tfile = None, None
