@@ -46,8 +46,13 @@ __global__ __launch_bounds__(512, 1) void ws_gemm(const float* __restrict__ A, c
 #else
 #define LOADT_COND(t_) true
 #endif
+#ifdef ABL_ROWLOAD
+#define LOADT(R_, t_) if (LOADT_COND(t_)) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { long row = ((t_) * TP) + wave * 4 + i; if (row >= P) row = P - 1; \
+    R_[i] = *reinterpret_cast<const f4*>(A + row * 256 + lane * 4); } }
+#else
 #define LOADT(R_, t_) if (LOADT_COND(t_)) { long row = ((t_) * TP) + srow; if (row >= P) row = P - 1; const float* ap = A + row * 256 + sc4 * 4; \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) R_[i] = *reinterpret_cast<const f4*>(ap + i * 64); }
+#endif
 #define STORET(R_, buf_) { float mx = 0.f; \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) mx = fmaxf(fmaxf(fmaxf(fabsf(R_[i].x), fabsf(R_[i].y)), fmaxf(fabsf(R_[i].z), fabsf(R_[i].w))), mx); \
     _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16)); \
