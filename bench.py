@@ -97,13 +97,14 @@ def main():
     cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)   # Color_NeuS_dtu.yml
     torch.manual_seed(0)
     renderer = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(dev)
-    params = list(renderer.parameters())
+    params0 = params = list(renderer.parameters())
     lib = cn.load_library()
     assert lib.backend == "hip-gfx950"
     if args.torch_optim:
         opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.99), fused=True)
     else:   # config/Color_NeuS_dtu.yml: adam, LR 5e-4, GRAD_CLIP NORM 1.0 TYPE 2 per parameter tensor
         opt = cn.ClipAdam(renderer._ordered_params(), lr=5e-4, betas=(0.9, 0.99), eps=1e-8, max_norm=1.0, library=lib)
+    opt0 = opt
 
     if args.scaling == "strong":
         if args.rays_total % world:
@@ -122,11 +123,13 @@ def main():
 
     torch.manual_seed(2)   # jitter stream (CPU generator, like the reference)
 
-    def step(i, r=None):
+    def step(i, r=None, alt=None):
         r = R if r is None else r
         rg = r * world
         o, d, near, far, gt, mask = batch(i, r)
-        out = renderer(o, d, near, far)
+        rnd, params, opt = alt if alt is not None else (renderer, params0, opt0)
+        M = rnd.rcfg.n_total
+        out = rnd(o, d, near, far)
         if args.torch_loss:    # the torch restatement of compute_loss (and its sharded counterpart)
             if world == 1:
                 loss, _ = cn.compute_loss(out, gt, mask)
@@ -151,13 +154,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed(nsteps, warmup, r=None):
+    def timed(nsteps, warmup, r=None, alt=None):
         for i in range(warmup):
-            step(i, r)
+            step(i, r, alt)
         sync()
         t0 = time.perf_counter()
         for i in range(nsteps):
-            loss = step(warmup + i, r)
+            loss = step(warmup + i, r, alt)
         sync()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -264,6 +267,16 @@ def main():
             dts, _ = timed(n, 5, r)
             small[str(r)] = round(r * world * n / dts, 1)
         result["small_batch"] = {"unit": "rays/s", "rays_per_step_per_gpu": small}
+        # BASELINE config 2 as written: DTU network, 512 rays per batch x 64 samples, no importance sampling
+        cfg2 = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0, n_samples=64, n_importance=0)
+        r2 = cn.ColorNeuSRenderer(cfg2).to(dev)
+        r2.load_state_dict(renderer.state_dict())
+        opt2 = (torch.optim.Adam(list(r2.parameters()), lr=5e-4, betas=(0.9, 0.99), fused=True) if args.torch_optim
+                else cn.ClipAdam(r2._ordered_params(), lr=5e-4, betas=(0.9, 0.99), eps=1e-8, max_norm=1.0, library=lib))
+        alt = (r2, list(r2.parameters()), opt2)
+        n = max(20, min(args.steps, 60))
+        dts, _ = timed(n, 5, 512, alt)
+        result["small_batch"]["c2_512rays_x_64samples_no_importance"] = round(512 * world * n / dts, 1)
 
     # ---- the plain-PyTorch restatement on the same GPU (the 'reference single-GPU PyTorch' stand-in), bounded sample
     if not args.no_torch_gpu_baseline and rank == 0:
