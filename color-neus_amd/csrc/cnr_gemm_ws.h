@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 
 #include "cnr_backend.h"
@@ -260,7 +261,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
 #undef WS_TILE
 }
 
-inline int ws_next_rev() { static unsigned parity = 0; return (int)(parity++ & 1u); }
+// walk-direction parity of consecutive layer launches: process-wide, atomic (host threads may launch concurrently); it only picks the
+// order in which a launch visits its tiles, never a value
+inline int ws_next_rev() { static std::atomic<unsigned> parity{0}; return (int)(parity.fetch_add(1u, std::memory_order_relaxed) & 1u); }
 
 // ================================================================================================
 // "Stream" form of the same kernel for the launches that need none of its special cases: K in (240, 256], 256 live output columns

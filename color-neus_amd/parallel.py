@@ -3,9 +3,10 @@
 The reference is single-GPU only (train.py:111).  Rays are independent, so the path shards without any data-path
 collective; exact equality with the single-GPU objective needs two exchanges per step:
 
-  1. before backward, one all-reduce(sum) of 3 floats {sum relax*(|g|-1)^2, sum relax, sum delta_relight(*mask)}
-     because the eikonal term is a ratio of global sums (Color_NeuS.py:122-123) and the relight term the square of a
-     global mean (NeuS_Trainer.py:153);
+  1. before backward, one small all-reduce(sum): 3 floats {sum relax*(|g|-1)^2, sum relax, sum delta_relight(*mask)} in
+     sharded_loss below (torch loss; the separable terms are normalised locally), 5 floats in loss.compute_loss_fused
+     (the three cnr_loss_sums + the two eikonal sums) -- needed because the eikonal term is a ratio of global sums
+     (Color_NeuS.py:122-123) and the relight term the square of a global mean (NeuS_Trainer.py:153);
   2. after backward, ONE flat-bucket all-reduce(sum) of all parameter gradients (3.83 MiB for Color_NeuS) -- RCCL over
      xGMI on MI355X (backend "nccl"), gloo in the CPU tests -- placed before the per-parameter clip (train.py:72-73).
 """
@@ -41,7 +42,7 @@ def sharded_loss(out, rgb_gt, mask, n_rays_global, n_samples, group=None, lambda
     if lambda_mask != 0 and mask is not None:
         ws = out["weight_sum"].squeeze(-1).clip(1e-3, 1.0 - 1e-3)
         local = local + lambda_mask * (-(mask * torch.log(ws) + (1 - mask) * torch.log(1 - ws)).sum() / n_rays_global)
-    # ---- statistics of the non-separable terms: one 3-float all-reduce before backward
+    # ---- statistics of the non-separable terms: one 3-float all-reduce before backward (the fused loss sends 5, see loss.py)
     has_rel = lambda_relight != 0 and "delta_relight" in out
     dr_sum = None
     stats = torch.zeros(3, dtype=torch.float32, device=dev)

@@ -11,7 +11,10 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise; the caller owns all memory
- *     (outputs, context, scratch); the library allocates nothing and keeps no state between calls
+ *     (outputs, context, scratch); the library allocates nothing.  No RESULT depends on state kept between calls; what the
+ *     process does keep: the first-error latch behind cnr_last_error(), the optional timing records (cnr_timing_enable), debug
+ *     switches read once from the environment (CNR_*), the per-(kernel, device) "dynamic LDS opt-in applied" flags, and an
+ *     atomic launch counter whose parity only picks the order in which a layer launch walks its tiles (speed, never a value)
  *   - all work is enqueued on the given hipStream_t (passed as void*); no internal synchronisation
  *   - return value: 0 on success, negative on error; cnr_last_error() returns a message for the calling thread
  *   - parameters are passed as an array of device pointers in the canonical order reported by cnr_param_info()
@@ -107,7 +110,7 @@ typedef struct cnr_kernel_timing {
   char name[32];
   int32_t kind;     /* 0 = layer GEMM, 1 = weight-gradient GEMM, 2 = other */
   int32_t nt;       /* tile variant */
-  long P;           /* points (rows) or rays */
+  int64_t P;        /* points (rows) or rays */
   int32_t N, K, pairs;
   float ms;
   double bytes;     /* algorithmic HBM bytes of the launch (operands read once + outputs written once); 0 = not modelled */

@@ -100,9 +100,23 @@ def grad_tolerance(spread):
 
 
 GRAD_OUTLIER_FRAC = 0.25    # share of a tensor's entries that may exceed the bulk tolerance (never the cap), see check_param_grads
+# The HIP path (the product) is held to what profiles/r0x_param_grad_error_table.txt measures for it (strict=True below): per tensor at
+# most max(STRICT_OUTLIER_MIN, 1 %) of the compared entries above the bulk tolerance -- the kink argument of check_param_grads predicts a
+# handful, never a column block -- and a hard cap of 5e-4 of the tensor's own largest entry.  The loose constants above remain for the
+# CPU-emulation build and the float32 torch oracle (test infrastructure whose ReLU decisions round differently on the 16-ray fixtures).
+STRICT_OUTLIER_FRAC, STRICT_OUTLIER_MIN, STRICT_TOL_CAP = 0.01, 2, 5e-4
 
 
-def param_grad_table(fx, tag, grads):
+def _gate(strict):
+    return (STRICT_OUTLIER_FRAC, STRICT_OUTLIER_MIN, STRICT_TOL_CAP) if strict else (GRAD_OUTLIER_FRAC, 1, GRAD_TOL_CAP)
+
+
+def _allowed(n, strict):
+    frac, floor, _ = _gate(strict)
+    return max(floor, int(frac * n)) if n > 1 else 0
+
+
+def param_grad_table(fx, tag, grads, strict=False):
     """Per-tensor comparison of full gradient tensors ``grads`` (name -> tensor) with the fixture.  Rows:
     (name, numel, err64, err32, tol, sum_err, abs_err, n_over, err_bulk) -- err64 / err32: max-abs error vs the float64 / float32
     reference entries stored in the fixture (all entries for tensors <= FULL_TENSOR_LIMIT, every grad_stride-th beyond),
@@ -126,13 +140,13 @@ def param_grad_table(fx, tag, grads):
         sum_err = abs(float(full.sum()) - float(fx[f"{tag}:gsum64:{k}"])) / gabs
         abs_err = abs(float(full.abs().sum()) - float(fx[f"{tag}:gabs64:{k}"])) / gabs
         lim = grad_tolerance(fx[f"{tag}:gspread:{k}"])
-        allowed = max(1, int(GRAD_OUTLIER_FRAC * e.size)) if e.size > 1 else 0
+        allowed = _allowed(e.size, strict)
         bulk = float(np.sort(e)[-(allowed + 1)]) if e.size > allowed else 0.0
         rows.append((k, full.numel(), err64, err32, lim, sum_err, abs_err, int((e > lim).sum()), bulk))
     return rows
 
 
-def check_param_grads(fx, tag, grads, tol=None):
+def check_param_grads(fx, tag, grads, tol=None, strict=False):
     """Gate on every parameter-gradient tensor at its OWN scale against the float64 reference:
       * HARD: every compared entry within GRAD_TOL_CAP (1e-3) of the tensor's largest entry;
       * BULK: at least 1 - GRAD_OUTLIER_FRAC of the entries within grad_tolerance (1e-4, or 3x the reference's own float32 round-off on
@@ -144,18 +158,39 @@ def check_param_grads(fx, tag, grads, tol=None):
     an implementation rounds to, that single sample's whole contribution moves: one entry of the layer's own bias / weight gradient
     by up to 6e-4 of the tensor max on these 16-ray fixtures, and a fraction of the entries of the layers below it by 1e-4..3e-4.
     No float32 implementation is exempt (the derivative is discontinuous there); the cap bounds the effect.
-    Returns the offending rows.  ``tol`` (optional) raises the floor of the bulk tolerance."""
+    Returns the offending rows.  ``tol`` (optional) raises the floor of the bulk tolerance.  ``strict``: the HIP gate (constants above)."""
     bad = []
-    for k, n, err64, err32, lim, sum_err, abs_err, n_over, bulk in param_grad_table(fx, tag, grads):
+    cap = _gate(strict)[2]
+    for k, n, err64, err32, lim, sum_err, abs_err, n_over, bulk in param_grad_table(fx, tag, grads, strict):
         if tol is not None:
-            lim = min(GRAD_TOL_CAP, max(lim, tol))
+            lim = min(cap, max(lim, tol))
+        lim = min(lim, cap)
         slim = min(GRAD_TOL_CAP, 3.0 * lim)   # sums: same-sign round-off adds up over the entries while sum(|g|) can be far below n * max
-        if not (err64 <= GRAD_TOL_CAP and bulk <= lim and sum_err <= slim and abs_err <= slim):
+        if not (err64 <= cap and bulk <= lim and sum_err <= slim and abs_err <= slim):
             bad.append((k, err64, bulk, lim, sum_err, abs_err))
     return bad
 
 
-def check_input_grad(fx, tag, key, got):
+def check_grads_full(ref64, ref32, got, strict=True):
+    """EVERY entry of every gradient tensor (no stride) against a float64 evaluation ``ref64`` (name -> tensor) of the same algorithm
+    at the same inputs -- the oracle run live by the GPU tests; ``ref32`` is its float32 evaluation, whose distance from float64
+    calibrates the per-tensor tolerance exactly like the fixtures' ``gspread``.  Same rule as check_param_grads.  Returns offenders."""
+    bad = []
+    cap = _gate(strict)[2]
+    for k, r64 in ref64.items():
+        r64 = r64.detach().double().reshape(-1)
+        den = max(float(r64.abs().max()), 1e-300)
+        e = (got[k].detach().cpu().double().reshape(-1) - r64).abs() / den
+        spread = float((ref32[k].detach().double().reshape(-1) - r64).abs().max()) / den
+        lim = min(cap, grad_tolerance(spread))
+        allowed = _allowed(e.numel(), strict)
+        bulk = float(torch.sort(e).values[-(allowed + 1)]) if e.numel() > allowed else 0.0
+        if not (float(e.max()) <= cap and bulk <= lim):
+            bad.append((k, float(e.max()), bulk, lim, int((e > lim).sum())))
+    return bad
+
+
+def check_input_grad(fx, tag, key, got, strict=False):
     """d rays_o / d rays_d / d near / d far against the float64 reference at own scale under the same rule as check_param_grads
     (hard cap on every entry, bulk tolerance from the reference's own float32 spread measured from the two stored runs).
     Returns None when within the gate, else (key, err_max, err_bulk, tol)."""
@@ -163,10 +198,11 @@ def check_input_grad(fx, tag, key, got):
     den = max(float(np.abs(ref64).max()), 1e-300)
     spread = float(np.abs(ref32.astype(np.float64) - ref64).max()) / den
     e = np.abs(torch.as_tensor(got).detach().cpu().double().numpy().reshape(ref64.shape) - ref64).reshape(-1) / den
-    lim = grad_tolerance(spread)
-    allowed = max(1, int(GRAD_OUTLIER_FRAC * e.size))
+    cap = _gate(strict)[2]
+    lim = min(cap, grad_tolerance(spread))
+    allowed = max(1, _allowed(e.size, strict))
     bulk = float(np.sort(e)[-(allowed + 1)])
-    if float(e.max()) <= GRAD_TOL_CAP and bulk <= lim:
+    if float(e.max()) <= cap and bulk <= lim:
         return None
     return key, float(e.max()), bulk, lim
 
