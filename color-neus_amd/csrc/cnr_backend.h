@@ -26,7 +26,8 @@ struct PrepWeight {
 // dW partial reduction + weight-norm backward + un-permutation
 struct FinishWeight {
   const float* partial = nullptr; int nchunk = 0; int npad = 0; int ldk = 0;   // [nchunk][npad][ldk]
-  const float* colsum = nullptr;                                             // [nchunk][npad] or null
+  const float* colsum = nullptr;                                             // [ncolsum][npad] or null
+  int ncolsum = 0;            // slots that carry column sums (the first group of a region); 0 with colsum != null means nchunk
   const float* g = nullptr; const float* v = nullptr;
   int n = 0, k_ref = 0;
   int nseg = 0; Segment seg[4];
@@ -180,6 +181,11 @@ bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s);   // false: not h
 
 void be_layer_gemm(const LayerGemm& g, cnr_stream s);
 void be_dw_gemm(const DwGemm& g, cnr_stream s);
+// Layer launch g + the single-pair weight gradient d (X[0] = the launch's input view, Y[0] = the operand its epilogue derives from its side
+// inputs, see DwFuse in cnr_views.h) with d.partial / d.colsum laid out in kFdwSlots slots.  Callers test be_fdw_enabled() && fdw_shape_ok(g)
+// first; the backend may still run the two parts as separate launches (same results, same slots).
+bool be_fdw_enabled();
+void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s);
 void be_prep_weight(const PrepWeight& p, cnr_stream s);
 // fp32 matrix [rows][ld] -> two f16 planes of the row-scaled matrix (x * 2^e = hi + lo, 22 significand bits) + 1/2^e per row,
 // for the weight-stationary f16-split GEMM (cnr_gemm.hip)

@@ -1,0 +1,391 @@
+// Layer GEMM + weight gradient in one launch for gfx950 (MI355X / CDNA4).
+//
+// Why: in the backward pass every 256 -> 256 layer used to cost two passes over the same rows: the layer launch (cotangent through W^T,
+// or the second-order sweep through W) and, later, the weight-gradient GEMM that reads the launch's input AND the tensor its epilogue had
+// already fetched as a side input (2 - 3 KB per point and layer again, 23 % of a training step).  Here the weight gradient is formed
+// while both operands are on chip.
+//
+// The obstacle is the register file: a 256 x 256 layer as two f16 planes is 256 KB, a 256 x 256 fp32 accumulator another 256 KB, and a CU
+// has 512 KB.  So a launch is split into COLUMN HALVES: a workgroup owns 128 output columns (weights: 128 KB) and the matching
+// [256 x 128] block of dW (128 KB); the two halves of a point range run on the same XCD (blocks b and b + 8), so the second read of the
+// input tile is an L2 hit.  Inside a workgroup the waves are specialised (one of each kind per SIMD):
+//   waves 0..3 "P"  weight-stationary layer product of their 32 columns (3 x v_mfma_f32_32x32x16_f16 per k16 block, as cnr_gemm_ws.h),
+//                   fused epilogue with 16-byte global accesses, and -- from the side inputs the epilogue fetched anyway -- the tile of the
+//                   epilogue-side operand Ep, scaled and split hi / lo, written TRANSPOSED ([column][point]) into LDS;
+//   waves 4..7 "D"  stage the input tile S (HBM -> registers -> exact power-of-two row scale -> f16 hi / lo planes in LDS, the operand of
+//                   the P waves), and accumulate C[s][e] += sum_pt S'[pt][s] * Ep'[pt][e] for the tile the P waves finished one
+//                   iteration earlier: S' fragments are gathered from the row-major planes (8 two-byte reads per fragment), Ep' fragments
+//                   are 16-byte reads of the transposed tile; 64 x 128 outputs per wave = 128 accumulator registers.
+// Per 32-point tile and SIMD: 48 + 48 MFMAs.  One workgroup barrier per tile; three input-tile buffers (stage t + 1 | product t | dW t - 1).
+//
+// Scaling of the split-f16 weight gradient (same scheme as dw_gemm_hx_kernel): S' = S * ss[pt] are the planes the layer product uses
+// anyway; Ep' = Ep * 2^G / ss[pt], so S'^T Ep' = 2^G S^T Ep exactly.  G = 1 + min over the points seen so far of log2(ss * se) (se: the
+// row scale of Ep saved by the forward pass) is a RUNNING minimum: when a tile lowers it the accumulators are rescaled by the exact
+// power of two (wave-uniform, rare after the first tiles).  Fixed summation order per (range, half): bitwise deterministic.
+#include "cnr_gemm_ws.h"
+
+namespace cnr {
+
+constexpr int FD_TP = 32;                        // points per tile
+constexpr int FD_ALD = 256 * 2 + 16;             // bytes per LDS row of one S plane (+16: conflict-free ds_read_b128 of the product fragments)
+constexpr int FD_APLANE = FD_TP * FD_ALD;
+constexpr int FD_ABUF = 2 * FD_APLANE + 256;     // two planes + rs[32] (1 / row scale) + ss[32] (row scale; 0 / NaN: zero / non-finite row)
+constexpr int FD_YLD = 80;                       // bytes per column of one Ep' plane: 32 points x 2 B + 16 (conflict-free ds_read_b128)
+constexpr int FD_YPLANE = 128 * FD_YLD;
+constexpr int FD_YBUF = 2 * FD_YPLANE;
+constexpr int FD_TLD = 36;
+constexpr int FD_TBYTES = 32 * FD_TLD * 4;       // accumulator transposition buffer of one P wave
+constexpr int FD_OFF_Y = 3 * FD_ABUF;
+constexpr int FD_OFF_T = FD_OFF_Y + 2 * FD_YBUF;
+constexpr int FD_OFF_INFO = FD_OFF_T + 4 * FD_TBYTES;   // [3 tiles][4 D waves] min log2(ss * se) of the rows a wave staged
+constexpr int FD_LDS = FD_OFF_INFO + 64;
+static_assert(FD_LDS <= 160 * 1024, "LDS budget of one CU");
+constexpr int FD_GBIG = 0x3f000000;              // "no point with two non-zero rows yet"
+
+// 2^G / sx for a power-of-two sx > 0 by exponent arithmetic (0 stays 0, NaN stays NaN, underflow flushes to 0)
+__device__ __forceinline__ float fd_yscale(float sx, int G) {
+  const unsigned bits = __float_as_uint(sx);
+  const int field = G - (int)((bits >> 23) & 0xff) + 254;
+  const float r = __uint_as_float((unsigned)(field < 1 ? 0 : (field > 254 ? 254 : field)) << 23);
+  return sx > 0.0f ? (field < 1 ? 0.0f : r) : sx;
+}
+
+// the epilogue-side operand of 4 columns from the epilogue's side inputs (see DwFuse in cnr_views.h)
+template <int EK>
+__device__ __forceinline__ f4 fd_ep4(const Epi& e, const EpiRaw4& raw) {
+  f4 r;
+  if constexpr (EK == EK_RELU_MASK) {
+    r = raw.a;
+  } else if constexpr (EK == EK_VBACK) {
+    r.x = softplus100(raw.a.x); r.y = softplus100(raw.a.y); r.z = softplus100(raw.a.z); r.w = softplus100(raw.a.w);
+  } else {
+    r.x = softplus100_d1(raw.a.x) * (raw.b.x * e.vscale); r.y = softplus100_d1(raw.a.y) * (raw.b.y * e.vscale);
+    r.z = softplus100_d1(raw.a.z) * (raw.b.z * e.vscale); r.w = softplus100_d1(raw.a.w) * (raw.b.w * e.vscale);
+  }
+  return r;
+}
+
+__device__ __forceinline__ float fd_sel4(const f4& v, int j) {   // v[j] for a per-lane j without scratch memory
+  const float lo = (j & 1) ? v.y : v.x, hi = (j & 1) ? v.w : v.z;
+  return (j & 2) ? hi : lo;
+}
+
+template <int EK>
+__global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, const DwFuse f, int tiles_per_range) {
+  LayerGemm g = g_in;
+  g.A.kind = VK_DIRECT; g.E.kind = EK; g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // blocks b and b + 8 (same XCD under the observed round-robin placement: a speed matter only) are the two column halves of one range
+  const int b = blockIdx.x;
+  const int half = (b >> 3) & 1, range = (b >> 4) * 8 + (b & 7);
+  const long ntiles = g.P / FD_TP;
+  const long t0 = (long)range * tiles_per_range;
+  const int n = t0 < ntiles ? (int)((ntiles - t0) < tiles_per_range ? (ntiles - t0) : tiles_per_range) : 0;
+  int* info = reinterpret_cast<int*>(smem + FD_OFF_INFO);
+  float* out = f.partial + (long)range * f.Npad * f.ldk;
+  const bool isP = wave < 4;
+
+  if (isP) {
+    // ================================================================ P waves
+    const int c0 = half * 128 + wave * 32;               // first output column of this wave
+    f16x8 w1[16], w2[16];
+    {
+      const unsigned short* wp = g.Wp + (long)(c0 + (lane & 31)) * g.ldw + (lane >> 5) * 8;
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) {
+        w1[kb] = *reinterpret_cast<const f16x8*>(wp + kb * 16);
+        w2[kb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 16);
+      }
+    }
+    const int ecol = c0 + (lane & 7) * 4;
+    const f4 wsc = *reinterpret_cast<const f4*>(g.wscale + ecol);
+    const f4 bias4 = epi_bias4(g.E, ecol);
+    float* T = reinterpret_cast<float*>(smem + FD_OFF_T + wave * FD_TBYTES);
+    const int jrot = (lane & 7) >> 1;                    // rotation of the 2-byte Ep' stores over a lane's 4 columns (LDS banks)
+    EpiRaw4 ern[4];
+    if (n > 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ern[q] = epi_fetch4_plain<EK>(g.E, t0 * FD_TP + (lane >> 3) + 8 * q, ecol);
+    }
+    cnr_lds_barrier();   // tile 0 staged
+    int G = FD_GBIG, ab = 0;
+    for (int i = 0; i <= n; ++i) {
+      if (i < n) {
+        const long t = t0 + i;
+        const unsigned char* B = smem + ab * FD_ABUF;
+        {
+          const int* qi = info + ab * 4;
+          int m = qi[0]; m = qi[1] < m ? qi[1] : m; m = qi[2] < m ? qi[2] : m; m = qi[3] < m ? qi[3] : m;
+          if (m < FD_GBIG && m + 1 < G) G = m + 1;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+        const unsigned char* Ab = B + (lane & 31) * FD_ALD + (lane >> 5) * 16;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+          const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + kb * 32);
+          const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + FD_APLANE + kb * 32);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float* rs = reinterpret_cast<const float*>(B + 2 * FD_APLANE);
+        const float* ssr = rs + 32;
+        const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * FD_TLD + cl] = acc[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const long tn = t0 + (i + 1 < n ? i + 1 : n - 1);
+        unsigned char* Yb = smem + FD_OFF_Y + (i & 1) * FD_YBUF;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rr = (lane >> 3) + 8 * q, cc = (lane & 7) * 4;
+          const long row = t * FD_TP + rr;
+          const float rsc = rs[rr];
+          f4 v = *reinterpret_cast<const f4*>(T + rr * FD_TLD + cc);
+          v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
+          f4 ep = fd_ep4<EK>(g.E, ern[q]);
+          epi_finish4_plain<EK>(g.E, row, ecol, v, bias4, ern[q]);
+          ern[q] = epi_fetch4_plain<EK>(g.E, tn * FD_TP + rr, ecol);
+          const float ys = fd_yscale(ssr[rr], G);
+          ep.x *= ys; ep.y *= ys; ep.z *= ys; ep.w *= ys;
+          unsigned char* yrow = Yb + (wave * 32 + cc) * FD_YLD + rr * 2;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = (jj + jrot) & 3;
+            const float x = fd_sel4(ep, j);
+            const _Float16 h1 = (_Float16)x;
+            const _Float16 h2 = (_Float16)(x - (float)h1);
+            *reinterpret_cast<_Float16*>(yrow + j * FD_YLD) = h1;
+            *reinterpret_cast<_Float16*>(yrow + j * FD_YLD + FD_YPLANE) = h2;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ab = ab == 2 ? 0 : ab + 1;
+      cnr_lds_barrier();
+    }
+  } else {
+    // ================================================================ D waves
+    const int wd = wave - 4, dt = tid - 256;
+    const int srow = dt >> 4, scol = (dt & 15) * 4;
+    const int m = lane & 31, kg = lane >> 5;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    f4 ra[2][4];
+    float sev[2];
+    f4 cs[4];
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cs[q] = z4; ra[0][q] = z4; ra[1][q] = z4; }
+    sev[0] = 0.f; sev[1] = 0.f;
+    const bool want_cs = f.colsum != nullptr && half == 0;
+    const float ascale = g.A.scale;
+
+    auto d_fetch = [&](int i) {
+      const long t = t0 + i;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const long row = t * FD_TP + srow + 16 * p;
+        const float* src = g.A.a + row * g.A.lda + scol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[p][q] = *reinterpret_cast<const f4*>(src + 64 * q);
+        sev[p] = f.se[row];
+      }
+    };
+    auto d_put = [&](int i, int ab) {
+      unsigned char* B = smem + ab * FD_ABUF;
+      float* rs = reinterpret_cast<float*>(B + 2 * FD_APLANE);
+      int qmin = FD_GBIG;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        f4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = ra[p][q];
+          if (ascale != 1.0f) { v[q].x *= ascale; v[q].y *= ascale; v[q].z *= ascale; v[q].w *= ascale; }
+        }
+        float mx = fmaxf(fmaxf(ws_absmax4(v[0]), ws_absmax4(v[1])), fmaxf(ws_absmax4(v[2]), ws_absmax4(v[3])));
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+        const bool valid = mx > 0.0f && mx < 3.0e38f;
+        float sc = 1.0f;
+        if (valid) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); }
+        const int row_l = srow + 16 * p;
+        unsigned char* dst = B + row_l * FD_ALD + scol * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ws_put4(v[q], sc, dst + 128 * q, FD_APLANE);
+        if (want_cs) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { cs[q].x += v[q].x; cs[q].y += v[q].y; cs[q].z += v[q].z; cs[q].w += v[q].w; }
+        }
+        const float ssv = valid ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf(""));
+        if ((dt & 15) == 0) {
+          rs[row_l] = 1.0f / sc;
+          rs[32 + row_l] = ssv;
+          if (g.rs_out && half == 0) g.rs_out[(t0 + i) * FD_TP + row_l] = ssv;
+        }
+        const float se = sev[p];
+        if (valid && se > 0.0f) {
+          const int e = (int)((__float_as_uint(sc) >> 23) & 0xff) + (int)((__float_as_uint(se) >> 23) & 0xff) - 254;
+          qmin = e < qmin ? e : qmin;
+        }
+      }
+      { const int o = __shfl_xor(qmin, 16); qmin = o < qmin ? o : qmin; }
+      { const int o = __shfl_xor(qmin, 32); qmin = o < qmin ? o : qmin; }
+      if (lane == 0) info[ab * 4 + wd] = qmin;
+    };
+    auto d_dw = [&](int i, int ab) {
+      const unsigned char* B = smem + ab * FD_ABUF;
+      const unsigned char* Yb = smem + FD_OFF_Y + (i & 1) * FD_YBUF;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f16x8 a[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const unsigned char* src = B + pl * FD_APLANE + (kb * 16 + kg * 8) * FD_ALD + (wd * 64 + it * 32 + m) * 2;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[it][pl][q] = *reinterpret_cast<const _Float16*>(src + q * FD_ALD);
+          }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          const unsigned char* ysrc = Yb + (jt * 32 + m) * FD_YLD + kb * 32 + kg * 16;
+          const f16x8 b1 = *reinterpret_cast<const f16x8*>(ysrc);
+          const f16x8 b2 = *reinterpret_cast<const f16x8*>(ysrc + FD_YPLANE);
+          f32x16 c0 = acc[0][jt], c1 = acc[1][jt];
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b2, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b2, c1, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b1, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], b1, c1, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b1, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b1, c1, 0, 0, 0);
+          acc[0][jt] = c0; acc[1][jt] = c1;
+        }
+      }
+    };
+
+    if (n > 0) { d_fetch(0); d_put(0, 0); }
+    if (n > 1) d_fetch(1);
+    cnr_lds_barrier();   // tile 0 staged
+    int Gd = FD_GBIG, ab = 0;   // ab: buffer of tile i
+    for (int i = 0; i <= n; ++i) {
+      const int abn = ab == 2 ? 0 : ab + 1, abp = ab == 0 ? 2 : ab - 1;
+      if (i + 1 < n) d_put(i + 1, abn);
+      if (i + 2 < n) d_fetch(i + 2);
+      if (i >= 1) {
+        const int* qi = info + abp * 4;
+        int mq = qi[0]; mq = qi[1] < mq ? qi[1] : mq; mq = qi[2] < mq ? qi[2] : mq; mq = qi[3] < mq ? qi[3] : mq;
+        mq = __builtin_amdgcn_readfirstlane(mq);
+        if (mq < FD_GBIG && mq + 1 < Gd) {
+          if (Gd < FD_GBIG) {   // exact power-of-two rescale of what has been accumulated under the old exponent
+            const int dlt = mq + 1 - Gd;
+            const float u1 = ldexpf(1.0f, dlt / 2), u2 = ldexpf(1.0f, dlt - dlt / 2);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+              for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[it][jt][r] = acc[it][jt][r] * u1 * u2;
+          }
+          Gd = mq + 1;
+        }
+        d_dw(i - 1, abp);
+      }
+      ab = abn;
+      cnr_lds_barrier();
+    }
+
+    // ---- partial sums of this (range, half): undo 2^G in two exact steps; the transposed form goes through a per-wave LDS tile so that
+    // both forms store 128-byte row pieces
+    if (Gd >= FD_GBIG) Gd = 0;
+    const float u1 = ldexpf(1.0f, -(Gd / 2)), u2 = ldexpf(1.0f, -(Gd - Gd / 2));
+    float* X = reinterpret_cast<float*>(smem + wd * (32 * 33 * 4));
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int s0 = wd * 64 + it * 32, e0 = half * 128 + jt * 32;
+        if (!f.transposed) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            out[(long)s * f.ldk + e0 + m] = acc[it][jt][r] * u1 * u2;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) X[((r & 3) + 8 * (r >> 2) + 4 * kg) * 33 + m] = acc[it][jt][r] * u1 * u2;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int e = 2 * r + kg;
+            out[(long)(e0 + e) * f.ldk + s0 + m] = X[m * 33 + e];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    if (want_cs) {   // bias gradient: the 16 row owners of a column group are folded in a fixed order below
+      float* C = reinterpret_cast<float*>(smem + 4 * (32 * 33 * 4));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(C + srow * 256 + scol + 64 * q) = cs[q];
+    }
+  }
+  if (f.colsum != nullptr && half == 0) {
+    cnr_lds_barrier();
+    if (!isP) {
+      const int dt = tid - 256;
+      const float* C = reinterpret_cast<const float*>(smem + 4 * (32 * 33 * 4));
+      float sum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += C[r * 256 + dt];
+      f.colsum[(long)range * f.Npad + dt] = sum;
+    }
+  }
+}
+
+template <int EK>
+static void launch_fdw(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
+  static DeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const long ntiles = g.P / FD_TP;
+  const int tpr = (int)((ntiles + f.nslots - 1) / f.nslots);
+  TimingScope ts_("layer_dw", 0, 200 + EK, g.P, g.N, g.K, 1, s, fdw_bytes(g, f));
+  hipLaunchKernelGGL((layer_dw_kernel<EK>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr);
+}
+
+bool be_fdw_enabled() {
+  static const bool off = getenv("CNR_NO_FDW") != nullptr;   // debugging aid: separate layer and weight-gradient launches everywhere
+  return !off;
+}
+
+void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s) {
+  static const bool split_env = getenv("CNR_FDW_SPLIT") != nullptr;   // debugging aid: the same slots filled by the two separate kernels
+  if (split_env || !fdw_shape_ok(g) || f.se == nullptr || f.Npad != 256 || f.ldk != 256 || f.nslots < 8 || (f.nslots & 7) != 0 || f.nslots > kFdwSlots) {
+    be_dw_gemm(d, s);
+    be_layer_gemm(g, s);
+    return;
+  }
+  switch (g.E.kind) {
+    case EK_RELU_MASK: launch_fdw<EK_RELU_MASK>(g, f, s); break;
+    case EK_VBACK: launch_fdw<EK_VBACK>(g, f, s); break;
+    default: launch_fdw<EK_SWEEP>(g, f, s); break;
+  }
+  CNR_LAUNCH_CHECK("layer_dw");
+}
+
+}  // namespace cnr

@@ -444,7 +444,8 @@ __device__ __forceinline__ void finish_weight_row(const FinishWeight& p, const i
   }
   if (p.db != nullptr && p.colsum != nullptr) {
     float s = 0.0f;
-    for (int c = tid; c < p.nchunk; c += 256) s += p.colsum[(long)c * p.npad + n];
+    const int ncs = p.ncolsum > 0 ? p.ncolsum : p.nchunk;
+    for (int c = tid; c < ncs; c += 256) s += p.colsum[(long)c * p.npad + n];
     s = block_sum_256(s, red);
     if (tid == 0) p.db[nr] = s;
   }

@@ -4,6 +4,7 @@
 //
 // GEMMs are plain loops over the same views / epilogues; per-ray kernels are straightforward serial code.
 #include <algorithm>
+#include <cstdlib>
 #include <cstdio>
 #include <vector>
 
@@ -111,6 +112,12 @@ CNR_PW(be_coltop_bwd, ColTopBwd, body_coltop_bwd, p.P)
 CNR_PW(be_gbar_finish, GbarFinish, body_gbar_finish, p.P)
 CNR_PW(be_pbar_finish, PbarFinish, body_pbar_finish, p.P)
 
+bool be_fdw_enabled() { return getenv("CNR_NO_FDW") == nullptr; }
+void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse&, cnr_stream s) {
+  be_dw_gemm(d, s);      // (first: EK_VBACK updates o1 in place, but neither dW operand is an output of this launch, so the order is free)
+  be_layer_gemm(g, s);
+}
+
 static int seg_src_of(const Segment* seg, int nseg, int j) {
   for (int q = 0; q < nseg; ++q)
     if (j >= seg[q].dst && j < seg[q].dst + seg[q].len) return seg[q].src + (j - seg[q].dst);
@@ -169,7 +176,7 @@ void be_finish_weight(const FinishWeight& p, cnr_stream) {
     }
     if (p.db && p.colsum) {
       float s = 0.0f;
-      for (int c = 0; c < p.nchunk; ++c) s += p.colsum[(long)c * p.npad + n];
+      for (int c = 0; c < (p.ncolsum > 0 ? p.ncolsum : p.nchunk); ++c) s += p.colsum[(long)c * p.npad + n];
       p.db[nr] = s;
     }
   }

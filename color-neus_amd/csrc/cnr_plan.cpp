@@ -314,7 +314,17 @@ struct Bwd {   // backward scratch
   size_t partial_floats, partial_off;
   std::vector<FinishWeight> pending;  // reductions queued by run_dw, issued as one launch by flush_dw
   int nchunk; long chunk_pts;
+  int fslots;                         // slots (point ranges) of a fused layer + weight-gradient launch (cnr_gemm_fdw.hip)
+  int cap_slots;                      // slots reserved per layer in the pool: max(nchunk, 2 * fslots)
 };
+
+// point ranges of a fused launch: at least four 32-point tiles per range, a multiple of 8 (two column halves per range share an XCD)
+static int fdw_slots(long P) {
+  long s = round_up((int)((P / 32 + 3) / 4), 8);
+  if (s < 8) s = 8;
+  if (s > kFdwSlots) s = kFdwSlots;
+  return (int)s;
+}
 
 static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   const long P = R * m.M;
@@ -345,9 +355,11 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   if (nch > 256) nch = 256;
   b.nchunk = (int)nch;
   b.chunk_pts = round_up((int)((P + nch - 1) / nch), 16);
-  // every layer keeps its own [nchunk][npad][ldw] partial sums (+ bias column sums) until one batched reduction at the end
+  b.fslots = fdw_slots(P);
+  b.cap_slots = b.nchunk > 2 * b.fslots ? b.nchunk : 2 * b.fslots;
+  // every layer keeps its own [slots][npad][ldw] partial sums (+ bias column sums) until one batched reduction at the end
   size_t tot = 0;
-  auto upd = [&](const Lin& q) { tot += round_up_sz((size_t)b.nchunk * q.npad * q.ldw, 64) + round_up_sz((size_t)b.nchunk * q.npad, 64); };
+  auto upd = [&](const Lin& q) { tot += round_up_sz((size_t)b.cap_slots * q.npad * q.ldw, 64) + round_up_sz((size_t)b.cap_slots * q.npad, 64); };
   for (auto& q : m.sdf) upd(q);
   for (auto& q : m.col) upd(q);
   for (auto& q : m.rel) upd(q);
@@ -665,27 +677,58 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
 }
 
 // ------------------------------------------------------------------------------------------------
-static void run_dw(const Model& m, const Lin& q, DwGemm& g, Bwd& b, const float* const* params, float* const* dparams,
-                   bool with_bias, cnr_stream s) {
-  float* part = b.partial + b.partial_off;
-  b.partial_off += round_up_sz((size_t)b.nchunk * q.npad * q.ldw, 64);
-  float* csum = b.partial + b.partial_off;
-  b.partial_off += round_up_sz((size_t)b.nchunk * q.npad, 64);
-  g.N = q.n; g.K = q.k_int; g.nchunk = b.nchunk; g.chunk_pts = b.chunk_pts;
-  g.partial = part; g.Npad = q.npad; g.ldk = q.ldw; g.colsum = with_bias ? csum : nullptr;
+// A layer's region of the partial-sum pool: [slots][npad][ldw] + [slots][npad] column sums.  Several launches may fill consecutive slot
+// groups of one region (SDF layers: value pair | gradient-chain pair, each either fused into its layer launch or a separate GEMM);
+// finish_region queues the one reduction over all of them.  Only the group at slot 0 carries bias column sums.
+struct DwRegion { float* part = nullptr; float* csum = nullptr; };
+static DwRegion take_region(const Lin& q, Bwd& b) {
+  DwRegion r;
+  r.part = b.partial + b.partial_off;
+  b.partial_off += round_up_sz((size_t)b.cap_slots * q.npad * q.ldw, 64);
+  r.csum = b.partial + b.partial_off;
+  b.partial_off += round_up_sz((size_t)b.cap_slots * q.npad, 64);
+  return r;
+}
+static void finish_region(const Lin& q, const DwRegion& r, int nslots, int ncolsum, Bwd& b, const float* const* params, float* const* dparams) {
+  FinishWeight f;
+  f.partial = r.part; f.nchunk = nslots; f.npad = q.npad; f.ldk = q.ldw; f.colsum = ncolsum > 0 ? r.csum : nullptr; f.ncolsum = ncolsum;
+  f.g = q.p_g >= 0 ? params[q.p_g] : nullptr; f.v = params[q.p_v];
+  f.n = q.n; f.k_ref = q.k_ref; f.nseg = q.nseg;
+  for (int i = 0; i < q.nseg; ++i) f.seg[i] = q.seg[i];
+  f.dg = q.p_g >= 0 ? dparams[q.p_g] : nullptr; f.dv = dparams[q.p_v]; f.db = dparams[q.p_b]; f.row_rot = q.row_rot;
+  b.pending.push_back(f);
+}
+// separate weight-gradient GEMM into slots [slot0, slot0 + nchunk) of a region (bias column sums only for a group at slot 0)
+static void dw_into_region(const Lin& q, DwGemm& g, const DwRegion& r, int slot0, int nchunk, long P, bool with_bias, cnr_stream s) {
+  with_bias = with_bias && slot0 == 0;
+  g.N = q.n; g.K = q.k_int; g.nchunk = nchunk; g.chunk_pts = round_up((int)((P + nchunk - 1) / nchunk), 16);
+  g.partial = r.part + (size_t)slot0 * q.npad * q.ldw; g.Npad = q.npad; g.ldk = q.ldw; g.colsum = with_bias ? r.csum : nullptr;
   // split-f16 tiles need the row scales of every operand of the 256 x 256 tiles (the top SDF layer's unit-vector pair is dropped there)
   const int need = (g.npairs == 2 && g.X[1].kind == VK_CONST_COL0) ? 1 : g.npairs;
   bool scaled = q.n > 32 && q.k_int > 64;
   for (int i = 0; i < need; ++i) scaled = scaled && g.sx[i] && g.sy[i];
   g.split_f16 = scaled;
   be_dw_gemm(g, s);
-  FinishWeight f;
-  f.partial = part; f.nchunk = b.nchunk; f.npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? csum : nullptr;
-  f.g = q.p_g >= 0 ? params[q.p_g] : nullptr; f.v = params[q.p_v];
-  f.n = q.n; f.k_ref = q.k_ref; f.nseg = q.nseg;
-  for (int i = 0; i < q.nseg; ++i) f.seg[i] = q.seg[i];
-  f.dg = q.p_g >= 0 ? dparams[q.p_g] : nullptr; f.dv = dparams[q.p_v]; f.db = dparams[q.p_b]; f.row_rot = q.row_rot;
-  b.pending.push_back(f);
+}
+// layer launch + its weight-gradient pair (d.X[0] / d.Y[0]: the pair as a plain weight-gradient GEMM -- what the CPU emulation and the HIP
+// backend's unfused fallback run; se = row scales of the epilogue-side operand) into slots [slot0, slot0 + b.fslots) of a region
+static void fused_into_region(const Lin& q, const LayerGemm& g, DwGemm& d, const float* se, int transposed, const DwRegion& r, int slot0, Bwd& b,
+                              bool with_bias, cnr_stream s) {
+  with_bias = with_bias && slot0 == 0 && !transposed;
+  DwFuse f;
+  f.se = se; f.partial = r.part + (size_t)slot0 * q.npad * q.ldw; f.Npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? r.csum : nullptr;
+  f.transposed = transposed; f.nslots = b.fslots;
+  d.npairs = 1; d.P = g.P; d.N = q.n; d.K = q.k_int; d.nchunk = b.fslots; d.chunk_pts = round_up((int)((g.P + b.fslots - 1) / b.fslots), 16);
+  d.partial = f.partial; d.Npad = q.npad; d.ldk = q.ldw; d.colsum = f.colsum;
+  d.split_f16 = q.n > 32 && q.k_int > 64 && d.sx[0] && d.sy[0];
+  be_layer_dw_gemm(g, d, f, s);
+}
+
+static void run_dw(const Model& m, const Lin& q, DwGemm& g, Bwd& b, const float* const* params, float* const* dparams,
+                   bool with_bias, cnr_stream s) {
+  const DwRegion r = take_region(q, b);
+  dw_into_region(q, g, r, 0, b.nchunk, g.P, with_bias, s);
+  finish_region(q, r, b.nchunk, with_bias ? b.nchunk : 0, b, params, dparams);
   (void)m;
 }
 
@@ -747,6 +790,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   be_variance_finish(vf, s);
 
   // ---- 2. relight chain backward
+  const bool fdw = be_fdw_enabled();   // layer launch + weight gradient in one launch where the shape allows (cnr_gemm_fdw.hip)
   if (m.has_relight) {
     const int y = m.c.rel_y_in_layer - 1;
     for (int i = m.NR - 1; i >= 0; --i) {
@@ -758,13 +802,21 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
       g.E.kind = EK_RELU_MASK; g.E.n_out = q.k_int; g.E.split = m.Hr; g.E.o1 = b.D[i]; g.E.ld1 = m.Hr;
       g.E.aux = x.HR[i]; g.E.ldaux = hr_ld(m, x, i); g.E.o2 = (i == y) ? b.gc_b : nullptr; g.E.ld2 = 4;
-      if (q.n > 32) g.rs_out = b.rsD;
-      be_layer_gemm(g, s);
       DwGemm d;
       d.npairs = 1; d.P = P;
-      d.X[0] = g.A; d.sx[0] = g.rs_out; d.sy[0] = x.rsR[i];
+      d.X[0] = g.A; d.sy[0] = x.rsR[i];
       d.Y[0] = relight_input_view(m, i, x);
-      run_dw(m, q, d, b, params, dP, true, s);
+      const DwRegion r = take_region(q, b);
+      if (fdw && fdw_shape_ok(g) && x.rsR[i] && q.npad == 256 && q.ldw == 256) {
+        fused_into_region(q, g, d, x.rsR[i], 0, r, 0, b, true, s);
+        finish_region(q, r, b.fslots, b.fslots, b, params, dP);
+      } else {
+        if (q.n > 32) g.rs_out = b.rsD;
+        be_layer_gemm(g, s);
+        d.sx[0] = g.rs_out;
+        dw_into_region(q, d, r, 0, b.nchunk, P, true, s);
+        finish_region(q, r, b.nchunk, b.nchunk, b, params, dP);
+      }
     }
     {
       const Lin& q = m.rel[0];
@@ -798,13 +850,21 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.split = m.F; g.E.o1 = b.ZTOP; g.E.ld1 = x.ldztop; g.E.o1_off = 0;
       g.E.o2 = b.dAUXc; g.E.ld2 = kAux;
     }
-    if (q.n > 32) g.rs_out = b.rsD;
-    be_layer_gemm(g, s);
     DwGemm d;
     d.npairs = 1; d.P = P;
-    d.X[0] = g.A; d.sx[0] = g.rs_out; d.sy[0] = x.rsC[l];
+    d.X[0] = g.A; d.sy[0] = x.rsC[l];
     d.Y[0] = color_input_view(m, l, x);
-    run_dw(m, q, d, b, params, dP, true, s);
+    const DwRegion r = take_region(q, b);
+    if (fdw && l > 0 && fdw_shape_ok(g) && x.rsC[l] && q.npad == 256 && q.ldw == 256) {
+      fused_into_region(q, g, d, x.rsC[l], 0, r, 0, b, true, s);
+      finish_region(q, r, b.fslots, b.fslots, b, params, dP);
+    } else {
+      if (q.n > 32) g.rs_out = b.rsD;
+      be_layer_gemm(g, s);
+      d.sx[0] = g.rs_out;
+      dw_into_region(q, d, r, 0, b.nchunk, P, true, s);
+      finish_region(q, r, b.nchunk, b.nchunk, b, params, dP);
+    }
   }
   // ---- 4. total d g and the tangent of the embedding
   GbarFinish gb;
@@ -820,7 +880,10 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     else { v.a = b.VB[l - 1]; v.lda = m.Hs; if (m.skip(l)) v.scale = kInvSqrt2; }   // skip: tail columns of VB[l-1] hold cbar
     return v;
   };
-  for (int l = 0; l < m.L; ++l) {
+  // the launches of steps 5 and 6 as descriptors: each SDF layer's two weight-gradient pairs go into one region of the partial-sum pool,
+  // [value pair (zbar_l, input_l) | gradient-chain pair (u_l, qbar_l)], each either fused into its layer launch (value pair: the
+  // value-backward launch l; gradient-chain pair: the sweep launch l) or left to the separate weight-gradient GEMM of step 7
+  auto sweep_gemm = [&](int l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;
     g.A = qbar_view(l);
@@ -830,11 +893,9 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     else { g.E.v = x.V[l]; g.E.ldv = m.Hs; }
     g.E.o1 = b.Z2[l]; g.E.ld1 = m.Hs; g.E.o2 = b.VB[l]; g.E.ld2 = m.Hs;
     if (m.skip(l + 1)) { g.E.tail_src = b.cbar; g.E.ld_tail = kEmb; g.E.tail_n = m.emb; }
-    g.rs_out = b.rsY1[l];
-    be_layer_gemm(g, s);
-  }
-  // ---- 6. value-path backward through the SDF net (in place: Z2[l] becomes the total cotangent of z_l)
-  for (int l = m.L; l >= 1; --l) {
+    return g;
+  };
+  auto vback_gemm = [&](int l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;
     if (l == m.L) { g.A.kind = VK_DIRECT; g.A.a = b.ZTOP; g.A.lda = x.ldztop; }
@@ -842,8 +903,71 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
     g.E.kind = EK_VBACK; g.E.n_out = q.k_int; g.E.z = x.Z[l - 1]; g.E.ldz = m.Hs; g.E.o1 = b.Z2[l - 1]; g.E.ld1 = m.Hs;
     if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; g.E.o2_off = skip_off(m); }
-    g.rs_out = b.rsX0[l];
-    be_layer_gemm(g, s);
+    return g;
+  };
+  // value pair of layer l: X = zbar_l, Y = the layer's forward input
+  auto value_pair = [&](int l, DwGemm& d) {
+    if (l == m.L) { d.X[0].kind = VK_DIRECT; d.X[0].a = b.ZTOP; d.X[0].lda = x.ldztop; }
+    else { d.X[0].kind = VK_DIRECT; d.X[0].a = b.Z2[l]; d.X[0].lda = m.Hs; }
+    d.Y[0] = sdf_input_view(m, l, x.E, x.Z.data());
+    d.sx[0] = b.rsX0[l]; d.sy[0] = x.rsY[l];
+  };
+  // gradient-chain pair of layer l into operand slot i of d: X = u_l = sp'(z_l) v_l, Y = qbar_l
+  auto grad_pair = [&](int l, DwGemm& d, int i) {
+    if (l == m.L) {
+      d.X[i].kind = VK_CONST_COL0; d.X[i].a = b.ZTOP; d.X[i].lda = x.ldztop; d.X[i].scale = inv_scale; d.X[i].math_split = m.F;
+      d.Y[i].kind = VK_DIRECT; d.Y[i].a = b.VB[m.L - 1]; d.Y[i].lda = m.Hs;
+    } else {
+      d.X[i].a = x.Z[l]; d.X[i].lda = m.Hs;
+      if (l == m.L - 1) { d.X[i].kind = VK_SIGMUL_ROW; d.X[i].b = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; d.X[i].scale = inv_scale; }
+      else { d.X[i].kind = VK_SIGMUL; d.X[i].b = x.V[l]; d.X[i].ldb = m.Hs; }
+      d.Y[i] = qbar_view(l);
+      d.sx[i] = x.rsX1[l]; d.sy[i] = b.rsY1[l];
+    }
+  };
+  std::vector<DwRegion> sreg(m.L + 1);
+  std::vector<char> fuse_v(m.L + 1, 0), fuse_g(m.L + 1, 0);
+  for (int l = 0; l <= m.L; ++l) {
+    const Lin& q = m.sdf[l];
+    sreg[l] = take_region(q, b);
+    const bool sq = q.npad == 256 && q.ldw == 256;
+    if (fdw && sq && l >= 1 && l < m.L && x.rsY[l] && fdw_shape_ok(vback_gemm(l))) fuse_v[l] = 1;
+    if (fdw && sq && l < m.L && x.rsX1[l] && fdw_shape_ok(sweep_gemm(l))) fuse_g[l] = 1;
+  }
+  // slot groups of a region: the value pair first (it carries the bias column sums), the gradient-chain pair behind it; a pair takes
+  // fslots slots when it is fused, at most that many when it shares the region with a fused pair, and when neither is fused one launch
+  // over nchunk slots forms both
+  const int rest_slots = b.nchunk < b.fslots ? b.nchunk : b.fslots;
+  auto value_slots = [&](int l) { return fuse_v[l] ? b.fslots : (fuse_g[l] ? rest_slots : b.nchunk); };
+  auto grad_slots = [&](int l) { return fuse_g[l] ? b.fslots : (fuse_v[l] ? rest_slots : 0); };
+  for (int l = 0; l < m.L; ++l) {
+    const Lin& q = m.sdf[l];
+    LayerGemm g = sweep_gemm(l);
+    if (fuse_g[l]) {
+      DwGemm d;
+      d.npairs = 1; d.P = P;
+      grad_pair(l, d, 0);
+      d.sy[0] = nullptr;   // (a fused launch does not need qbar_l's row scales; the unfused fallback then takes the split-bf16 tiles)
+      fused_into_region(q, g, d, x.rsX1[l], 1, sreg[l], value_slots(l), b, false, s);
+    } else {
+      g.rs_out = b.rsY1[l];
+      be_layer_gemm(g, s);
+    }
+  }
+  // ---- 6. value-path backward through the SDF net (in place: Z2[l] becomes the total cotangent of z_l)
+  for (int l = m.L; l >= 1; --l) {
+    const Lin& q = m.sdf[l];
+    LayerGemm g = vback_gemm(l);
+    if (fuse_v[l]) {
+      DwGemm d;
+      d.npairs = 1; d.P = P;
+      value_pair(l, d);
+      d.sx[0] = nullptr;
+      fused_into_region(q, g, d, x.rsY[l], 0, sreg[l], 0, b, true, s);
+    } else {
+      g.rs_out = b.rsX0[l];
+      be_layer_gemm(g, s);
+    }
   }
   if (rays_grad) {
     const Lin& q = m.sdf[0];
@@ -853,28 +977,30 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = b.ebar0; g.E.ld1 = kEmb;
     be_layer_gemm(g, s);
   }
-  // ---- 7. SDF weight gradients: value pair (zbar_l, input_l) + gradient-chain pair (u_l, qbar_l)
+  // ---- 7. SDF weight gradients that were not formed inside a layer launch: value pair (zbar_l, input_l) + gradient-chain pair (u_l, qbar_l)
   for (int l = 0; l <= m.L; ++l) {
     const Lin& q = m.sdf[l];
-    DwGemm d;
-    d.npairs = 2; d.P = P;
-    if (l == m.L) { d.X[0].kind = VK_DIRECT; d.X[0].a = b.ZTOP; d.X[0].lda = x.ldztop; }
-    else { d.X[0].kind = VK_DIRECT; d.X[0].a = b.Z2[l]; d.X[0].lda = m.Hs; }
-    d.Y[0] = sdf_input_view(m, l, x.E, x.Z.data());
-    if (l == m.L) {
-      d.X[1].kind = VK_CONST_COL0; d.X[1].a = b.ZTOP; d.X[1].lda = x.ldztop; d.X[1].scale = inv_scale; d.X[1].math_split = m.F;
-      d.Y[1].kind = VK_DIRECT; d.Y[1].a = b.VB[m.L - 1]; d.Y[1].lda = m.Hs;
-    } else {
-      d.X[1].a = x.Z[l]; d.X[1].lda = m.Hs;
-      if (l == m.L - 1) { d.X[1].kind = VK_SIGMUL_ROW; d.X[1].b = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; d.X[1].scale = inv_scale; }
-      else { d.X[1].kind = VK_SIGMUL; d.X[1].b = x.V[l]; d.X[1].ldb = m.Hs; }
-      d.Y[1] = qbar_view(l);
+    const DwRegion& r = sreg[l];
+    if (!fuse_v[l] && !fuse_g[l]) {          // both pairs in one launch sharing the accumulators
+      DwGemm d;
+      d.npairs = 2; d.P = P;
+      value_pair(l, d);
+      grad_pair(l, d, 1);
+      dw_into_region(q, d, r, 0, b.nchunk, P, true, s);
+    } else if (!fuse_v[l]) {                 // the value pair alone, into the leading slots
+      DwGemm d;
+      d.npairs = 1; d.P = P;
+      value_pair(l, d);
+      dw_into_region(q, d, r, 0, value_slots(l), P, true, s);
+    } else if (!fuse_g[l]) {                 // the gradient-chain pair alone, behind the fused value pair
+      DwGemm d;
+      d.npairs = 1; d.P = P;
+      grad_pair(l, d, 0);
+      dw_into_region(q, d, r, value_slots(l), grad_slots(l), P, false, s);
     }
-    d.sx[0] = b.rsX0[l]; d.sy[0] = x.rsY[l];
-    if (l < m.L) { d.sx[1] = x.rsX1[l]; d.sy[1] = b.rsY1[l]; }
-    run_dw(m, q, d, b, params, dP, true, s);
+    finish_region(q, r, value_slots(l) + grad_slots(l), value_slots(l), b, params, dP);
   }
-  flush_dw(b, s);   // all 19 partial-sum reductions + weight-norm backward in one launch
+  flush_dw(b, s);   // all partial-sum reductions + weight-norm backward in one launch
   // ---- 8. d rays (camera refinement configs)
   if (rays_grad) {
     PbarFinish pf;

@@ -403,6 +403,40 @@ inline double layer_gemm_bytes(const LayerGemm& g) {
   }
   return b;
 }
+// Layer GEMM + weight gradient in ONE launch (cnr_gemm_fdw.hip): the launch that consumes an operand S = A (its staged input) forms the
+// weight-gradient pair (S, Ep) on chip, where Ep ("epilogue-side operand") is what its fused epilogue computes from its side inputs anyway:
+//   EK_RELU_MASK  Ep = aux                         (the layer input h_{l-1} of the ReLU stacks; dW_l = sum_pt dout_l (x) h_{l-1})
+//   EK_VBACK      Ep = softplus(z_{l-1})           (SDF value pair:           dW_l += sum_pt zbar_l (x) h_{l-1})
+//   EK_SWEEP      Ep = sp'(z_l) * v_l * vscale     (SDF gradient-chain pair:  dW_l += sum_pt u_l (x) qbar_l, written transposed)
+// so the separate weight-gradient GEMM of that pair -- a second pass over both operands -- disappears.
+constexpr int kFdwSlots = 128;   // most point ranges (= partial-sum slots) of a fused launch: two workgroups (column halves) per range
+struct DwFuse {
+  const float* se = nullptr;  // [P] power-of-two row scales of Ep saved by the forward launch that consumed the same rows (LayerGemm::rs_out):
+                              // 0 = all-zero row, NaN = non-finite row
+  float* partial = nullptr;   // [nslots][Npad][ldk] partial sums of this pair, every slot written in full
+  int Npad = 0, ldk = 0;
+  float* colsum = nullptr;    // optional [nslots][Npad]: column sums of S (bias gradient); only with transposed == 0
+  int transposed = 0;         // 0: dW[n = column of S][k = column of Ep] ; 1: dW[n = column of Ep][k = column of S]
+  int nslots = 0;             // point ranges = partial-sum slots of this launch: a multiple of 8, <= kFdwSlots
+};
+
+// structural conditions of the fused kernel: a plain 256 -> 256 launch on full 32-point tiles whose epilogue takes the 16-byte path everywhere
+inline bool fdw_shape_ok(const LayerGemm& g) {
+  const Epi& e = g.E;
+  if (g.A.kind != VK_DIRECT || (g.A.lda & 3) != 0 || g.K != 256 || g.N != 256 || g.col0 != 0 || g.P_dev != nullptr) return false;
+  if (g.P <= 0 || (g.P % 32) != 0 || g.Wp == nullptr || g.wscale == nullptr) return false;
+  if (e.kind != EK_RELU_MASK && e.kind != EK_VBACK && e.kind != EK_SWEEP) return false;
+  if (e.tail_src != nullptr || e.n_out != 256 || e.split < 256) return false;
+  switch (e.kind) {
+    case EK_RELU_MASK: return ((e.ld1 | e.ldaux) & 3) == 0 && e.aux != nullptr;
+    case EK_VBACK: return ((e.ld1 | e.ldz) & 3) == 0;
+    default: return ((e.ld1 | e.ld2 | e.ldz | e.ldv) & 3) == 0 && e.o2 != nullptr;
+  }
+}
+inline double fdw_bytes(const LayerGemm& g, const DwFuse& f) {   // the layer launch's operands + the partial sums; S counted once (its second read is an L2 hit)
+  return layer_gemm_bytes(g) + 4.0 * f.nslots * (double)f.Npad * f.ldk;
+}
+
 inline double dw_gemm_bytes(const DwGemm& g, int n, int k) {
   double b = 0;
   for (int i = 0; i < g.npairs; ++i) b += view_bytes(g.X[i], g.P, n) + view_bytes(g.Y[i], g.P, k);

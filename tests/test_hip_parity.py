@@ -476,3 +476,27 @@ def test_stream_form_of_the_layer_kernel_is_bit_identical(tmp_path):
     assert set(res["stream"]) == set(res["general"])
     for k in sorted(res["stream"]):
         assert np.array_equal(res["stream"][k], res["general"][k], equal_nan=True), k
+
+
+def test_fused_layer_dw_matches_separate_launches(tmp_path):
+    """layer_dw_kernel (cnr_gemm_fdw.hip: a backward layer launch that also forms the weight gradient of its layer on chip) against the
+    separate layer + weight-gradient launches (CNR_NO_FDW=1, child processes): outputs and input gradients are the same arithmetic and must
+    agree to the bit; weight gradients differ only in the summation order over points and the power-of-two exponent of the split."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("fused", {}), ("separate", {"CNR_NO_FDW": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _STREAM_CHILD, root, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = dict(np.load(path))
+    assert set(res["fused"]) == set(res["separate"])
+    bad = []
+    for k in sorted(res["fused"]):
+        a, b = res["fused"][k].astype(np.float64), res["separate"][k].astype(np.float64)
+        if k.startswith("g:"):
+            e = float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-300)
+            if not e < 5e-6:
+                bad.append((k, e))
+        elif not np.array_equal(a, b, equal_nan=True):
+            bad.append((k, "not bit-identical"))
+    assert not bad, bad
