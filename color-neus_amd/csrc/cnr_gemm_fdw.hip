@@ -70,8 +70,10 @@ __device__ __forceinline__ float fd_sel4(const f4& v, int j) {   // v[j] for a p
   return (j & 2) ? hi : lo;
 }
 
-template <int EK>
-__global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, const DwFuse f, int tiles_per_range) {
+// DP: the P waves keep the epilogue side inputs of TWO tiles in flight (tile i + 2 is requested while tile i is finished);
+// DD: the D waves keep two input tiles in flight (tile i + 3 is requested when tile i + 1 has been converted).
+template <int EK, bool DP, bool DD>
+__global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, const DwFuse f, int tiles_per_range, int dbg) {
   LayerGemm g = g_in;
   g.A.kind = VK_DIRECT; g.E.kind = EK; g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
   int* info = reinterpret_cast<int*>(smem + FD_OFF_INFO);
   float* out = f.partial + (long)range * f.Npad * f.ldk;
   const bool isP = wave < 4;
+  const int nlast = n > 0 ? n - 1 : 0;
 
   if (isP) {
     // ================================================================ P waves
@@ -103,73 +106,92 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     const f4 bias4 = epi_bias4(g.E, ecol);
     float* T = reinterpret_cast<float*>(smem + FD_OFF_T + wave * FD_TBYTES);
     const int jrot = (lane & 7) >> 1;                    // rotation of the 2-byte Ep' stores over a lane's 4 columns (LDS banks)
-    EpiRaw4 ern[4];
-    if (n > 0) {
+    int G = FD_GBIG;
+    // one tile: product, epilogue, Ep' tile; `ern` holds this tile's side inputs and receives those of tile i + ahead (clamped to the range)
+    auto p_tile = [&](const int i, const int ab, EpiRaw4 (&ern)[4], const int ahead) {
+      const long t = t0 + i;
+      const unsigned char* B = smem + ab * FD_ABUF;
+      {
+        const int* qi = info + ab * 4;
+        int m = qi[0]; m = qi[1] < m ? qi[1] : m; m = qi[2] < m ? qi[2] : m; m = qi[3] < m ? qi[3] : m;
+        if (m < FD_GBIG && m + 1 < G) G = m + 1;
+      }
+      f32x16 acc;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) ern[q] = epi_fetch4_plain<EK>(g.E, t0 * FD_TP + (lane >> 3) + 8 * q, ecol);
+      for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+      const unsigned char* Ab = B + (lane & 31) * FD_ALD + (lane >> 5) * 16;
+      if (!(dbg & 4))
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) {
+        const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + kb * 32);
+        const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + FD_APLANE + kb * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float* rs = reinterpret_cast<const float*>(B + 2 * FD_APLANE);
+      const float* ssr = rs + 32;
+      const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * FD_TLD + cl] = acc[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const long tn = t0 + (i + ahead < nlast ? i + ahead : nlast);
+      unsigned char* Yb = smem + FD_OFF_Y + (i & 1) * FD_YBUF;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = (lane >> 3) + 8 * q, cc = (lane & 7) * 4;
+        const long row = t * FD_TP + rr;
+        const float rsc = rs[rr];
+        f4 v = *reinterpret_cast<const f4*>(T + rr * FD_TLD + cc);
+        v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
+        f4 ep = fd_ep4<EK>(g.E, ern[q]);
+        epi_finish4_plain<EK>(g.E, row, ecol, v, bias4, ern[q]);
+        ern[q] = epi_fetch4_plain<EK>(g.E, tn * FD_TP + rr, ecol);
+        const float ys = fd_yscale(ssr[rr], G);
+        ep.x *= ys; ep.y *= ys; ep.z *= ys; ep.w *= ys;
+        unsigned char* yrow = Yb + (wave * 32 + cc) * FD_YLD + rr * 2;
+        if (!(dbg & 2))
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = (jj + jrot) & 3;
+          const float x = fd_sel4(ep, j);
+          const _Float16 h1 = (_Float16)x;
+          const _Float16 h2 = (_Float16)(x - (float)h1);
+          *reinterpret_cast<_Float16*>(yrow + j * FD_YLD) = h1;
+          *reinterpret_cast<_Float16*>(yrow + j * FD_YLD + FD_YPLANE) = h2;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    EpiRaw4 ernA[4], ernB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ernA[q] = epi_fetch4_plain<EK>(g.E, t0 * FD_TP + (lane >> 3) + 8 * q, ecol);   // (a range past the end is clamped to tile 0 of the launch: loaded, never used)
+      if (DP) ernB[q] = epi_fetch4_plain<EK>(g.E, (t0 + (1 < nlast ? 1 : nlast)) * FD_TP + (lane >> 3) + 8 * q, ecol);
     }
     cnr_lds_barrier();   // tile 0 staged
-    int G = FD_GBIG, ab = 0;
-    for (int i = 0; i <= n; ++i) {
-      if (i < n) {
-        const long t = t0 + i;
-        const unsigned char* B = smem + ab * FD_ABUF;
-        {
-          const int* qi = info + ab * 4;
-          int m = qi[0]; m = qi[1] < m ? qi[1] : m; m = qi[2] < m ? qi[2] : m; m = qi[3] < m ? qi[3] : m;
-          if (m < FD_GBIG && m + 1 < G) G = m + 1;
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-        const unsigned char* Ab = B + (lane & 31) * FD_ALD + (lane >> 5) * 16;
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-          const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + kb * 32);
-          const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + FD_APLANE + kb * 32);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb], acc, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const float* rs = reinterpret_cast<const float*>(B + 2 * FD_APLANE);
-        const float* ssr = rs + 32;
-        const int hi = lane >> 5, cl = lane & 31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * FD_TLD + cl] = acc[r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const long tn = t0 + (i + 1 < n ? i + 1 : n - 1);
-        unsigned char* Yb = smem + FD_OFF_Y + (i & 1) * FD_YBUF;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int rr = (lane >> 3) + 8 * q, cc = (lane & 7) * 4;
-          const long row = t * FD_TP + rr;
-          const float rsc = rs[rr];
-          f4 v = *reinterpret_cast<const f4*>(T + rr * FD_TLD + cc);
-          v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
-          f4 ep = fd_ep4<EK>(g.E, ern[q]);
-          epi_finish4_plain<EK>(g.E, row, ecol, v, bias4, ern[q]);
-          ern[q] = epi_fetch4_plain<EK>(g.E, tn * FD_TP + rr, ecol);
-          const float ys = fd_yscale(ssr[rr], G);
-          ep.x *= ys; ep.y *= ys; ep.z *= ys; ep.w *= ys;
-          unsigned char* yrow = Yb + (wave * 32 + cc) * FD_YLD + rr * 2;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int j = (jj + jrot) & 3;
-            const float x = fd_sel4(ep, j);
-            const _Float16 h1 = (_Float16)x;
-            const _Float16 h2 = (_Float16)(x - (float)h1);
-            *reinterpret_cast<_Float16*>(yrow + j * FD_YLD) = h1;
-            *reinterpret_cast<_Float16*>(yrow + j * FD_YLD + FD_YPLANE) = h2;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+    int ab = 0;
+    if (!DP) {
+      for (int i = 0; i <= n; ++i) {
+        if (i < n) p_tile(i, ab, ernA, 1);
+        ab = ab == 2 ? 0 : ab + 1;
+        cnr_lds_barrier();
       }
-      ab = ab == 2 ? 0 : ab + 1;
-      cnr_lds_barrier();
+    } else {
+      for (int i = 0; i <= n; i += 2) {
+        if (i < n) p_tile(i, ab, ernA, 2);
+        ab = ab == 2 ? 0 : ab + 1;
+        cnr_lds_barrier();
+        if (i + 1 <= n) {
+          if (i + 1 < n) p_tile(i + 1, ab, ernB, 2);
+          ab = ab == 2 ? 0 : ab + 1;
+          cnr_lds_barrier();
+        }
+      }
     }
   } else {
     // ================================================================ D waves
@@ -183,28 +205,26 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    f4 ra[2][4];
-    float sev[2];
+    struct RawTile { f4 r[2][4]; float se[2]; };
     f4 cs[4];
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { cs[q] = z4; ra[0][q] = z4; ra[1][q] = z4; }
-    sev[0] = 0.f; sev[1] = 0.f;
+    for (int q = 0; q < 4; ++q) cs[q] = z4;
     const bool want_cs = f.colsum != nullptr && half == 0;
     const float ascale = g.A.scale;
 
-    auto d_fetch = [&](int i) {
-      const long t = t0 + i;
+    auto d_fetch = [&](int i, RawTile& rt) {
+      const long t = t0 + (i < nlast ? i : nlast);   // (clamped: the redundant request at the end of a range is never converted)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const long row = t * FD_TP + srow + 16 * p;
         const float* src = g.A.a + row * g.A.lda + scol;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ra[p][q] = *reinterpret_cast<const f4*>(src + 64 * q);
-        sev[p] = f.se[row];
+        for (int q = 0; q < 4; ++q) rt.r[p][q] = *reinterpret_cast<const f4*>(src + 64 * q);
+        rt.se[p] = f.se[row];
       }
     };
-    auto d_put = [&](int i, int ab) {
+    auto d_put = [&](int i, int ab, const RawTile& rt) {
       unsigned char* B = smem + ab * FD_ABUF;
       float* rs = reinterpret_cast<float*>(B + 2 * FD_APLANE);
       int qmin = FD_GBIG;
@@ -213,7 +233,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         f4 v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          v[q] = ra[p][q];
+          v[q] = rt.r[p][q];
           if (ascale != 1.0f) { v[q].x *= ascale; v[q].y *= ascale; v[q].z *= ascale; v[q].w *= ascale; }
         }
         float mx = fmaxf(fmaxf(ws_absmax4(v[0]), ws_absmax4(v[1])), fmaxf(ws_absmax4(v[2]), ws_absmax4(v[3])));
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
           rs[32 + row_l] = ssv;
           if (g.rs_out && half == 0) g.rs_out[(t0 + i) * FD_TP + row_l] = ssv;
         }
-        const float se = sev[p];
+        const float se = rt.se[p];
         if (valid && se > 0.0f) {
           const int e = (int)((__float_as_uint(sc) >> 23) & 0xff) + (int)((__float_as_uint(se) >> 23) & 0xff) - 254;
           qmin = e < qmin ? e : qmin;
@@ -276,36 +296,72 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         }
       }
     };
-
-    if (n > 0) { d_fetch(0); d_put(0, 0); }
-    if (n > 1) d_fetch(1);
-    cnr_lds_barrier();   // tile 0 staged
-    int Gd = FD_GBIG, ab = 0;   // ab: buffer of tile i
-    for (int i = 0; i <= n; ++i) {
-      const int abn = ab == 2 ? 0 : ab + 1, abp = ab == 0 ? 2 : ab - 1;
-      if (i + 1 < n) d_put(i + 1, abn);
-      if (i + 2 < n) d_fetch(i + 2);
-      if (i >= 1) {
-        const int* qi = info + abp * 4;
-        int mq = qi[0]; mq = qi[1] < mq ? qi[1] : mq; mq = qi[2] < mq ? qi[2] : mq; mq = qi[3] < mq ? qi[3] : mq;
-        mq = __builtin_amdgcn_readfirstlane(mq);
-        if (mq < FD_GBIG && mq + 1 < Gd) {
-          if (Gd < FD_GBIG) {   // exact power-of-two rescale of what has been accumulated under the old exponent
-            const int dlt = mq + 1 - Gd;
-            const float u1 = ldexpf(1.0f, dlt / 2), u2 = ldexpf(1.0f, dlt - dlt / 2);
+    int Gd = FD_GBIG;
+    // weight-gradient contribution of tile i (buffer abp): fold the tile's exponent into the running one first
+    auto d_acc = [&](int i, int abp) {
+      const int* qi = info + abp * 4;
+      int mq = qi[0]; mq = qi[1] < mq ? qi[1] : mq; mq = qi[2] < mq ? qi[2] : mq; mq = qi[3] < mq ? qi[3] : mq;
+      mq = __builtin_amdgcn_readfirstlane(mq);
+      if (mq < FD_GBIG && mq + 1 < Gd) {
+        if (Gd < FD_GBIG) {   // exact power-of-two rescale of what has been accumulated under the old exponent
+          const int dlt = mq + 1 - Gd;
+          const float u1 = ldexpf(1.0f, dlt / 2), u2 = ldexpf(1.0f, dlt - dlt / 2);
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
+          for (int it = 0; it < 2; ++it)
 #pragma unroll
-              for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[it][jt][r] = acc[it][jt][r] * u1 * u2;
-          }
-          Gd = mq + 1;
+              for (int r = 0; r < 16; ++r) acc[it][jt][r] = acc[it][jt][r] * u1 * u2;
         }
-        d_dw(i - 1, abp);
+        Gd = mq + 1;
       }
-      ab = abn;
-      cnr_lds_barrier();
+      if (!(dbg & 1)) d_dw(i, abp);
+    };
+
+    RawTile ta, tb;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ta.r[p][q] = z4; tb.r[p][q] = z4; }
+      ta.se[p] = 0.f; tb.se[p] = 0.f;
+    }
+    int ab = 0;   // buffer of tile i
+    if (!DD) {
+      if (n > 0) { d_fetch(0, ta); d_put(0, 0, ta); }
+      if (n > 1) d_fetch(1, ta);
+      cnr_lds_barrier();   // tile 0 staged
+      for (int i = 0; i <= n; ++i) {
+        const int abn = ab == 2 ? 0 : ab + 1, abp = ab == 0 ? 2 : ab - 1;
+        if (i + 1 < n) d_put(i + 1, abn, ta);
+        if (i + 2 < n) d_fetch(i + 2, ta);
+        if (i >= 1) d_acc(i - 1, abp);
+        ab = abn;
+        cnr_lds_barrier();
+      }
+    } else {
+      // tile j travels in set a for even j, in set b for odd j; a set is re-requested (tile j + 2) right after its conversion
+      if (n > 0) { d_fetch(0, ta); d_put(0, 0, ta); }
+      d_fetch(1, tb);
+      d_fetch(2, ta);
+      cnr_lds_barrier();   // tile 0 staged
+      for (int i = 0; i <= n; i += 2) {
+        {
+          const int abn = ab == 2 ? 0 : ab + 1, abp = ab == 0 ? 2 : ab - 1;
+          if (i + 1 < n) d_put(i + 1, abn, tb);
+          d_fetch(i + 3, tb);
+          if (i >= 1) d_acc(i - 1, abp);
+          ab = abn;
+          cnr_lds_barrier();
+        }
+        if (i + 1 <= n) {
+          const int abn = ab == 2 ? 0 : ab + 1, abp = ab == 0 ? 2 : ab - 1;
+          if (i + 2 < n) d_put(i + 2, abn, ta);
+          d_fetch(i + 4, ta);
+          d_acc(i, abp);
+          ab = abn;
+          cnr_lds_barrier();
+        }
+      }
     }
 
     // ---- partial sums of this (range, half): undo 2^G in two exact steps; the transposed form goes through a per-wave LDS tile so that
@@ -357,15 +413,26 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
   }
 }
 
-template <int EK>
-static void launch_fdw(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
+template <int EK, bool DP, bool DD>
+static void launch_fdw_v(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
   static DeviceOnce attr_once;
   if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = g.P / FD_TP;
   const int tpr = (int)((ntiles + f.nslots - 1) / f.nslots);
   TimingScope ts_("layer_dw", 0, 200 + EK, g.P, g.N, g.K, 1, s, fdw_bytes(g, f));
-  hipLaunchKernelGGL((layer_dw_kernel<EK>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr);
+  static const int dbg = getenv("CNR_FDW_DBG") ? atoi(getenv("CNR_FDW_DBG")) : 0;   // ablation switches (timing experiments only: results are wrong)
+  hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
+}
+template <int EK>
+static void launch_fdw(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
+  static const int deep = getenv("CNR_FDW_DEEP") ? atoi(getenv("CNR_FDW_DEEP")) : 0;   // tuning aid: bit 0 = DP, bit 1 = DD
+  switch (deep & 3) {
+    case 0: launch_fdw_v<EK, false, false>(g, f, s); break;
+    case 1: launch_fdw_v<EK, true, false>(g, f, s); break;
+    case 2: launch_fdw_v<EK, false, true>(g, f, s); break;
+    default: launch_fdw_v<EK, true, true>(g, f, s); break;
+  }
 }
 
 bool be_fdw_enabled() {

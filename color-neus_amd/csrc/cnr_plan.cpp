@@ -315,7 +315,7 @@ struct Bwd {   // backward scratch
   std::vector<FinishWeight> pending;  // reductions queued by run_dw, issued as one launch by flush_dw
   int nchunk; long chunk_pts;
   int fslots;                         // slots (point ranges) of a fused layer + weight-gradient launch (cnr_gemm_fdw.hip)
-  int cap_slots;                      // slots reserved per layer in the pool: max(nchunk, 2 * fslots)
+  int cap_slots;                      // slots reserved per layer in the pool: fslots + max(nchunk, fslots)
 };
 
 // point ranges of a fused launch: at least four 32-point tiles per range, a multiple of 8 (two column halves per range share an XCD)
@@ -356,7 +356,7 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   b.nchunk = (int)nch;
   b.chunk_pts = round_up((int)((P + nch - 1) / nch), 16);
   b.fslots = fdw_slots(P);
-  b.cap_slots = b.nchunk > 2 * b.fslots ? b.nchunk : 2 * b.fslots;
+  b.cap_slots = b.fslots + (b.nchunk > b.fslots ? b.nchunk : b.fslots);   // a fused pair + either a second fused pair or a separate GEMM over nchunk slots
   // every layer keeps its own [slots][npad][ldw] partial sums (+ bias column sums) until one batched reduction at the end
   size_t tot = 0;
   auto upd = [&](const Lin& q) { tot += round_up_sz((size_t)b.cap_slots * q.npad * q.ldw, 64) + round_up_sz((size_t)b.cap_slots * q.npad, 64); };
@@ -935,11 +935,10 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     if (fdw && sq && l < m.L && x.rsX1[l] && fdw_shape_ok(sweep_gemm(l))) fuse_g[l] = 1;
   }
   // slot groups of a region: the value pair first (it carries the bias column sums), the gradient-chain pair behind it; a pair takes
-  // fslots slots when it is fused, at most that many when it shares the region with a fused pair, and when neither is fused one launch
-  // over nchunk slots forms both
-  const int rest_slots = b.nchunk < b.fslots ? b.nchunk : b.fslots;
-  auto value_slots = [&](int l) { return fuse_v[l] ? b.fslots : (fuse_g[l] ? rest_slots : b.nchunk); };
-  auto grad_slots = [&](int l) { return fuse_g[l] ? b.fslots : (fuse_v[l] ? rest_slots : 0); };
+  // fslots slots when it is fused and nchunk slots as a separate GEMM (one workgroup per slot: fewer would leave CUs idle); when neither is
+  // fused one launch over nchunk slots forms both
+  auto value_slots = [&](int l) { return fuse_v[l] ? b.fslots : b.nchunk; };
+  auto grad_slots = [&](int l) { return fuse_g[l] ? b.fslots : (fuse_v[l] ? b.nchunk : 0); };
   for (int l = 0; l < m.L; ++l) {
     const Lin& q = m.sdf[l];
     LayerGemm g = sweep_gemm(l);
