@@ -97,10 +97,12 @@ def composite_with_background(type_, rays_o, rays_d, z, sample_dist, inv_s, sdf,
     col = (mixed * w[..., None]).sum(1)
     if background_rgb is not None:
         col = col + background_rgb * (1.0 - wsum)
-    gerr = (relax * (torch.linalg.norm(gradients, ord=2, dim=-1) - 1.0) ** 2).sum() / (relax.sum() + 1e-5)
+    eik_num, eik_den = (relax * (torch.linalg.norm(gradients, ord=2, dim=-1) - 1.0) ** 2).sum(), relax.sum()
+    gerr = eik_num / (eik_den + 1e-5)
     out = {"color_fine": col, "s_val": (1.0 / inv_s).expand(n, M).mean(-1, keepdim=True), "cdf_fine": prev_cdf, "weight_sum": wsum,
            "weight_max": torch.max(w, dim=-1, keepdim=True)[0], "gradients": gradients, "weights": w, "gradient_error": gerr,
-           "inside_sphere": inside, "depth": torch.sum(w * z_feed, -1)}
+           "inside_sphere": inside, "depth": torch.sum(w * z_feed, -1),
+           "eik_sums": torch.stack([eik_num, eik_den])}   # {sum relax*(|g|-1)^2, sum relax}: what ray-sharded training all-reduces
     if type_ == "Color_NeuS":
         w_in = alpha_in * _exclusive_transmittance(alpha_in)          # global colour is composited with the foreground weights only
         out["global_color"] = (gcolor * w_in[..., None]).sum(1)

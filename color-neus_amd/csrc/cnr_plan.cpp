@@ -419,6 +419,9 @@ static View sdf_input_view(const Model& m, int l, const float* E, const float* c
 // layer only evaluates row 0 (the sdf) and writes sign*sdf/scale... (sign folded by the caller through `top_scale`).
 static bool sdf_value_chain_fused(const Model& m, long n, const float* E, float* sdf_out, float top_scale, cnr_stream s) {
   if (m.Hs != 256 || m.L < 1) return false;
+  // what the kernel hard-codes beyond the hidden width: the top layer is not a skip layer, the last hidden layer is 256 wide and the sdf
+  // row of the top layer is readable as 256 contiguous floats; anything else stays on the per-layer path
+  if (m.skip(m.L) || m.sdf[m.L - 1].n != 256 || m.sdf[m.L].ldw < 256) return false;
   SdfValueChain c;
   c.E = E; c.P = n; c.nl = m.L; c.skip_mask = m.c.sdf_skip_mask; c.emb = m.emb;
   for (int l = 0; l < m.L; ++l) {

@@ -43,6 +43,7 @@ class ClipAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._library = library
         self._lib_obj = None
+        self._scratch = {}
 
     @property
     def _lib(self):
@@ -58,35 +59,57 @@ class ClipAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
-            ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
+            allp = list(group["params"])
+            if not any(p.grad is not None for p in allp):
                 continue
-            for p in ps:
+            for p in allp:
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("ClipAdam: parameters must be contiguous float32")
-            st = self.state.setdefault(ps[0], {})   # group state hangs off the group's first parameter (state_dict-compatible)
-            sizes = [p.numel() for p in ps]
-            total = sum(sizes)
-            if "exp_avg" not in st or st["exp_avg"].numel() != total:
-                st["step"] = 0
-                st["exp_avg"] = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
-                st["exp_avg_sq"] = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
-            st["step"] += 1
+            # The moments of a group live in two flat buffers laid out over ALL its parameters in group order (offsets fixed for the life
+            # of the optimiser), so a parameter that receives a gradient only on some steps keeps its moments and its own step count --
+            # like torch.optim.Adam's per-parameter state.  The state hangs off the group's first parameter (state_dict-compatible).
+            st = self.state.setdefault(allp[0], {})
+            sizes_all = [p.numel() for p in allp]
+            total = sum(sizes_all)
+            dev = allp[0].device
+            if "exp_avg" not in st:
+                st["exp_avg"] = torch.zeros(total, dtype=torch.float32, device=dev)
+                st["exp_avg_sq"] = torch.zeros(total, dtype=torch.float32, device=dev)
+                st["steps"] = [0] * len(allp)
+            if st["exp_avg"].numel() != total or len(st["steps"]) != len(allp):
+                raise RuntimeError("ClipAdam: the parameter list of a group changed after the first step")
             b1, b2 = group["betas"]
             mn = group.get("max_norm")
-            cfg = _lib.CnrAdamConfig(lr=float(group["lr"]), beta1=float(b1), beta2=float(b2), eps=float(group["eps"]),
-                                     max_norm=float(mn) if mn else 0.0, step=int(st["step"]))
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
-            n = len(ps)
-            sz = (C.c_int64 * n)(*sizes)
-            pw = (C.c_void_p * n)(*[p.data_ptr() for p in ps])
-            pg = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
-            dev = ps[0].device
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else C.c_void_p(0)
-            nb = self._lib.lib.cnr_clip_adam_scratch_bytes(n, sz)
-            if "scratch" not in st or st["scratch"].numel() < nb:
-                st["scratch"] = torch.empty(nb, dtype=torch.uint8, device=dev)
-            rc = self._lib.lib.cnr_clip_adam_step(C.byref(cfg), n, sz, pw, pg, C.c_void_p(st["exp_avg"].data_ptr()),
-                                                  C.c_void_p(st["exp_avg_sq"].data_ptr()), C.c_void_p(st["scratch"].data_ptr()), nb, stream)
-            self._lib.check(rc, "cnr_clip_adam_step")
+            offs = [0]
+            for z in sizes_all:
+                offs.append(offs[-1] + z)
+            # runs of consecutive parameters that have a gradient and share a step count: one library call each (normally one per group)
+            i = 0
+            while i < len(allp):
+                if allp[i].grad is None:
+                    i += 1
+                    continue
+                j = i
+                while j + 1 < len(allp) and allp[j + 1].grad is not None and st["steps"][j + 1] == st["steps"][i]:
+                    j += 1
+                ps = allp[i:j + 1]
+                for k in range(i, j + 1):
+                    st["steps"][k] += 1
+                cfg = _lib.CnrAdamConfig(lr=float(group["lr"]), beta1=float(b1), beta2=float(b2), eps=float(group["eps"]),
+                                         max_norm=float(mn) if mn else 0.0, step=int(st["steps"][i]))
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+                n = len(ps)
+                sz = (C.c_int64 * n)(*sizes_all[i:j + 1])
+                pw = (C.c_void_p * n)(*[p.data_ptr() for p in ps])
+                pg = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
+                nb = self._lib.lib.cnr_clip_adam_scratch_bytes(n, sz)
+                key = (gi, str(dev))
+                if key not in self._scratch or self._scratch[key].numel() < nb:   # scratch is not optimiser state: kept out of state_dict
+                    self._scratch[key] = torch.empty(nb, dtype=torch.uint8, device=dev)
+                rc = self._lib.lib.cnr_clip_adam_step(C.byref(cfg), n, sz, pw, pg, C.c_void_p(st["exp_avg"].data_ptr() + 4 * offs[i]),
+                                                      C.c_void_p(st["exp_avg_sq"].data_ptr() + 4 * offs[i]),
+                                                      C.c_void_p(self._scratch[key].data_ptr()), nb, stream)
+                self._lib.check(rc, "cnr_clip_adam_step")
+                i = j + 1
         return loss

@@ -57,10 +57,20 @@ class _GenRays(torch.autograd.Function):
         dev = c2w.device
         c2w_c = c2w.detach().reshape(-1, 4, 4).contiguous().float()
         focal_c = focal.detach().reshape(-1).contiguous().float().to(dev)
-        img = image.detach().contiguous().float() if image is not None else None
-        msk = mask.detach().contiguous().float() if mask is not None else None
+        # every operand is dereferenced on c2w's device: move host-resident batches there (the reference's torch ops would raise a device
+        # mismatch; a raw pointer would be a GPU memory fault) and keep the index list inside the image stack
+        img = image.detach().to(dev).contiguous().float() if image is not None else None
+        msk = mask.detach().to(dev).contiguous().float() if mask is not None else None
         org = origin.detach().reshape(-1).contiguous().float().to(dev) if origin is not None else None
-        idx = pix_idx.contiguous().to(torch.int64) if pix_idx is not None else None
+        idx = pix_idx.to(dev).contiguous().to(torch.int64) if pix_idx is not None else None
+        n_cams = c2w_c.shape[0]
+        for name, t in (("image", img), ("mask", msk)):
+            if t is not None and t.shape[0] != n_cams:
+                raise ValueError(f"{name} holds {t.shape[0]} cameras but c2w holds {n_cams}")
+        if idx is not None and idx.numel() > 0 and __debug__:
+            lo, hi = int(idx.min()), int(idx.max())
+            if lo < 0 or hi >= n_cams * H * W:
+                raise IndexError(f"pixel index range [{lo}, {hi}] outside [0, {n_cams * H * W})")
         f32 = dict(dtype=torch.float32, device=dev)
         rays_o, rays_d = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
         rgb = torch.empty(n, 3, **f32) if img is not None else None

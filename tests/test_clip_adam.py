@@ -37,7 +37,7 @@ def _run(library, device, steps=5, max_norm=0.05):
     flat_v = torch.cat([o_ref.state[p]["exp_avg_sq"].reshape(-1) for p in ref])
     assert float((st["exp_avg"] - flat_m).abs().max()) <= 1e-6 * float(flat_m.abs().max())
     assert float((st["exp_avg_sq"] - flat_v).abs().max()) <= 5e-6 * float(flat_v.abs().max())   # (the clip coefficient enters squared)
-    assert st["step"] == steps
+    assert st["steps"] == [steps] * len(ours)
 
 
 @pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
@@ -79,3 +79,43 @@ def test_backward_lays_gradients_out_in_one_flat_buffer():
     opt = cn.ClipAdam(params, lr=1e-3, max_norm=1.0, library=N.EMU_LIB)
     opt.step()
     assert any(float((a - b.detach()).abs().max()) > 0 for a, b in zip(before, params))
+
+
+def _run_intermittent(library, device):
+    """A parameter that receives a gradient only on some steps (auxiliary / background parameters) keeps its moments and its own step
+    count, exactly like torch.optim.Adam's per-parameter state; the others are unaffected by its absence."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 33), (64,), (5, 7), (129,)]
+    ref = [torch.randn(s, generator=g).to(device).requires_grad_(True) for s in shapes]
+    ours = [p.detach().clone().requires_grad_(True) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    o_our = cn.ClipAdam(ours, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, max_norm=None, library=library)
+    for it in range(6):
+        for i, (p, q) in enumerate(zip(ref, ours)):
+            if (i == 2 and it % 2 == 1) or (i == 0 and it == 3):   # no gradient for these tensors on these steps (incl. the first one of the group)
+                p.grad = None
+                q.grad = None
+                continue
+            gr = torch.randn(p.shape, generator=g).to(device)
+            p.grad = gr.clone()
+            q.grad = gr.clone()
+        o_ref.step()
+        o_our.step()
+    for p, q in zip(ref, ours):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-6 * max(1.0, float(p.detach().abs().max())), p.shape
+    assert o_our.state[ours[0]]["steps"] == [5, 6, 3, 6]
+    sd = o_our.state_dict()            # round trip: the scratch buffer is not part of the state
+    assert set(sd["state"][0].keys()) == {"exp_avg", "exp_avg_sq", "steps"}
+    o2 = cn.ClipAdam(ours, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, max_norm=None, library=library)
+    o2.load_state_dict(sd)
+    assert o2.state[ours[0]]["steps"] == [5, 6, 3, 6]
+
+
+@pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
+def test_clip_adam_intermittent_gradients_emu():
+    _run_intermittent(N.EMU_LIB, "cpu")
+
+
+@pytest.mark.gpu
+def test_clip_adam_intermittent_gradients_hip():
+    _run_intermittent(None, "cuda:0")

@@ -61,6 +61,9 @@ def test_nerfpp_background_fallback(name, tag):
             assert G.relerr(out[k].detach().reshape(fx[f"{tag}:out_{k}"].shape), fx[f"{tag}:out_{k}"]) < TOL, k
     assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
     assert any(k.startswith("nerf.") for k in grads)
+    # the ray-sharded objective needs the two eikonal sums of the shard (parallel.sharded_loss): same ratio as gradient_error
+    es = out["eik_sums"].detach()
+    assert es.shape == (2,) and abs(float(es[0] / (es[1] + 1e-5)) - float(out["gradient_error"].detach())) < 1e-6
     bad = G.check_param_grads(fx, tag, grads)
     assert not bad, bad
     for key, got in (("grad_rays_o", o.grad), ("grad_rays_d", d.grad)):
