@@ -7,7 +7,8 @@ import _golden as G
 import color_neus_amd as cn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU_LIB = os.path.join(ROOT, "tests", "_build", "libcolorneus_emu.so")
+# CNR_EMU_LIB: an alternative build of the CPU emulation (tools/run_sanitizers.sh points it at the ASan / UBSan build)
+EMU_LIB = os.environ.get("CNR_EMU_LIB") or os.path.join(ROOT, "tests", "_build", "libcolorneus_emu.so")
 
 
 def render_config_from_oracle(ocfg) -> cn.RenderConfig:
