@@ -16,11 +16,16 @@ Extra objects on the JSON line:
                       work (3 f16 MFMAs per fp32 product) against the 2.5 PFLOP/s dense f16 peak (mfma_frac).  Measured in a second,
                       event-instrumented pass over the same steps.
   kernel_breakdown    per kernel family: ms per step, GB/s (algorithmic), TFLOP/s -- includes the sampler / compositor kernels.
+  step_ms             per-step HIP-event times of the K timed steps (events on the launch stream, rank 0): median, p10, p90, and the
+                      rate the median implies (SURVEY 8d protocol); `value` itself stays K steps over the barrier-to-barrier wall time.
+  inference           forward-only rays/s (validate_image, NeuS_Trainer.py:216-277) without and with the early-termination compaction
+                      (prune_eps 1e-4: wavefront ballot / popcount, north_star), bounded sample.
+  c5                  BASELINE config 5 on this GPU: 512^3 SDF lattice (extract_fields), device marching cubes, 500 k vertex colours.
   small_batch         rays/s of the same step at 512 and 1024 rays per step (the reference trains at N_RAYS 1024; 512 is C4's per-GPU share).
   torch_gpu_baseline  the plain-PyTorch restatement of the reference algorithm (oracle/) on the same GPU, bounded sample: the
                       stand-in for "reference single-GPU PyTorch" (the reference's own Python cannot travel to the GPU box).
   cpu_baseline        the same restatement on the host cores (contract object: best thread count), plus cpu_baseline_1thread (the
-                      reference pins OMP/MKL to one thread, train.py:4-8) and cpu_baseline_allcores; bounded samples, rank 0, N = 1 only.
+                      reference pins OMP/MKL to one thread, train.py:4-8); warmed, bounded samples, rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -37,7 +42,7 @@ import torch.distributed as dist
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
 F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (no sparsity)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s measured with a float4 copy)
-SPLIT_F16_KERNELS = ("layer_gemm_ws", "dw_gemm_hx", "chain_sdf_value")   # 3 f16 MFMAs per fp32-equivalent product
+SPLIT_F16_KERNELS = ("layer_gemm_ws", "layer_dw", "dw_gemm_hx", "chain_sdf_value")   # 3 f16 MFMAs per fp32-equivalent product
 
 
 def parse():
@@ -54,6 +59,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true")
+    ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the contract CPU baseline (16 was the fastest of {8,16,32,64,128} on the 2x64-core bench host)")
@@ -154,21 +161,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed(nsteps, warmup, r=None, alt=None):
+    def timed(nsteps, warmup, r=None, alt=None, per_step=None):
         for i in range(warmup):
             step(i, r, alt)
         sync()
+        # per-step HIP events on the stream every kernel of the step is launched on (torch's current stream): nsteps + 1 marks
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)] if per_step is not None else None
         t0 = time.perf_counter()
         for i in range(nsteps):
+            if marks:
+                marks[i].record()
             loss = step(warmup + i, r, alt)
+        if marks:
+            marks[nsteps].record()
         sync()
         dt = time.perf_counter() - t0
+        if marks:
+            per_step.extend(marks[i].elapsed_time(marks[i + 1]) for i in range(nsteps))
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), loss
 
-    dt, loss = timed(args.steps, args.warmup)
+    step_times = []
+    dt, loss = timed(args.steps, args.warmup, per_step=step_times)
     Rg = R * world
     ms_per_step = dt / args.steps * 1e3
     value = Rg * args.steps / dt
@@ -188,6 +204,13 @@ def main():
                            (("+rccl-allreduce" if backend == "nccl" else "+%s-allreduce" % backend) if world > 1 else ""),
                    "final_loss": float(loss.detach())},
     }
+
+    if step_times:
+        st = sorted(step_times)
+        pick = lambda q: st[min(len(st) - 1, int(q * len(st)))]
+        result["step_ms"] = {"median": round(pick(0.5), 3), "p10": round(pick(0.1), 3), "p90": round(pick(0.9), 3), "n": len(st),
+                             "rays_per_s_at_median": round(R / (pick(0.5) * 1e-3) * world, 1),
+                             "note": "HIP events on the launch stream around each timed step (rank 0); includes the host's launch gaps"}
 
     # ---- roofline of the dominant kernel: event-instrumented pass over the same steps (rank 0)
     if not args.no_roofline:
@@ -213,6 +236,8 @@ def main():
         desc = {"layer_gemm_ws": "layer_gemm_ws_kernel (weight-stationary layer GEMM: 256x256 layer held in registers as two f16 "
                                  "planes, 3 f16 MFMA 32x32x16 per product with exact power-of-two row scaling, points streamed "
                                  "HBM->LDS->MFMA->HBM with fused prologue/epilogue)",
+                "layer_dw": "layer_dw_kernel (backward layer GEMM + the weight gradient of the same layer in one launch: column halves, 4 product waves "
+                            "with the weights in registers + 4 waves that stage the input tile and accumulate dW from the on-chip operands, 3 f16 MFMA per product)",
                 "layer_gemm": "layer_gemm_kernel (FP32 MFMA 32x32x2, 128-point tile)",
                 "dw_gemm": "dw_gemm_kernel (FP32 MFMA weight-gradient GEMM, output-stationary)"}.get(dom_name, dom_name)
         gbs = dom[3] / (dom[0] * 1e-3) / 1e9
@@ -220,9 +245,17 @@ def main():
         f16_tfl = 3.0 * tfl if dom_name in SPLIT_F16_KERNELS else None
         # Every layer launch streams its operand matrices once (1-4 KB per point in, 1-2 KB out) against 131 kFLOP per point: the
         # launch is bound by HBM bytes, not by the matrix pipe -- both fractions are reported so that the claim can be checked.
-        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                "mfma_frac": round(f16_tfl / F16_MFMA_PEAK_TFLOPS, 4) if f16_tfl else round(tfl / FP32_MFMA_PEAK_TFLOPS, 4),
+        hbm_frac = gbs / HBM_PEAK_GBS
+        mfma_frac = f16_tfl / F16_MFMA_PEAK_TFLOPS if f16_tfl else tfl / FP32_MFMA_PEAK_TFLOPS
+        # the bound is whichever resource the launch uses the larger share of (computed, not assumed): frac / achieved / peak / unit follow it
+        if hbm_frac >= mfma_frac:
+            head = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
+        else:
+            head = {"bound": "mfma", "achieved": round(f16_tfl or tfl, 1), "peak": F16_MFMA_PEAK_TFLOPS if f16_tfl else FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(mfma_frac, 4)}
+        roof = {**head,
+                "hbm_frac": round(hbm_frac, 4), "hbm_achieved_gbs": round(gbs, 1),
+                "mfma_frac": round(mfma_frac, 4),
                 "mfma_achieved_tflops": round(f16_tfl, 1) if f16_tfl else round(tfl, 1),
                 "mfma_peak_tflops": F16_MFMA_PEAK_TFLOPS if f16_tfl else FP32_MFMA_PEAK_TFLOPS,
                 "mfma_note": "f16 MFMA FLOP/s actually issued (3 per fp32-equivalent product) against the 2.5 PFLOP/s dense f16 peak" if f16_tfl
@@ -233,7 +266,7 @@ def main():
         # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed summary
         # of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py)
         traffic, tfile = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             cand = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic_%drays.json" % (rnd, R))
             if os.path.exists(cand):
                 t = json.load(open(cand))["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
@@ -277,6 +310,54 @@ def main():
         n = max(20, min(args.steps, 60))
         dts, _ = timed(n, 5, 512, alt)
         result["small_batch"]["c2_512rays_x_64samples_no_importance"] = round(512 * world * n / dts, 1)
+
+    # ---- inference use of the path (validate_image, NeuS_Trainer.py:216-277): forward only, EVAL-style chunks, without / with the
+    # early-termination compaction (colour / relight stacks only on samples with weight >= eps: ballot + popcount compaction, inference only)
+    if not args.no_inference and rank == 0:
+        Ri = 8192
+        o, d, near, far, _, _ = batch(0, Ri)
+        inf = {}
+        with torch.no_grad():
+            ref = renderer(o, d, near, far, perturb_overwrite=0)
+            for eps in (0.0, 1e-4):
+                for _ in range(2):
+                    out = renderer(o, d, near, far, perturb_overwrite=0, prune_eps=eps)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    out = renderer(o, d, near, far, perturb_overwrite=0, prune_eps=eps)
+                torch.cuda.synchronize(dev)
+                dti = (time.perf_counter() - t1) / 5
+                inf["prune_eps_%g" % eps] = {"rays_per_s": round(Ri / dti, 1), "ms": round(dti * 1e3, 2),
+                                             "kept_fraction": round(float((out["weights"] >= eps).float().mean()), 3) if eps > 0 else 1.0,
+                                             "max_abs_color_diff": float((out["color_fine"] - ref["color_fine"]).abs().max())}
+        result["inference"] = {"unit": "rays/s", "sample": "5 forward passes of %d rays x 128 samples, no jitter, DTU renderer block" % Ri, **inf}
+
+    # ---- BASELINE config 5 (evaluation.py -rr 512): dense SDF lattice + device marching cubes + vertex colours, one pass each
+    if not args.no_c5 and rank == 0:
+        res_, nv = 512, 500000
+        renderer.extract_fields([-1.01] * 3, [1.01] * 3, dev, 64)   # warm-up
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        u = renderer.extract_fields([-1.01] * 3, [1.01] * 3, dev, res_)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        mv, mt = renderer.marching_cubes(u, [-1.01] * 3, [1.01] * 3, 0.0)
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        gv = torch.Generator().manual_seed(3)
+        v = torch.randn(nv, 3, generator=gv)
+        v = (v / v.norm(dim=-1, keepdim=True) * (0.5 + 0.02 * torch.randn(nv, 1, generator=gv))).numpy()
+        renderer.extract_color(v[:1000], dev)
+        torch.cuda.synchronize(dev)
+        t4 = time.perf_counter()
+        renderer.extract_color(v, dev)
+        t5 = time.perf_counter()
+        result["c5"] = {"lattice": "%d^3" % res_, "lattice_s": round(t2 - t1, 3), "lattice_Mpts_per_s": round(res_ ** 3 / (t2 - t1) / 1e6, 1),
+                        "marching_cubes_ms": round((t3 - t2) * 1e3, 2), "mesh_vertices": int(mv.shape[0]), "mesh_triangles": int(mt.shape[0]),
+                        "vertex_colours": nv, "vertex_colour_ms": round((t5 - t4) * 1e3, 2),
+                        "note": "extract_fields / extract_geometry / extract_color (NeuS.py:14-64) on the device; vertex colours include the H2D / D2H of the caller's numpy arrays"}
+        del u, mv, mt
 
     # ---- the plain-PyTorch restatement on the same GPU (the 'reference single-GPU PyTorch' stand-in), bounded sample
     if not args.no_torch_gpu_baseline and rank == 0:
@@ -344,10 +425,6 @@ def main():
         v1, n1 = cpu_rate(1, 32, 8.0, 1)
         result["cpu_baseline_1thread"] = {"value": round(v1, 2), "unit": "rays/s", "cores": 1, "kind": "port",
                                           "sample": "%d iterations of 32 rays x (64+64) samples, one thread (the reference pins OMP/MKL to 1, train.py:4-8)" % n1}
-        # torch CPU ops oversubscribe badly on this many threads (0.5 rays/s on 256): one small iteration without warm-up bounds the run
-        va, na = cpu_rate(ncpu, 8, 0.0, 1, warm=False)
-        result["cpu_baseline_allcores"] = {"value": round(va, 2), "unit": "rays/s", "cores": ncpu, "kind": "port",
-                                           "sample": "%d iteration of 8 rays x (64+64) samples, no warm-up, torch threads = all %d logical CPUs" % (na, ncpu)}
 
     if rank == 0:
         print(json.dumps(result))

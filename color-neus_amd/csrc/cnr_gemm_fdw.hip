@@ -420,7 +420,7 @@ static void launch_fdw_v(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = g.P / FD_TP;
   const int tpr = (int)((ntiles + f.nslots - 1) / f.nslots);
-  TimingScope ts_("layer_dw", 0, 200 + EK, g.P, g.N, g.K, 1, s, fdw_bytes(g, f));
+  TimingScope ts_("layer_dw", 0, 200 + EK, g.P, g.N, g.K, 2, s, fdw_bytes(g, f));   // pairs = 2: the layer product + the weight-gradient product
   static const int dbg = getenv("CNR_FDW_DBG") ? atoi(getenv("CNR_FDW_DBG")) : 0;   // ablation switches (timing experiments only: results are wrong)
   hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
 }

@@ -1,5 +1,6 @@
-"""Device iso-surface extraction (cnr_mc_count / cnr_mc_emit).  There is no mcubes fixture (PyMCubes is not
-installed, its output is unpinned), so the checks are what any correct marching-cubes mesh of a closed level set satisfies:
+"""Device iso-surface extraction (cnr_mc_count / cnr_mc_emit): mesh INVARIANTS.  The comparison with the independent
+float64 restatement of the published algorithm lives in tests/test_mc_oracle.py; here are the properties any correct marching-cubes mesh
+of a closed level set satisfies:
 every edge is shared by exactly two triangles with opposite orientation, the Euler characteristic of a sphere is 2 (a torus 0),
 vertices lie on the lattice edges at the linear zero crossing, normals point out of the inside region, and the enclosed volume
 converges to the analytic one.  The CPU-emulation build and the HIP kernels must emit the identical mesh."""
