@@ -1036,7 +1036,7 @@ static void layout_eval(Model& m, long chunk, Arena& a, EvalBuf& e) {
 }
 
 static int sdf_eval_impl(const cnr_config* cfg, const float* const* params, const float* pts, const float* bmin, const float* bmax,
-                         int res, long n, float sign, float* out, void* scratch, size_t scratch_bytes, cnr_stream s) {
+                         int res, long n, float sign, float* out, void* scratch, size_t scratch_bytes, cnr_stream s, long lattice_start = 0) {
   Model m;
   if (build_model(cfg, m)) return -1;
   if (!params || !out || !scratch) return fail("null argument");
@@ -1051,7 +1051,7 @@ static int sdf_eval_impl(const cnr_config* cfg, const float* const* params, cons
   for (long start = 0; start < n; start += chunk) {
     const long cnt = (n - start) < chunk ? (n - start) : chunk;
     EmbedPts ep;
-    ep.pts = pts ? pts + start * 3 : nullptr; ep.n = cnt; ep.res = res; ep.start = start;
+    ep.pts = pts ? pts + start * 3 : nullptr; ep.n = cnt; ep.res = res; ep.start = lattice_start + start;
     for (int c = 0; c < 3; ++c) { ep.bmin[c] = bmin ? bmin[c] : 0.f; ep.bmax[c] = bmax ? bmax[c] : 0.f; }
     ep.scale = m.c.sdf_scale; ep.multires = m.c.sdf_multires; ep.E = e.E; ep.AUX = nullptr;
     be_embed_pts(ep, s);
@@ -1323,6 +1323,20 @@ int cnr_sdf_grid(const cnr_config* cfg, const float* const* params, const float*
   if (!bound_min || !bound_max || resolution < 2) return fail("bad lattice");
   const long n = (long)resolution * resolution * resolution;
   return sdf_eval_impl(cfg, params, nullptr, bound_min, bound_max, resolution, n, -1.0f, u, scratch, scratch_bytes, (cnr_stream)stream);
+}
+
+size_t cnr_sdf_grid_slab_scratch_bytes(const cnr_config* cfg, int32_t resolution, int32_t x_begin, int32_t x_end) {
+  if (x_begin < 0 || x_end > resolution || x_begin >= x_end) return 0;
+  return eval_scratch_bytes(cfg, (long)(x_end - x_begin) * resolution * resolution);
+}
+
+int cnr_sdf_grid_slab(const cnr_config* cfg, const float* const* params, const float* bound_min, const float* bound_max, int32_t resolution,
+                      int32_t x_begin, int32_t x_end, float* u_slab, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!bound_min || !bound_max || resolution < 2) return fail("bad lattice");
+  if (x_begin < 0 || x_end > resolution || x_begin >= x_end) return fail("sdf_grid_slab: need 0 <= x_begin < x_end <= resolution");
+  const long plane = (long)resolution * resolution;
+  return sdf_eval_impl(cfg, params, nullptr, bound_min, bound_max, resolution, (long)(x_end - x_begin) * plane, -1.0f, u_slab, scratch, scratch_bytes,
+                       (cnr_stream)stream, (long)x_begin * plane);
 }
 
 static int mc_layout(int32_t res, float thr, const float* u, void* scratch, size_t scratch_bytes, McVolume& v) {

@@ -14,6 +14,74 @@ import torch
 import torch.distributed as dist
 
 
+def _world(group=None):
+    return (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+
+
+def _gather_rows(local, counts, dst, group):
+    """Blocks of rows of unequal height from every rank -> one tensor on rank dst (None elsewhere): padded to the tallest block, gathered, trimmed."""
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    hmax = max(counts)
+    pad = torch.zeros((hmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def sharded_extract_fields(renderer, bound_min, bound_max, device, resolution, group=None, dst=0):
+    """extract_fields (NeuS.py:14-28) over the ranks of a node: rank r evaluates a slab of lattice rows x, the slabs are gathered on rank
+    ``dst`` (returns the [res, res, res] volume there, None elsewhere).  No data-path collective besides that gather."""
+    rank, world = _world(group)
+    per = (resolution + world - 1) // world
+    bounds = [(min(r * per, resolution), min((r + 1) * per, resolution)) for r in range(world)]
+    x0, x1 = bounds[rank]
+    if x1 > x0:
+        slab = renderer.extract_fields_slab(bound_min, bound_max, device, resolution, x0, x1)
+    else:
+        slab = torch.empty(0, resolution, resolution, dtype=torch.float32, device=torch.device(device))
+    return _gather_rows(slab, [b - a for a, b in bounds], dst, group)
+
+
+def sharded_render_image(renderer, rays_o, rays_d, near, far, chunk=1024, group=None, dst=0, keys=("color_fine", "depth"), **render_kw):
+    """validate_image's render loop (NeuS_Trainer.py:233-245: all rays of a view in EVAL_RAY_SIZE chunks, only colour and depth consumed)
+    over the ranks of a node: contiguous, chunk-aligned blocks of chunks per rank, results gathered on rank ``dst`` ({key: tensor} there,
+    None elsewhere).  Every rank holds the full ray set (cheap: 32 B / ray) and walks ALL chunks in order so that the per-chunk jitter
+    draws from the CPU generator (the reference jitters in eval mode too, NeuS.py:320-326) are the ones a single process makes; it renders
+    only its own chunks."""
+    rank, world = _world(group)
+    n = rays_o.shape[0]
+    nchunks = (n + chunk - 1) // chunk
+    per = (nchunks + world - 1) // world
+    c0, c1 = min(rank * per, nchunks), min((rank + 1) * per, nchunks)
+    perturb = render_kw.get("perturb_overwrite", -1)
+    draws = perturb != 0 and (perturb > 0 or renderer.perturb > 0)
+    parts = {k: [] for k in keys}
+    with torch.no_grad():
+        for c in range(nchunks):
+            a, b = c * chunk, min((c + 1) * chunk, n)
+            if c0 <= c < c1:
+                out = renderer(rays_o[a:b], rays_d[a:b], near[a:b], far[a:b], **render_kw)
+                for k in keys:
+                    parts[k].append(out[k].reshape(b - a, -1))
+            elif draws:   # another rank's chunk: keep the generator in step (NeuS.py:325, and :335 for the background samples)
+                torch.rand([b - a, 1])
+                if getattr(renderer, "n_outside", 0) > 0:
+                    torch.rand([b - a, renderer.n_outside])
+    counts = [max(0, min((r + 1) * per, nchunks) * chunk - min(r * per, nchunks) * chunk) for r in range(world)]
+    counts = [min(cnt, max(0, n - min(r * per, nchunks) * chunk)) for r, cnt in enumerate(counts)]
+    res = {}
+    for k in keys:
+        width = {"color_fine": 3}.get(k, 1)
+        local = torch.cat(parts[k], 0) if parts[k] else torch.empty(0, width, dtype=torch.float32, device=rays_o.device)
+        res[k] = _gather_rows(local, counts, dst, group)
+    return res if rank == dst else None
+
+
 def shard_slice(n_rays: int, rank: int, world: int) -> slice:
     """Contiguous block of rays for this rank (n_rays must divide evenly so every rank does equal work)."""
     if n_rays % world != 0:

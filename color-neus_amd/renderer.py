@@ -469,6 +469,19 @@ class NeuSRenderer(nn.Module):
         self._lib.check(rc, "cnr_sdf_grid")
         return u
 
+    def extract_fields_slab(self, bound_min, bound_max, device, resolution, x_begin, x_end):
+        """Rows x in [x_begin, x_end) of extract_fields' lattice (same values): the unit of the sharded evaluation (parallel.sharded_extract_fields)."""
+        bmin = (C.c_float * 3)(*[float(x) for x in bound_min])
+        bmax = (C.c_float * 3)(*[float(x) for x in bound_max])
+        dev = torch.device(device)
+        u = torch.empty(x_end - x_begin, resolution, resolution, dtype=torch.float32, device=dev)
+        plist, parr = self._param_array()
+        nb = self._lib.lib.cnr_sdf_grid_slab_scratch_bytes(C.byref(self._ccfg), resolution, x_begin, x_end)
+        scratch = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+        rc = self._lib.lib.cnr_sdf_grid_slab(C.byref(self._ccfg), parr, bmin, bmax, resolution, x_begin, x_end, _ptr(u), _ptr(scratch), nb, _stream_of(u))
+        self._lib.check(rc, "cnr_sdf_grid_slab")
+        return u
+
     def marching_cubes(self, u, bound_min, bound_max, threshold=0.0):
         """Iso-surface of a device-resident lattice u[x][y][z] (cnr_mc_count / cnr_mc_emit): returns device tensors
         (vertices [V, 3] float32 in world coordinates, triangles [F, 3] int32)."""

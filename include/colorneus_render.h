@@ -215,6 +215,11 @@ int cnr_sdf_eval(const cnr_config* cfg, const float* const* params, const float*
 size_t cnr_sdf_grid_scratch_bytes(const cnr_config* cfg, int32_t resolution);
 int cnr_sdf_grid(const cnr_config* cfg, const float* const* params, const float* bound_min, const float* bound_max,
                  int32_t resolution, float* u, void* scratch, size_t scratch_bytes, void* stream);
+/* the slab x in [x_begin, x_end) of the same lattice (u_slab[x - x_begin][y][z], identical values): extract_fields sharded over the GPUs
+ * of a node, one slab per rank, gathered by the caller (the reference walks the lattice in 64^3 blocks, NeuS.py:19-27) */
+size_t cnr_sdf_grid_slab_scratch_bytes(const cnr_config* cfg, int32_t resolution, int32_t x_begin, int32_t x_end);
+int cnr_sdf_grid_slab(const cnr_config* cfg, const float* const* params, const float* bound_min, const float* bound_max, int32_t resolution,
+                      int32_t x_begin, int32_t x_end, float* u_slab, void* scratch, size_t scratch_bytes, void* stream);
 
 /* extract_geometry's iso-surface step on the device-resident lattice (NeuS.py:31-40 calls the third-party CPU mcubes.marching_cubes on
  * a host copy of u): marching cubes over u[x][y][z] at `threshold`, "inside" = u > threshold, vertices on the lattice edges by linear
