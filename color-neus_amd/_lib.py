@@ -27,7 +27,7 @@ class CnrInputs(C.Structure):
 
 OUTPUT_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
                  "inside_sphere", "depth", "global_color", "delta_relight", "z_vals", "eik_sums", "sdf_samples", "color_samples",
-                 "global_color_samples"]
+                 "global_color_samples", "delta_relight_ray_sum"]
 OUT_GRAD_FIELDS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
                    "depth", "global_color", "delta_relight", "sdf_samples", "color_samples", "global_color_samples",
                    "delta_relight_per_ray"]
@@ -81,7 +81,7 @@ def c_config(cfg) -> CnrConfig:
 EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_count", "cnr_param_info", "cnr_ctx_bytes",
            "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_sdf_grid_slab_scratch_bytes", "cnr_sdf_grid_slab", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
-           "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_grads",
+           "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_sums_ray", "cnr_loss_grads",
            "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward", "cnr_sample_z", "cnr_mc_scratch_bytes", "cnr_mc_count", "cnr_mc_emit"]
 
 
@@ -119,6 +119,7 @@ class RenderLibrary:
         L.cnr_loss_scratch_bytes.restype = C.c_size_t
         L.cnr_loss_scratch_bytes.argtypes = [C.c_int64]
         L.cnr_loss_sums.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_size_t, _FP]
+        L.cnr_loss_sums_ray.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_size_t, _FP]
         L.cnr_loss_grads.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, _FP, _FP]
         L.cnr_sample_pdf.argtypes = [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, _FP]
         L.cnr_up_sample.argtypes = [_FP, _FP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_float, _FP, _FP]
@@ -138,7 +139,7 @@ class RenderLibrary:
         L.cnr_timing_enable.argtypes = [C.c_int]
         L.cnr_timing_enable.restype = None
         L.cnr_timing_collect.argtypes = [C.POINTER(CnrKernelTiming), C.c_int]
-        if L.cnr_abi_version() != 2:
+        if L.cnr_abi_version() != 3:
             raise RuntimeError("colorneus library ABI mismatch")
 
     @property

@@ -90,6 +90,7 @@ struct CompositeFwd {   // Color_NeuS.py:66-123, NeuS.py:382-399
   float* eik_partial;    // [R][2]
   // optional per-sample copies of the network outputs for callers that composite themselves (N_OUTSIDE > 0 background mixing)
   float* sdf_s; float* color_s; float* gcolor_s;   // [P], [P][3], [P][3] or null
+  const float* delta = nullptr; float* delta_ray_sum = nullptr;   // optional: [P][3] relight offsets -> [R] sums over samples and rgb
 };
 
 // inference-only early-termination compaction: samples whose compositing weight is below eps contribute < eps to the pixel,
@@ -220,6 +221,7 @@ void be_memset_zero(void* p, size_t bytes, cnr_stream s);
 struct LossArgs {
   const float* color; const float* wsum; const float* drel; const float* gt; const float* mask;
   long R; int M; int rgb_l1; int include_mask;
+  int drel_per_ray = 0;   // 1: drel is [R], the per-ray sums over samples and rgb (CompositeFwd::delta_ray_sum)
 };
 constexpr int kLossBlocks = 256;
 void be_loss_sums(const LossArgs& a, float* partial /* [kLossBlocks][4] */, float* sums /* [4] */, cnr_stream s);

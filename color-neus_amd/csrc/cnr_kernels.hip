@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs a, flo
   if (a.mask)
     for (long r = (long)b * 256 + tid; r < a.R; r += (long)nb * 256) s_bce += loss_bce_term(a.wsum[r], a.mask[r]);
   if (a.drel) {
-    const long per_ray = (long)a.M * 3, n_rel = a.R * per_ray;
+    const long per_ray = a.drel_per_ray ? 1 : (long)a.M * 3, n_rel = a.R * per_ray;
     for (long i = (long)b * 256 + tid; i < n_rel; i += (long)nb * 256) {
       const float m = (a.include_mask && a.mask) ? a.mask[i / per_ray] : 1.0f;
       s_rel += a.drel[i] * m;
@@ -757,12 +757,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeFwd p
   const float inv_s = fminf(fmaxf(expf(p.variance[0] * 10.0f), 1e-6f), 1e6f);
 
   float carry = 1.0f;
-  float wsum = 0.f, wmax = -1.f, dep = 0.f, col[3] = {0.f, 0.f, 0.f}, gcl[3] = {0.f, 0.f, 0.f}, e0 = 0.f, e1 = 0.f;
+  float wsum = 0.f, wmax = -1.f, dep = 0.f, col[3] = {0.f, 0.f, 0.f}, gcl[3] = {0.f, 0.f, 0.f}, e0 = 0.f, e1 = 0.f, drs = 0.f;
 #pragma unroll
   for (int c = 0; c < kRayChunks; ++c) {
     if (c * 64 < M) {
       const int j = c * 64 + lane;
       const long pt = ray * M + j;
+      if (p.delta && j < M) drs += (p.delta[pt * 3] + p.delta[pt * 3 + 1]) + p.delta[pt * 3 + 2];
       RaySample q = ray_sample(zs, j, M, p.sample_dist, o, d, p.sdf, p.g, pt, inv_s, p.cos_anneal);
       const float f = q.ok ? 1.0f - q.a.alpha + 1e-7f : 1.0f;
       const float incl = wave_scan_incl_mul(f, lane);
@@ -790,6 +791,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeFwd p
   wsum = wave_sum(wsum); wmax = wave_max(wmax); dep = wave_sum(dep);
   for (int k = 0; k < 3; ++k) { col[k] = wave_sum(col[k]); gcl[k] = wave_sum(gcl[k]); }
   e0 = wave_sum(e0); e1 = wave_sum(e1);
+  if (p.delta_ray_sum) { drs = wave_sum(drs); if (lane == 0 && active) p.delta_ray_sum[ray] = drs; }
   if (lane == 0 && active) {
     for (int k = 0; k < 3; ++k) {
       float cc = col[k];

@@ -30,7 +30,7 @@ void be_loss_sums(const LossArgs& a, float* partial, float* sums, cnr_stream) {
   for (long i = 0; i < a.R * 3; ++i) s_rgb += loss_rgb_term(a.color[i], a.gt[i], a.rgb_l1);
   if (a.mask) for (long r = 0; r < a.R; ++r) s_bce += loss_bce_term(a.wsum[r], a.mask[r]);
   if (a.drel) {
-    const long per_ray = (long)a.M * 3;
+    const long per_ray = a.drel_per_ray ? 1 : (long)a.M * 3;
     for (long i = 0; i < a.R * per_ray; ++i) s_rel += a.drel[i] * ((a.include_mask && a.mask) ? a.mask[i / per_ray] : 1.0f);
   }
   sums[0] = (float)s_rgb; sums[1] = (float)s_bce; sums[2] = (float)s_rel; sums[3] = 0.f;
@@ -400,6 +400,11 @@ void be_composite_fwd(const CompositeFwd& p, cnr_stream) {
     }
     p.weight_sum[ray] = wsum; p.weight_max[ray] = wmax; p.depth[ray] = dep; p.s_val[ray] = 1.0f / inv_s;
     p.eik_partial[ray * 2] = e0; p.eik_partial[ray * 2 + 1] = e1;
+    if (p.delta && p.delta_ray_sum) {
+      float drs = 0.f;
+      for (long i = ray * M * 3; i < (ray + 1) * M * 3; ++i) drs += p.delta[i];
+      p.delta_ray_sum[ray] = drs;
+    }
   }
 }
 

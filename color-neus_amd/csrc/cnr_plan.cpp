@@ -225,6 +225,7 @@ struct Arena {
 struct Ctx {   // forward-saved state
   // effective weights live in the Lin structs
   float *E, *AUX, *sdf, *featx, *hry, *CE0, *CES, *gcol, *relit, *eik_partial, *eik_sums;
+  float *gbuf, *delta_s;   // [P][3] each: sdf gradients / relight offsets when the caller does not take them as outputs ("loss only" training)
   // early-termination compaction (inference): compact copies of the colour-chain inputs/outputs + index list
   float *featx_c, *aux_c, *gcol_c, *relit_c, *delta_c; int *p_idx, *p_counts, *p_offsets;
   int ldfx = 0, ldy = 0;   // row strides of featx = [feat | aux | 0] and hry = [relight hidden | global colour | 0]
@@ -271,6 +272,8 @@ static void layout_ctx(Model& m, long R, Arena& a, Ctx& x) {
   x.relit = a.f((size_t)P * 4);
   x.eik_partial = a.f((size_t)R * 2);
   x.eik_sums = a.f(64);
+  x.gbuf = a.f((size_t)P * 3);
+  x.delta_s = m.has_relight ? a.f((size_t)P * 3) : nullptr;
   x.Z.resize(m.L); x.V.resize(m.L);
   for (int l = 0; l < m.L; ++l) x.Z[l] = a.f((size_t)P * m.Hs);
   for (int l = 0; l + 1 < m.L; ++l) x.V[l] = a.f((size_t)P * m.Hs);
@@ -610,10 +613,14 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   Ctx x;
   layout_ctx(m, R, a, x);
   if (a.off > ctx_bytes) return fail("context buffer too small: need %zu bytes, got %zu", a.off, ctx_bytes);
-  if (!out->z_vals || !out->gradients || !out->weights || !out->color_fine || !out->cdf_fine || !out->inside_sphere ||
+  if (!out->z_vals || !out->weights || !out->color_fine || !out->cdf_fine || !out->inside_sphere ||
       !out->weight_sum || !out->weight_max || !out->depth || !out->s_val || !out->gradient_error)
     return fail("missing output buffer");
-  if (m.has_relight && (!out->delta_relight || !out->global_color)) return fail("Color_NeuS needs delta_relight and global_color buffers");
+  if (m.has_relight && !out->global_color) return fail("Color_NeuS needs a global_color buffer");
+  if (m.has_relight && !out->delta_relight && !out->delta_relight_ray_sum) return fail("Color_NeuS needs delta_relight or delta_relight_ray_sum");
+  if (in->prune_eps > 0.0f && m.has_relight && !out->delta_relight) return fail("prune_eps > 0 needs the delta_relight buffer");
+  float* const g_out = out->gradients ? out->gradients : x.gbuf;                       // "loss only" callers leave both to the context buffer
+  float* const delta_out = m.has_relight ? (out->delta_relight ? out->delta_relight : x.delta_s) : nullptr;
   const long P = R * m.M;
   const float scale = m.c.sdf_scale;
 
@@ -632,11 +639,11 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   GradFinish gf;
   gf.featx = x.featx; gf.ldfx = x.ldfx; gf.F = m.F;
   gf.P = P; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES + skip_off(m) : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
-  gf.grad_out = out->gradients; gf.AUX = x.AUX; gf.neg_g_as_view = 0; gf.multires_view = m.mv;
+  gf.grad_out = g_out; gf.AUX = x.AUX; gf.neg_g_as_view = 0; gf.multires_view = m.mv;
   be_grad_finish(gf, s);
   CompositeFwd cf;
   cf.o = in->rays_o; cf.d = in->rays_d; cf.z = out->z_vals; cf.R = R; cf.M = m.M; cf.sample_dist = 2.0f / (float)m.S;
-  cf.sdf = x.sdf; cf.g = out->gradients;
+  cf.sdf = x.sdf; cf.g = g_out;
   cf.color = m.has_relight ? x.relit : x.gcol; cf.ldcolor = 4;
   cf.gcolor = m.has_relight ? x.gcol : nullptr; cf.ldg = 4;
   cf.variance = params[m.p_variance]; cf.cos_anneal = in->cos_anneal_ratio; cf.background_rgb = in->background_rgb;
@@ -644,6 +651,7 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   cf.weight_max = out->weight_max; cf.weights = out->weights; cf.inside_sphere = out->inside_sphere; cf.depth = out->depth;
   cf.global_color = m.has_relight ? out->global_color : nullptr; cf.eik_partial = x.eik_partial;
   cf.sdf_s = out->sdf_samples; cf.color_s = out->color_samples; cf.gcolor_s = m.has_relight ? out->global_color_samples : nullptr;
+  if (m.has_relight && out->delta_relight_ray_sum) { cf.delta = delta_out; cf.delta_ray_sum = out->delta_relight_ray_sum; }
 
   if (in->prune_eps > 0.0f) {
     // inference-only early termination: weights first (they need only sdf and its gradient), then the colour / relight networks
@@ -670,7 +678,7 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
     be_prune_scatter(sc, s);
   } else {
     color_chain(m, P, x, s);
-    if (m.has_relight) relight_chain(m, P, x, out->delta_relight, s);
+    if (m.has_relight) relight_chain(m, P, x, delta_out, s);
   }
   be_composite_fwd(cf, s);
   ReduceEik re;
@@ -775,7 +783,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   be_zero_cols(b.ZTOP, x.ldztop, m.F + 1, x.ldztop, P, s);   // pad columns of [feat cotangent | sdf cotangent | 0]: every other column is written below
   CompositeBwd cb;
   cb.o = in->rays_o; cb.d = in->rays_d; cb.z = out->z_vals; cb.R = R; cb.M = m.M; cb.sample_dist = 2.0f / (float)m.S;
-  cb.sdf = x.sdf; cb.g = out->gradients; cb.color = m.has_relight ? x.relit : x.gcol; cb.ldcolor = 4;
+  cb.sdf = x.sdf; cb.g = out->gradients ? out->gradients : x.gbuf; cb.color = m.has_relight ? x.relit : x.gcol; cb.ldcolor = 4;
   cb.gcolor = m.has_relight ? x.gcol : nullptr; cb.ldg = 4;
   cb.variance = params[m.p_variance]; cb.cos_anneal = in->cos_anneal_ratio; cb.background_rgb = in->background_rgb;
   cb.eik_sums = x.eik_sums; cb.sdf_scale = scale; cb.inv_sigmoid = m.c.rel_inv_sigmoid; cb.has_relight = m.has_relight ? 1 : 0;
@@ -1193,6 +1201,19 @@ int cnr_loss_sums(const cnr_loss_config* cfg, const float* color_fine, const flo
   if (scratch_bytes < cnr_loss_scratch_bytes(n_rays)) return fail("loss scratch too small");
   be_loss_sums(a, static_cast<float*>(scratch), sums, (cnr_stream)stream);
   return check_backend("loss_sums");
+}
+
+int cnr_loss_sums_ray(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight_ray_sum,
+                      const float* rgb_gt, const float* mask, int64_t n_rays, int32_t n_samples, float* sums, void* scratch, size_t scratch_bytes,
+                      void* stream) {
+  LossArgs a;
+  if (loss_args(cfg, color_fine, weight_sum, delta_relight_ray_sum, rgb_gt, mask, n_rays, n_samples, a)) return -1;
+  if (!sums || !scratch) return fail("null argument");
+  if (mask && !weight_sum) return fail("weight_sum is required with a mask");
+  if (scratch_bytes < cnr_loss_scratch_bytes(n_rays)) return fail("loss scratch too small");
+  a.drel_per_ray = 1;
+  be_loss_sums(a, static_cast<float*>(scratch), sums, (cnr_stream)stream);
+  return check_backend("loss_sums_ray");
 }
 
 int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* rgb_gt, const float* mask,

@@ -50,11 +50,12 @@ def _stream(t):
 
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, lib, lcfg, lambdas, n_rays_global, group, color, wsum, gerr, eik_sums, drel, gt, mask):
+    def forward(ctx, lib, lcfg, lambdas, n_rays_global, group, color, wsum, gerr, eik_sums, drel, gt, mask, n_samples_=0):
         from ._lib import CnrLossConfig  # noqa: F401
         lam_f, lam_e, lam_m, lam_r = lambdas
         R = color.shape[0]
-        M = drel.shape[1] if drel is not None else 1
+        per_ray = drel is not None and drel.dim() == 1    # [R] sums over samples and rgb (renderer training_outputs="loss_only")
+        M = (n_samples_ if per_ray else drel.shape[1]) if drel is not None else 1
         dev = color.device
         color_c, gt_c = color.contiguous(), gt.contiguous()
         wsum_c = wsum.reshape(-1).contiguous()
@@ -63,8 +64,9 @@ class _FusedLoss(torch.autograd.Function):
         sums = torch.empty(4, dtype=torch.float32, device=dev)
         nb = lib.lib.cnr_loss_scratch_bytes(R)
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-        lib.check(lib.lib.cnr_loss_sums(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), _p(gt_c), _p(mask_c), R, M, _p(sums),
-                                        _p(scratch), nb, _stream(color_c)), "cnr_loss_sums")
+        fn = lib.lib.cnr_loss_sums_ray if per_ray else lib.lib.cnr_loss_sums
+        lib.check(fn(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), _p(gt_c), _p(mask_c), R, M, _p(sums),
+                     _p(scratch), nb, _stream(color_c)), "cnr_loss_sums")
         import torch.distributed as dist
         world = dist.get_world_size(group) if (dist.is_initialized() and n_rays_global is not None) else 1
         Rg = float(n_rays_global if n_rays_global is not None else R)
@@ -109,7 +111,7 @@ class _FusedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *_unused):
         if g_loss is None:   # nothing depends on ``loss`` (cannot happen through the components: they are non-differentiable)
-            return (None,) * 12
+            return (None,) * 13
         color_c, wsum_c, gt_c, mask_c, mean_rel, eik_factor = ctx.saved_tensors
         lam_f, lam_e, lam_m, lam_r = ctx.lambdas
         has_mask, has_rel, _ = ctx.has
@@ -132,9 +134,9 @@ class _FusedLoss(torch.autograd.Function):
             # d mean(delta_relight * mask)^2 / d delta_relight[r, j, c] = 2 mean / n * mask[r]: one value per ray.  Handed to the renderer's
             # backward as an expanded (stride-0) view -- its compositor backward takes the per-ray vector, no [R][M][3] buffer is written
             per_ray = coef[2] * mask_t if (lcfg.include_mask and mask_t is not None) else coef[2].expand(R)
-            d_drel = per_ray.reshape(R, 1, 1).expand(ctx.shapes[2])
+            d_drel = per_ray.reshape(R, 1, 1).expand(ctx.shapes[2]) if len(ctx.shapes[2]) == 3 else per_ray.reshape(ctx.shapes[2])
         d_gerr = g_loss * lam_e * eik_factor
-        return (None, None, None, None, None, d_color.reshape(ctx.shapes[0]), d_wsum.reshape(ctx.shapes[1]), d_gerr, None, d_drel, None, None)
+        return (None, None, None, None, None, d_color.reshape(ctx.shapes[0]), d_wsum.reshape(ctx.shapes[1]), d_gerr, None, d_drel, None, None, None)
 
 
 def compute_loss_fused(render_dict, rgb_gt, mask=None, lambda_fine=1.0, lambda_eikonal=0.1, lambda_mask=0.1, lambda_relight=1.0,
@@ -146,12 +148,17 @@ def compute_loss_fused(render_dict, rgb_gt, mask=None, lambda_fine=1.0, lambda_e
     lib = library if library is not None else load_library()
     lcfg = CnrLossConfig(lambda_fine, lambda_eikonal, lambda_mask, lambda_relight, 0 if rgb_loss_type == "mse" else 1, 1 if include_mask else 0)
     drel = render_dict.get("delta_relight") if lambda_relight != 0 else None
+    n_samples = 0
+    if drel is None and lambda_relight != 0 and render_dict.get("delta_relight_ray_sum") is not None:
+        # the renderer's training_outputs="loss_only" form: per-ray sums of delta_relight, no [R][M][3] tensor
+        drel = render_dict["delta_relight_ray_sum"]
+        n_samples = int(render_dict["weights"].shape[1])
     eik_sums = render_dict.get("eik_sums")
     if n_rays_global is not None and eik_sums is None:
         raise ValueError("ray-sharded fused loss needs the renderer's eik_sums output")
     loss, rgb_l, eik_l, mask_l, rel_l = _FusedLoss.apply(lib, lcfg, (lambda_fine, lambda_eikonal, lambda_mask, lambda_relight), n_rays_global,
                                                        group, render_dict["color_fine"], render_dict["weight_sum"],
-                                                       render_dict["gradient_error"], eik_sums, drel, rgb_gt, mask)
+                                                       render_dict["gradient_error"], eik_sums, drel, rgb_gt, mask, n_samples)
     loss_dict = {"rgb_fine_loss": rgb_l, "eikonal_loss": eik_l, "loss": loss}
     if lambda_mask != 0 and mask is not None:
         loss_dict["mask_loss"] = mask_l

@@ -41,12 +41,17 @@ class _RenderFunction(torch.autograd.Function):
         rays_o_c, rays_d_c = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
         near_c, far_c = near.detach().reshape(-1).contiguous().float(), far.detach().reshape(-1).contiguous().float()
         color = cfg.type == "Color_NeuS"
+        # want_samples: False / True (per-sample network outputs for the N_OUTSIDE mixing) / "loss_only" (the training outputs compute_loss
+        # needs: no [R][M][3] dict tensors, the relight term as per-ray sums)
+        loss_only = want_samples == "loss_only"
+        want_samples = want_samples is True
         out = dict(color_fine=torch.empty(R, 3, **f32), s_val=torch.empty(R, 1, **f32), cdf_fine=torch.empty(R, M, **f32),
                    weight_sum=torch.empty(R, 1, **f32), weight_max=torch.empty(R, 1, **f32),
-                   gradients=torch.empty(R, M, 3, **f32), weights=torch.empty(R, M, **f32),
+                   gradients=None if loss_only else torch.empty(R, M, 3, **f32), weights=torch.empty(R, M, **f32),
                    gradient_error=torch.empty((), **f32), inside_sphere=torch.empty(R, M, **f32), depth=torch.empty(R, **f32),
                    global_color=torch.empty(R, 3, **f32) if color else None,
-                   delta_relight=torch.empty(R, M, 3, **f32) if color else None,
+                   delta_relight=torch.empty(R, M, 3, **f32) if (color and not loss_only) else None,
+                   delta_relight_ray_sum=torch.empty(R, **f32) if (color and loss_only) else None,
                    z_vals=torch.empty(R, M, **f32), eik_sums=torch.empty(2, **f32),
                    sdf_samples=torch.empty(R, M, **f32) if want_samples else None,
                    color_samples=torch.empty(R, M, 3, **f32) if want_samples else None,
@@ -69,7 +74,7 @@ class _RenderFunction(torch.autograd.Function):
         # tensor -> grad_fn -> ctx -> tensor cycle and leak the multi-GB context buffer every step)
         ctx.cfg_aux = (float(cos_anneal_ratio), z_override is not None, t_rand is not None, background_rgb is not None, len(plist),
                        float(prune_eps))
-        saved = [rays_o_c, rays_d_c, near_c, far_c, out["z_vals"], out["gradients"], ctx_buf]
+        saved = [rays_o_c, rays_d_c, near_c, far_c, out["z_vals"], out["gradients"] if out["gradients"] is not None else torch.empty(0, **f32), ctx_buf]
         if t_rand is not None:
             saved.append(t_rand)
         if background_rgb is not None:
@@ -81,7 +86,8 @@ class _RenderFunction(torch.autograd.Function):
         ctx.nearfar_shapes = (near.shape, far.shape)
         ctx.mark_non_differentiable(out["inside_sphere"], out["z_vals"], out["eik_sums"])
         ctx.sample_names = [k for k in _SAMPLE_OUT if out[k] is not None]
-        res = [out[k] for k in _OUT_DIFF if out[k] is not None] + [out[k] for k in ctx.sample_names] + \
+        ctx.diff_names = [k for k in _OUT_DIFF + ["delta_relight_ray_sum"] if out.get(k) is not None]
+        res = [out[k] for k in ctx.diff_names] + [out[k] for k in ctx.sample_names] + \
               [out["inside_sphere"], out["z_vals"], out["eik_sums"]]
         return tuple(res)
 
@@ -102,9 +108,13 @@ class _RenderFunction(torch.autograd.Function):
         plist = sv[pos:pos + nparams]
         R = rays_o.shape[0]
         color = cfg.type == "Color_NeuS"
-        names = [k for k in _OUT_DIFF if color or k not in ("global_color", "delta_relight")] + ctx.sample_names
+        names = ctx.diff_names + ctx.sample_names
         gmap = {}
         for k, g in zip(names, gouts[:len(names)]):
+            if k == "delta_relight_ray_sum":   # d loss / d (sum_jc delta[r, j, c]) = the per-ray gradient of every delta[r, j, c]
+                if g is not None:
+                    gmap["delta_relight_per_ray"] = g.reshape(-1).contiguous().float()
+                continue
             if k == "delta_relight" and g is not None and g.dim() == 3 and g.stride(1) == 0 and g.stride(2) == 0:
                 # a gradient that is constant along each ray and over rgb (what the relight loss term produces, loss.compute_loss_fused
                 # hands it over as an expanded view): pass the per-ray vector, never materialise [R][M][3]
@@ -130,7 +140,7 @@ class _RenderFunction(torch.autograd.Function):
         cin = _lib.CnrInputs(rays_o=_ptr(rays_o), rays_d=_ptr(rays_d), near_=_ptr(near), far_=_ptr(far), t_rand=_ptr(t_rand),
                              z_vals_override=_ptr(z_vals) if had_override else None,
                              background_rgb=_ptr(background_rgb), n_rays=R, cos_anneal_ratio=car)
-        cout = _lib.CnrOutputs(z_vals=_ptr(z_vals), gradients=_ptr(gradients))   # the only forward outputs backward reads
+        cout = _lib.CnrOutputs(z_vals=_ptr(z_vals), gradients=_ptr(gradients) if gradients.numel() else None)   # the only forward outputs backward reads (gradients: NULL = kept in the context buffer)
         nbytes = lib.lib.cnr_bwd_scratch_bytes(C.byref(ccfg), R)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=rays_o.device)
         rc = lib.lib.cnr_render_backward(C.byref(ccfg), parr, C.byref(cin), C.byref(cout), _ptr(ctx_buf), ctx_buf.numel(),
@@ -340,11 +350,18 @@ class NeuSRenderer(nn.Module):
 
     # -- NeuS.forward (NeuS.py:294-408) -------------------------------------------------------------------------------
     def forward(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0, z_vals=None,
-                prune_eps=0.0, **kwargs):
+                prune_eps=0.0, training_outputs="dict", **kwargs):
         """input: rays_o [n_rays,3], rays_d [n_rays,3], near/far [n_rays].  Extra kwarg ``z_vals`` (not in the reference)
         overrides the sampler so that render_core can be checked at fixed sample positions; ``prune_eps`` > 0 (inference only, not in the
         reference) skips the colour / relight networks for samples whose compositing weight is below it (NeuS_Trainer.validate_image
-        consumes only color_fine and depth, :244-245)."""
+        consumes only color_fine and depth, :244-245).  ``training_outputs="loss_only"`` (not in the reference; default "dict" = the reference's
+        return dict): the two [n_rays, M, 3] entries `gradients` and `delta_relight` are not materialised; the dict carries
+        `delta_relight_ray_sum` [n_rays] instead, which is all compute_loss needs (loss.compute_loss_fused accepts either form)."""
+        if training_outputs not in ("dict", "loss_only"):
+            raise ValueError("training_outputs must be 'dict' or 'loss_only'")
+        loss_only = training_outputs == "loss_only"
+        if loss_only and (self.n_outside > 0 or prune_eps > 0):
+            raise ValueError("training_outputs='loss_only' is for the plain training step (no background samples, no pruning)")
         n_rays = len(rays_o)
         dev = rays_d.device
         if n_rays == 0:
@@ -363,14 +380,21 @@ class NeuSRenderer(nn.Module):
         params = self._ordered_params()
         if self.n_outside > 0:
             return self._forward_with_background(rays_o, rays_d, near, far, perturb, t_rand, bg, cos_anneal_ratio, params, z_vals)
-        res = _RenderFunction.apply(self, rays_o, rays_d, near, far, t_rand, z_vals, bg, cos_anneal_ratio, prune_eps, False, *params)
-        names = [k for k in _OUT_DIFF if not (k in ("global_color", "delta_relight") and self.rcfg.type != "Color_NeuS")]
+        res = _RenderFunction.apply(self, rays_o, rays_d, near, far, t_rand, z_vals, bg, cos_anneal_ratio, prune_eps,
+                                    "loss_only" if loss_only else False, *params)
+        color = self.rcfg.type == "Color_NeuS"
+        names = [k for k in _OUT_DIFF if not (k in ("global_color", "delta_relight") and not color) and not (loss_only and k in ("gradients", "delta_relight"))]
+        if loss_only and color:
+            names.append("delta_relight_ray_sum")
         out = dict(zip(names + ["inside_sphere", "z_vals", "eik_sums"], res))
         ret = {k: out[k] for k in ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",
-                                   "gradient_error", "inside_sphere", "depth"]}
-        if self.rcfg.type == "Color_NeuS":
+                                   "gradient_error", "inside_sphere", "depth"] if k in out}
+        if color:
             ret["global_color"] = out["global_color"]
-            ret["delta_relight"] = out["delta_relight"]
+            if loss_only:
+                ret["delta_relight_ray_sum"] = out["delta_relight_ray_sum"]
+            else:
+                ret["delta_relight"] = out["delta_relight"]
         ret["z_vals"] = out["z_vals"]       # extra keys (not in the reference dict)
         ret["eik_sums"] = out["eik_sums"]   # {sum relax*(|g|-1)^2, sum relax}: needed by ray-sharded training
         return ret

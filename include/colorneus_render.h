@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CNR_ABI_VERSION 2
+#define CNR_ABI_VERSION 3
 
 typedef struct cnr_config {
   int32_t type;              /* 0 = NeuS (NeuS.py:68), 1 = Color_NeuS (Color_NeuS.py:10) */
@@ -69,13 +69,13 @@ typedef struct cnr_render_outputs {
   float* cdf_fine;       /* [R][M]    */
   float* weight_sum;     /* [R]       */
   float* weight_max;     /* [R]       */
-  float* gradients;      /* [R][M][3] */
+  float* gradients;      /* [R][M][3] or NULL (the library then keeps them in its context buffer; see delta_relight_ray_sum) */
   float* weights;        /* [R][M]    */
   float* gradient_error; /* [1]       */
   float* inside_sphere;  /* [R][M]    */
   float* depth;          /* [R]       */
   float* global_color;   /* [R][3]    (Color_NeuS only, else NULL) */
-  float* delta_relight;  /* [R][M][3] (Color_NeuS only, else NULL) */
+  float* delta_relight;  /* [R][M][3] (Color_NeuS only, else NULL); may also be NULL for Color_NeuS when only delta_relight_ray_sum is wanted */
   float* z_vals;         /* [R][M]    */
   float* eik_sums;       /* [2] or NULL: {sum relax*(|g|-1)^2, sum relax} of this call's rays -- lets a ray-sharded run rebuild the global eikonal ratio */
   /* optional per-sample network outputs, for callers that do their own alpha / compositing (the N_OUTSIDE > 0 background mixing of
@@ -83,6 +83,10 @@ typedef struct cnr_render_outputs {
   float* sdf_samples;           /* [R][M]    or NULL: sdf at the section midpoints */
   float* color_samples;         /* [R][M][3] or NULL: the colour that is composited (relit colour for Color_NeuS) */
   float* global_color_samples;  /* [R][M][3] or NULL: colour-network output before relighting (Color_NeuS only) */
+  /* "loss only" training outputs: compute_loss (NeuS_Trainer.py:129-171) consumes `gradients` only through
+     gradient_error and `delta_relight` only through mean(delta_relight * mask) -- with this per-ray sum the two [R][M][3] dict tensors
+     need not be materialised for the caller (pass gradients = delta_relight = NULL): */
+  float* delta_relight_ray_sum; /* [R] or NULL: sum over the samples and rgb of delta_relight of each ray (Color_NeuS only) */
 } cnr_render_outputs;
 
 /* upstream gradients of the outputs; any member may be NULL (= zero) */
@@ -135,6 +139,10 @@ size_t cnr_loss_scratch_bytes(int64_t n_rays);
 int cnr_loss_sums(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight /* or NULL */,
                   const float* rgb_gt, const float* mask /* [R] or NULL */, int64_t n_rays, int32_t n_samples, float* sums /* device [4] */,
                   void* scratch, size_t scratch_bytes, void* stream);
+/* cnr_loss_sums with the relight term given as the per-ray sums cnr_render_outputs.delta_relight_ray_sum [R] instead of [R][M][3] */
+int cnr_loss_sums_ray(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight_ray_sum,
+                      const float* rgb_gt, const float* mask, int64_t n_rays, int32_t n_samples, float* sums, void* scratch, size_t scratch_bytes,
+                      void* stream);
 int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* rgb_gt, const float* mask,
                    int64_t n_rays, int32_t n_samples, const float* coef /* device [4] */, float* d_color_fine, float* d_weight_sum,
                    float* d_delta_relight /* or NULL */, void* stream);

@@ -107,3 +107,51 @@ def test_fused_loss_against_reference_goldens_emu():
         pytest.skip("emulation library not built")
     import color_neus_amd as cn
     _loss_goldens("cpu", cn.load_library(N.EMU_LIB))
+
+
+def _loss_only(library, device, name="tiny_sharp"):
+    """training_outputs="loss_only" (no [R][M][3] dict tensors, relight term from per-ray sums) gives the loss and the
+    gradients of the default dict mode (NeuS.py:387-408 return dict + compute_loss)."""
+    import _golden as G
+    import color_neus_amd as cn
+    fx = G.load(name)
+    ocfg, P = G.weights_of(name, fx)
+    lib = cn.load_library(library)
+    res = {}
+    for mode in ("dict", "loss_only"):
+        r = N.make_renderer(ocfg, P, library, device)
+        t = lambda k: torch.from_numpy(fx[k]).to(device)
+        o, d = t("rays_o").requires_grad_(True), t("rays_d").requires_grad_(True)
+        out = r(o, d, t("jit:near"), t("jit:far"), z_vals=t("jit:z_vals"), training_outputs=mode)
+        if mode == "loss_only":
+            assert "gradients" not in out and "delta_relight" not in out and out["delta_relight_ray_sum"].shape == (o.shape[0],)
+        else:
+            want = out["delta_relight"].detach().sum(dim=(1, 2))
+        loss, parts = cn.compute_loss_fused(out, t("rgb_gt"), t("mask"), library=lib)
+        loss.backward()
+        res[mode] = (out, float(loss.detach()), {k: p.grad.detach().cpu().clone() for k, p in r.named_parameters()}, o.grad.cpu().clone(), d.grad.cpu().clone(),
+                     {k: float(v.detach()) for k, v in parts.items()})
+    a, b = res["dict"], res["loss_only"]
+    got = b[0]["delta_relight_ray_sum"].detach()
+    assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert abs(a[1] - b[1]) <= 2e-6 * abs(a[1])
+    for k in a[5]:
+        assert abs(a[5][k] - b[5][k]) <= 2e-6 * max(abs(a[5][k]), 1e-6), k
+    for k in a[2]:   # the per-ray relight sum is folded in another order than the [R][M][3] sum: the seed of the relight branch moves by ~1e-6 relative
+        den = float(a[2][k].abs().max())
+        assert float((a[2][k] - b[2][k]).abs().max()) <= 1e-5 * den + 1e-12, k
+    for x, y in ((a[3], b[3]), (a[4], b[4])):
+        assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())
+    for k in ("color_fine", "weights", "weight_sum", "gradient_error", "depth", "global_color"):
+        assert torch.equal(a[0][k].detach().cpu(), b[0][k].detach().cpu()), k
+
+
+@pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
+def test_loss_only_training_outputs_emu():
+    _loss_only(N.EMU_LIB, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_sharp", "dtu_sharp"])
+def test_loss_only_training_outputs_hip(name):
+    _loss_only(None, "cuda:0", name)
