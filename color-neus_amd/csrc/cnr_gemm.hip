@@ -64,7 +64,7 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
   if (g.E.tail_src && g.E.n_out + g.E.tail_n > ncols) ncols = g.E.n_out + g.E.tail_n;   // tail-fill columns need a tile too
   // layers wider than 256 columns (257 = sdf + features, 259/262 = cotangents of concatenated inputs) run as a 256-wide launch
   // at two workgroups per CU plus a narrow launch for the remaining columns (cheaper than one 288-wide tile at one workgroup per CU)
-  for (int c0 = 0; c0 < ncols; c0 += 256) {
+  for (int c0 = g.first_col; c0 < ncols; c0 += 256) {
     LayerGemm part = g;
     part.col0 = c0;
     const int w = ncols - c0 < 256 ? ncols - c0 : 256;

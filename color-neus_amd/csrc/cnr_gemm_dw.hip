@@ -752,6 +752,7 @@ void be_dw_gemm(const DwGemm& g, cnr_stream s) {
     for (int k0 = 0; k0 < g.K;) {
       const int krem = g.K - k0;
       if (nrem > 32) {
+        if (krem > 64 && g.skip_main) { k0 += 256; continue; }   // main tile formed by the fused layer + weight-gradient launch
         if (krem > 64) {
           // the gradient-chain pair of the top SDF layer is a unit vector at the sdf row: it adds nothing to other row tiles
           DwGemm gm = g;

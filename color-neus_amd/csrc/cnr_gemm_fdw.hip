@@ -72,7 +72,8 @@ __device__ __forceinline__ float fd_sel4(const f4& v, int j) {   // v[j] for a p
 
 // DP: the P waves keep the epilogue side inputs of TWO tiles in flight (tile i + 2 is requested while tile i is finished);
 // DD: the D waves keep two input tiles in flight (tile i + 3 is requested when tile i + 1 has been converted).
-template <int EK, bool DP, bool DD>
+// NKB: k16 blocks of the layer product (16; 14 for the 217-wide SDF layer in front of the skip connection, whose pad columns are zero)
+template <int EK, bool DP, bool DD, int NKB = 16>
 __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, const DwFuse f, int tiles_per_range, int dbg) {
   LayerGemm g = g_in;
   g.A.kind = VK_DIRECT; g.E.kind = EK; g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30;
@@ -92,11 +93,11 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
   if (isP) {
     // ================================================================ P waves
     const int c0 = half * 128 + wave * 32;               // first output column of this wave
-    f16x8 w1[16], w2[16];
+    f16x8 w1[NKB], w2[NKB];
     {
       const unsigned short* wp = g.Wp + (long)(c0 + (lane & 31)) * g.ldw + (lane >> 5) * 8;
 #pragma unroll
-      for (int kb = 0; kb < 16; ++kb) {
+      for (int kb = 0; kb < NKB; ++kb) {
         w1[kb] = *reinterpret_cast<const f16x8*>(wp + kb * 16);
         w2[kb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 16);
       }
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
       const unsigned char* Ab = B + (lane & 31) * FD_ALD + (lane >> 5) * 16;
       if (!(dbg & 4))
 #pragma unroll
-      for (int kb = 0; kb < 16; ++kb) {
+      for (int kb = 0; kb < NKB; ++kb) {
         const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + kb * 32);
         const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + FD_APLANE + kb * 32);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w2[kb], acc, 0, 0, 0);
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            out[(long)s * f.ldk + e0 + m] = acc[it][jt][r] * u1 * u2;
+            if (s < f.Npad) out[(long)s * f.ldk + e0 + m] = acc[it][jt][r] * u1 * u2;
           }
         } else {
 #pragma unroll
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int e = 2 * r + kg;
-            out[(long)(e0 + e) * f.ldk + s0 + m] = X[m * 33 + e];
+            if (e0 + e < f.Npad) out[(long)(e0 + e) * f.ldk + s0 + m] = X[m * 33 + e];
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -408,21 +409,21 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
       float sum = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sum += C[r * 256 + dt];
-      f.colsum[(long)range * f.Npad + dt] = sum;
+      if (dt < f.Npad) f.colsum[(long)range * f.Npad + dt] = sum;
     }
   }
 }
 
-template <int EK, bool DP, bool DD>
+template <int EK, bool DP, bool DD, int NKB = 16>
 static void launch_fdw_v(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
   static DeviceOnce attr_once;
   if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD, NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = g.P / FD_TP;
   const int tpr = (int)((ntiles + f.nslots - 1) / f.nslots);
-  TimingScope ts_("layer_dw", 0, 200 + EK, g.P, g.N, g.K, 2, s, fdw_bytes(g, f));   // pairs = 2: the layer product + the weight-gradient product
+  TimingScope ts_("layer_dw", 0, 200 + EK, g.P, 256, g.K, 2, s, fdw_bytes(g, f));   // pairs = 2: the layer product + the weight-gradient product
   static const int dbg = getenv("CNR_FDW_DBG") ? atoi(getenv("CNR_FDW_DBG")) : 0;   // ablation switches (timing experiments only: results are wrong)
-  hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
+  hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD, NKB>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
 }
 template <int EK>
 static void launch_fdw(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
@@ -442,17 +443,24 @@ bool be_fdw_enabled() {
 
 void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s) {
   static const bool split_env = getenv("CNR_FDW_SPLIT") != nullptr;   // debugging aid: the same slots filled by the two separate kernels
-  if (split_env || !fdw_shape_ok(g) || f.se == nullptr || f.Npad != 256 || f.ldk != 256 || f.nslots < 8 || (f.nslots & 7) != 0 || f.nslots > kFdwSlots) {
+  const bool slots_ok = f.se != nullptr && f.nslots >= 8 && (f.nslots & 7) == 0 && f.nslots <= kFdwSlots;
+  if (split_env || !slots_ok || !fdw_shape_ok(g) || f.Npad < 224 || f.Npad > 256 || f.ldk < 256 || f.ldk > 320) {
     be_dw_gemm(d, s);
     be_layer_gemm(g, s);
     return;
   }
-  switch (g.E.kind) {
+  // the fused launch covers output columns [0, 256) and the 256 x 256 main tile of the weight gradient
+  if (g.K <= 224) launch_fdw_v<EK_VBACK, false, false, 14>(g, f, s);
+  else switch (g.E.kind) {
     case EK_RELU_MASK: launch_fdw<EK_RELU_MASK>(g, f, s); break;
     case EK_VBACK: launch_fdw<EK_VBACK>(g, f, s); break;
     default: launch_fdw<EK_SWEEP>(g, f, s); break;
   }
   CNR_LAUNCH_CHECK("layer_dw");
+  // a layer with a few more input columns (relight y-layer: 256 hidden + rgb): their cotangent columns by the narrow layer kernel, the
+  // weight-gradient strip beyond column 256 by the strip kernels into the same slots
+  if (g.N > 256) { LayerGemm tail = g; tail.first_col = 256; tail.rs_out = nullptr; be_layer_gemm(tail, s); }
+  if (d.K > 256) { DwGemm strips = d; strips.skip_main = true; strips.colsum = nullptr; be_dw_gemm(strips, s); }
 }
 
 }  // namespace cnr

@@ -61,7 +61,7 @@ void be_layer_gemm(const LayerGemm& g0, cnr_stream) {
     }
     int ncols = g.N;
     if (g.E.tail_src && g.E.n_out + g.E.tail_n > ncols) ncols = g.E.n_out + g.E.tail_n;
-    for (int n = 0; n < round_up(ncols, 32); ++n) {
+    for (int n = g.first_col; n < round_up(ncols, 32); ++n) {
       const float* w = g.W + (long)(n < round_up(g.N, 32) ? n : 0) * g.ldw;
 #ifdef CNR_EMU_DOUBLE_ACC
       double accd = 0.0;
@@ -88,7 +88,7 @@ void be_dw_gemm(const DwGemm& g, cnr_stream) {
       for (long pt = p0; pt < p1; ++pt) {
         for (int n = 0; n < g.N; n += 4) { f4 v = view_eval4(g.X[pair], pt, n); x[n] = v.x; x[n + 1] = v.y; x[n + 2] = v.z; x[n + 3] = v.w; }
         for (int k = 0; k < g.K; k += 4) { f4 v = view_eval4(g.Y[pair], pt, k); y[k] = v.x; y[k + 1] = v.y; y[k + 2] = v.z; y[k + 3] = v.w; }
-        for (int n = 0; n < g.N; ++n) {
+        for (int n = 0; n < g.N; ++n) {   // (skip_main is a speed matter of the HIP backend: the emulation forms every tile here)
           float xv = x[n];
           if (pair == 0 && g.colsum) g.colsum[(long)chunk * g.Npad + n] += xv;
           if (xv == 0.0f) continue;

@@ -818,7 +818,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       d.X[0] = g.A; d.sy[0] = x.rsR[i];
       d.Y[0] = relight_input_view(m, i, x);
       const DwRegion r = take_region(q, b);
-      if (fdw && fdw_shape_ok(g) && x.rsR[i] && q.npad == 256 && q.ldw == 256) {
+      if (fdw && fdw_shape_ok(g) && x.rsR[i] && q.npad == 256 && q.ldw <= 320) {
         fused_into_region(q, g, d, x.rsR[i], 0, r, 0, b, true, s);
         finish_region(q, r, b.fslots, b.fslots, b, params, dP);
       } else {
@@ -866,7 +866,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     d.X[0] = g.A; d.sy[0] = x.rsC[l];
     d.Y[0] = color_input_view(m, l, x);
     const DwRegion r = take_region(q, b);
-    if (fdw && l > 0 && fdw_shape_ok(g) && x.rsC[l] && q.npad == 256 && q.ldw == 256) {
+    if (fdw && fdw_shape_ok(g) && x.rsC[l] && q.npad == 256 && q.ldw <= 320) {
       fused_into_region(q, g, d, x.rsC[l], 0, r, 0, b, true, s);
       finish_region(q, r, b.fslots, b.fslots, b, params, dP);
     } else {
@@ -941,9 +941,10 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   for (int l = 0; l <= m.L; ++l) {
     const Lin& q = m.sdf[l];
     sreg[l] = take_region(q, b);
-    const bool sq = q.npad == 256 && q.ldw == 256;
-    if (fdw && sq && l >= 1 && l < m.L && x.rsY[l] && fdw_shape_ok(vback_gemm(l))) fuse_v[l] = 1;
-    if (fdw && sq && l < m.L && x.rsX1[l] && fdw_shape_ok(sweep_gemm(l))) fuse_g[l] = 1;
+    const bool sq = q.npad >= 224 && q.npad <= 256 && q.ldw == 256;
+    auto ok = [&](const LayerGemm& g) { return fdw_shape_ok(g); };
+    if (fdw && sq && l >= 1 && l < m.L && x.rsY[l] && ok(vback_gemm(l))) fuse_v[l] = 1;
+    if (fdw && sq && l < m.L && x.rsX1[l] && ok(sweep_gemm(l))) fuse_g[l] = 1;
   }
   // slot groups of a region: the value pair first (it carries the bias column sums), the gradient-chain pair behind it; a pair takes
   // fslots slots when it is fused and nchunk slots as a separate GEMM (one workgroup per slot: fewer would leave CUs idle); when neither is

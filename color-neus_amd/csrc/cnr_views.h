@@ -346,6 +346,7 @@ struct LayerGemm {
   long P = 0;
   Epi E;
   int col0 = 0;               // first output column handled by this launch (a wide layer may be split into column ranges)
+  int first_col = 0;          // be_layer_gemm starts at this column (a multiple of 256): the columns below belong to another launch
   const unsigned short* Wp = nullptr;   // optional: W as two f16 planes (hi, lo) of the row-scaled weights, same [rows][ldw] layout each
   long wp_stride = 0;                   // elements between planes
   const float* wscale = nullptr;        // per W row: 1 / (power-of-two scale applied before the f16 split)
@@ -371,6 +372,7 @@ struct DwGemm {
   const float* sx[2] = {nullptr, nullptr};
   const float* sy[2] = {nullptr, nullptr};
   bool split_f16 = false;
+  bool skip_main = false;     // leave out the 256 x 256 main tiles (formed elsewhere: the fused layer + weight-gradient launch); strips only
 };
 
 // Algorithmic HBM bytes of one launch: every operand matrix read once, every output written once (weights and bias are
@@ -423,10 +425,15 @@ struct DwFuse {
 // structural conditions of the fused kernel: a plain 256 -> 256 launch on full 32-point tiles whose epilogue takes the 16-byte path everywhere
 inline bool fdw_shape_ok(const LayerGemm& g) {
   const Epi& e = g.E;
-  if (g.A.kind != VK_DIRECT || (g.A.lda & 3) != 0 || g.K != 256 || g.N != 256 || g.col0 != 0 || g.P_dev != nullptr) return false;
+  if (g.A.kind != VK_DIRECT || (g.A.lda & 3) != 0 || g.col0 != 0 || g.first_col != 0 || g.P_dev != nullptr) return false;
   if (g.P <= 0 || (g.P % 32) != 0 || g.Wp == nullptr || g.wscale == nullptr) return false;
   if (e.kind != EK_RELU_MASK && e.kind != EK_VBACK && e.kind != EK_SWEEP) return false;
-  if (e.tail_src != nullptr || e.n_out != 256 || e.split < 256) return false;
+  // contraction: 16 k16 blocks, or 14 for the value-backward launch of the 217-wide layer (its pad columns are zero, its weight planes 224 wide)
+  if (!(g.K > 240 && g.K <= 256) && !(e.kind == EK_VBACK && g.K > 208 && g.K <= 224 && g.ldw >= 224)) return false;
+  // the first 256 output columns are plain (no tail fill, no split point below 256); further columns (N > 256, EK_RELU_MASK only: the
+  // relight y-layer) go to the narrow launch that follows
+  if (e.tail_src != nullptr || e.n_out < 256 || e.split < 256 || g.N < 256) return false;
+  if (g.N > 256 && e.kind != EK_RELU_MASK) return false;
   switch (e.kind) {
     case EK_RELU_MASK: return ((e.ld1 | e.ldaux) & 3) == 0 && e.aux != nullptr;
     case EK_VBACK: return ((e.ld1 | e.ldz) & 3) == 0;
