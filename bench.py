@@ -273,7 +273,7 @@ def main():
                 if t:
                     traffic, tfile = t, cand
                     break
-        roof.update({"kernel": desc, "traffic": traffic, "traffic_source": os.path.relpath(tfile, ROOT) if traffic else None, "avg_launch_ms": round(dom[0] / dom[2], 4),
+        roof.update({"kernel": desc, "kernel_name": dom_name, "traffic": traffic, "traffic_source": os.path.relpath(tfile, ROOT) if traffic else None, "avg_launch_ms": round(dom[0] / dom[2], 4),
                      "algorithmic_bytes_per_launch": round(dom[3] / dom[2]), "launches_per_step": dom[2] // nrep,
                      "share_of_kernel_time": round(dom[0] / tot_ms, 3)})
         result["roofline"] = roof

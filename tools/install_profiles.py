@@ -14,12 +14,12 @@ json.dump(d, open(dst + rnd + "_pmc_hbm_traffic_4096rays.json", "w"), indent=1)
 open(dst + rnd + "_kernel_stats_by_family.txt", "w").write("# build %s\n" % H + open(src + "kernel_stats_by_family.txt").read())
 shutil.copy(src + "kernel_stats.csv", dst + rnd + "_kernel_stats_4096rays.csv")
 hdr = ("# build %s; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES "
-       "SQ_INSTS_VALU over python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-small-batch --no-torch-gpu-baseline (percentages of SQ_WAVE_CYCLES)\n" % H)
+       "SQ_INSTS_VALU over python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-small-batch --no-torch-gpu-baseline --no-inference --no-c5 (percentages of SQ_WAVE_CYCLES)\n" % H)
 open(dst + rnd + "_pmc_sq_summary.txt", "w").write(hdr + open(src + "pmc_sq_summary.txt").read())
 b = json.loads(open(os.path.join(root, "gpurun_out", tag + "_bench.json")).read().strip().split("\n")[-1])
 b["build"] = H
 if b.get("roofline"):
-    b["roofline"]["traffic"] = d["kernels"].get("layer_gemm_ws", {}).get("hbm_bytes_per_launch")   # the value bench.py reads from now on
+    b["roofline"]["traffic"] = d["kernels"].get(b["roofline"].get("kernel_name", "layer_gemm_ws"), {}).get("hbm_bytes_per_launch")   # the value bench.py reads from now on
 json.dump(b, open(dst + rnd + "_bench_4096rays.json", "w"), indent=1)
 t = open(os.path.join(root, "gpurun_out", "param_grad_error_table.txt")).read()
 open(dst + rnd + "_param_grad_error_table.txt", "w").write("# build %s; written by tests/test_hip_parity.py::test_param_grad_error_table on an MI355X (HIP path vs the reference's "
