@@ -82,7 +82,8 @@ EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_c
            "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_sdf_grid_slab_scratch_bytes", "cnr_sdf_grid_slab", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
            "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_sums_ray", "cnr_loss_grads",
-           "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward", "cnr_sample_z", "cnr_mc_scratch_bytes", "cnr_mc_count", "cnr_mc_emit"]
+           "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward", "cnr_sample_z", "cnr_mc_scratch_bytes", "cnr_mc_count", "cnr_mc_emit",
+           "cnr_linear_scratch_bytes", "cnr_linear_forward", "cnr_linear_backward"]
 
 
 class RenderLibrary:
@@ -115,6 +116,10 @@ class RenderLibrary:
         L.cnr_sdf_grid_slab_scratch_bytes.argtypes = [C.POINTER(CnrConfig), C.c_int32, C.c_int32, C.c_int32]
         L.cnr_sdf_grid_slab.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_int32,
                                         _FP, _FP, C.c_size_t, _FP]
+        L.cnr_linear_scratch_bytes.restype = C.c_size_t
+        L.cnr_linear_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+        L.cnr_linear_forward.argtypes = [_FP, C.c_int64, C.c_int32, _FP, _FP, C.c_int32, C.c_int32, _FP, _FP, C.c_size_t, _FP]
+        L.cnr_linear_backward.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int32, _FP, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, C.c_size_t, _FP]
         L.cnr_vertex_color.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), _FP, C.c_int64, _FP, _FP, C.c_size_t, _FP]
         L.cnr_loss_scratch_bytes.restype = C.c_size_t
         L.cnr_loss_scratch_bytes.argtypes = [C.c_int64]

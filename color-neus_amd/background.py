@@ -1,13 +1,58 @@
 """N_OUTSIDE > 0: the NeRF++ background of NeuS (lib/models/renderers/NeuS.py:95-134, 313-369, fields.py:192-274).
 
-No shipped configuration enables it (N_OUTSIDE is absent from every config/*.yml, NeuS.py:82), so this is the FALLBACK form
-SURVEY.md 8(a19) asks for, not an accelerated path: the background network and the inside / outside alpha mixing are plain torch ops
-with autograd.  The foreground -- sampler, SDF / colour / relight stacks and their backward -- still runs in the HIP library: the
-render call hands out its per-sample outputs (sdf, normals, colours: cnr_render_outputs.*_samples) and takes their gradients back
-(cnr_render_out_grads.*_samples), so only the [R, M + N_OUTSIDE] compositing arithmetic is done here."""
+No shipped configuration enables it (N_OUTSIDE is absent from every config/*.yml, NeuS.py:82).  The foreground -- sampler, SDF / colour /
+relight stacks and their backward -- runs in the HIP library: the render call hands out its per-sample outputs (sdf, normals, colours:
+cnr_render_outputs.*_samples) and takes their gradients back (cnr_render_out_grads.*_samples).  The background NETWORK (the 8 x 256 ReLU
+stack, its skip layer, the view branch and the two heads: 12 nn.Linear layers) runs on the library's layer / weight-gradient kernels through
+cnr_linear_forward / cnr_linear_backward (HipLinear below) whenever a render library is attached (NeRF.library); what stays in torch is the
+glue around it: the positional encodings, the concatenations, and the [R, M + N_OUTSIDE] inside / outside alpha mixing."""
+import ctypes as C
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+class HipLinear(torch.autograd.Function):
+    """y = act(x W^T + b) through cnr_linear_forward / cnr_linear_backward (the render library's layer GEMM + weight-gradient GEMM)."""
+
+    @staticmethod
+    def forward(ctx, lib, x, weight, bias, relu):
+        x2 = x.detach().reshape(-1, x.shape[-1]).contiguous().float()
+        w, b = weight.detach().contiguous().float(), (bias.detach().contiguous().float() if bias is not None else None)
+        n, k, n_out = x2.shape[0], x2.shape[1], w.shape[0]
+        y = torch.empty(n, n_out, dtype=torch.float32, device=x2.device)
+        if n > 0:
+            nb = lib.lib.cnr_linear_scratch_bytes(n, k, n_out, 0)
+            scratch = torch.empty(nb, dtype=torch.uint8, device=x2.device)
+            stream = C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream) if x2.is_cuda else C.c_void_p(0)
+            p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+            lib.check(lib.lib.cnr_linear_forward(p(x2), n, k, p(w), p(b), n_out, int(relu), p(y), p(scratch), nb, stream), "cnr_linear_forward")
+        ctx.lib, ctx.relu, ctx.has_bias, ctx.xshape = lib, bool(relu), bias is not None, x.shape
+        ctx.save_for_backward(x2, w, y)
+        return y.reshape(*x.shape[:-1], n_out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        lib = ctx.lib
+        n, k, n_out = x2.shape[0], x2.shape[1], w.shape[0]
+        dy2 = dy.reshape(-1, n_out).contiguous().float()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        dW = torch.empty_like(w)
+        db = torch.empty(n_out, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+        if n > 0:
+            nb = lib.lib.cnr_linear_scratch_bytes(n, k, n_out, 1)
+            scratch = torch.empty(nb, dtype=torch.uint8, device=x2.device)
+            stream = C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream) if x2.is_cuda else C.c_void_p(0)
+            p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+            lib.check(lib.lib.cnr_linear_backward(p(x2), p(y), p(dy2), n, k, p(w), n_out, int(ctx.relu), p(dx), p(dW), p(db), p(scratch), nb, stream),
+                      "cnr_linear_backward")
+        else:
+            dW.zero_()
+            if db is not None:
+                db.zero_()
+        return None, (dx.reshape(ctx.xshape) if dx is not None else None), dW, db, None
 
 
 def _embed(x, multires):
@@ -32,19 +77,26 @@ class NeRF(nn.Module):
         self.feature_linear = nn.Linear(W, W)
         self.alpha_linear = nn.Linear(W, 1)
         self.rgb_linear = nn.Linear(W // 2, 3)
+        self.library = None   # a _lib.RenderLibrary: the layers then run on its kernels (set by the renderer that owns this network)
+
+    def _lin(self, lin, x, relu):
+        if self.library is not None:
+            return HipLinear.apply(self.library, x, lin.weight, lin.bias, relu)
+        y = lin(x)
+        return F.relu(y) if relu else y
 
     def forward(self, pts, views):
         e = _embed(pts, self.multires)
         h = e
         for i, lin in enumerate(self.pts_linears):
-            h = F.relu(lin(h))
+            h = self._lin(lin, h, True)
             if i in self.skips:
                 h = torch.cat([e, h], -1)
-        density = self.alpha_linear(h)
-        h = torch.cat([self.feature_linear(h), _embed(views, self.multires_view)], -1)
+        density = self._lin(self.alpha_linear, h, False)
+        h = torch.cat([self._lin(self.feature_linear, h, False), _embed(views, self.multires_view)], -1)
         for lin in self.views_linears:
-            h = F.relu(lin(h))
-        return density, self.rgb_linear(h)
+            h = self._lin(lin, h, True)
+        return density, self._lin(self.rgb_linear, h, False)
 
 
 def outside_samples(far, n_outside, n_samples, perturb):

@@ -307,6 +307,8 @@ CNR_HD int mc_popcount3(unsigned x) { return (int)((x & 1) + ((x >> 1) & 1) + ((
 
 // p[row][c] = 0 for c in [c0, c1), row < rows: zero the pad columns a GEMM reads without touching the rest of a wide buffer
 void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream s);
+// dst[row][c] = src[row][c] for c < ncols (two row-major matrices with different row strides): compact <-> padded operand buffers
+void be_copy_cols(float* dst, int ld_dst, const float* src, int ld_src, int ncols, long rows, cnr_stream s);
 void be_grid_points(float* pts /*unused*/, cnr_stream s);
 struct KernelTiming { char name[32]; int kind; int nt; long P; int N, K, pairs; float ms; double bytes; };
 void be_timing_enable(int on);

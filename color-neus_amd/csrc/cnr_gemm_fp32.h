@@ -74,11 +74,11 @@ __global__ __launch_bounds__(256, 2) void layer_gemm_kernel(const LayerGemm g) {
   if (arow1 >= Pn) arow1 = Pn - 1;
   View A = g.A;
   if (VK >= 0) A.kind = VK;
-  const bool has_b = A.kind == VK_SIGMUL || A.kind == VK_SIGMUL_ROW;
+  const bool has_b = A.kind == VK_SIGMUL || A.kind == VK_SIGMUL_ROW || A.kind == VK_RELUGATE;
   const float* a0p = A.a + arow0 * A.lda + ac4;
   const float* a1p = A.a + arow1 * A.lda + ac4;
-  const float* b0p = A.kind == VK_SIGMUL ? A.b + arow0 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a0p);
-  const float* b1p = A.kind == VK_SIGMUL ? A.b + arow1 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a1p);
+  const float* b0p = (A.kind == VK_SIGMUL || A.kind == VK_RELUGATE) ? A.b + arow0 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a0p);
+  const float* b1p = (A.kind == VK_SIGMUL || A.kind == VK_RELUGATE) ? A.b + arow1 * A.ldb + ac4 : (A.kind == VK_SIGMUL_ROW ? A.b + ac4 : a1p);
   const float* wp = g.W + (long)(g.col0 + (tid >> 2)) * g.ldw + ac4;
 
 #define LG_LOAD_SLAB(s_)                                                                     \

@@ -93,6 +93,22 @@ void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream s) {
   CNR_LAUNCH_CHECK("zero_cols");
 }
 
+__global__ __launch_bounds__(256) void copy_cols_kernel(float* dst, int ld_dst, const float* src, int ld_src, int ncols, long rows) {
+  const long n = rows * ncols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / ncols;
+    const int c = (int)(i - r * ncols);
+    dst[r * ld_dst + c] = src[r * ld_src + c];
+  }
+}
+void be_copy_cols(float* dst, int ld_dst, const float* src, int ld_src, int ncols, long rows, cnr_stream s) {
+  if (ncols <= 0 || rows <= 0) return;
+  long blocks = (rows * ncols + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, ld_dst, src, ld_src, ncols, rows);
+  CNR_LAUNCH_CHECK("copy_cols");
+}
+
 // ================================================================================================
 // point-wise kernels
 // ================================================================================================

@@ -47,6 +47,9 @@ void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream) {
   for (long r = 0; r < rows; ++r) for (int c = c0; c < c1; ++c) p[r * ld + c] = 0.0f;
 }
 void be_grid_points(float*, cnr_stream) {}
+void be_copy_cols(float* dst, int ld_dst, const float* src, int ld_src, int ncols, long rows, cnr_stream) {
+  for (long r = 0; r < rows; ++r) memcpy(dst + r * ld_dst, src + r * ld_src, (size_t)ncols * sizeof(float));
+}
 
 void be_layer_gemm(const LayerGemm& g0, cnr_stream) {
   LayerGemm g = g0;

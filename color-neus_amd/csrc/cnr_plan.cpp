@@ -240,17 +240,19 @@ struct Ctx {   // forward-saved state
 
 static int hr_ld(const Model& m, const Ctx& x, int i) { return i == m.c.rel_y_in_layer - 1 ? x.ldy : m.Hr; }
 
+static void place_lin(Lin& q, Arena& a) {
+  q.W = a.f((size_t)q.npad * q.ldw);
+  q.Wt = a.f((size_t)q.kpad * q.ldwt);
+  q.bias = a.f(q.npad);
+  q.Wp = reinterpret_cast<unsigned short*>(a.f((size_t)q.npad * q.ldw));
+  q.Wtp = reinterpret_cast<unsigned short*>(a.f((size_t)q.kpad * q.ldwt));
+  q.Wps = a.f(q.npad > 256 ? q.npad : 256);   // (the fused kernels read 256 column scales; entries >= npad are never used)
+  q.Wtps = a.f(q.kpad);
+  q.Wf = (q.ldw <= 256) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldw / 16) * 2 * 64 * 8 / 2)) : nullptr;
+}
+
 static void layout_weights(Model& m, Arena& a) {
-  auto place = [&](Lin& q) {
-    q.W = a.f((size_t)q.npad * q.ldw);
-    q.Wt = a.f((size_t)q.kpad * q.ldwt);
-    q.bias = a.f(q.npad);
-    q.Wp = reinterpret_cast<unsigned short*>(a.f((size_t)q.npad * q.ldw));
-    q.Wtp = reinterpret_cast<unsigned short*>(a.f((size_t)q.kpad * q.ldwt));
-    q.Wps = a.f(q.npad > 256 ? q.npad : 256);   // (the fused kernels read 256 column scales; entries >= npad are never used)
-    q.Wtps = a.f(q.kpad);
-    q.Wf = (q.ldw <= 256) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldw / 16) * 2 * 64 * 8 / 2)) : nullptr;
-  };
+  auto place = [&](Lin& q) { place_lin(q, a); };
   for (auto& q : m.sdf) place(q);
   for (auto& q : m.col) place(q);
   for (auto& q : m.rel) place(q);
@@ -1100,6 +1102,51 @@ static void layout_vc(Model& m, long n, Arena& a, Ctx& x) {
   for (int l = 0; l + 1 < m.NC; ++l) x.HC[l] = a.f((size_t)n * m.Hc);
   a.f(1024);
 }
+
+// ------------------------------------------------------------------------------------------------
+// one plain fully-connected layer y = act(x W^T + b) and its backward on the layer / weight-gradient kernels of the render path:
+// the NeRF++ background stack (fields.py:192-274) is a chain of these (color-neus_amd/background.py)
+// ------------------------------------------------------------------------------------------------
+struct LinearOp { Lin q; int ldx = 0, ldy = 0; float *xp = nullptr, *yp = nullptr, *gp = nullptr, *dxp = nullptr; float* part = nullptr; int nchunk = 1; };
+
+static int linear_setup(long n, int k, int n_out, bool backward, Arena& a, LinearOp& op) {
+  if (n <= 0 || k < 1 || n_out < 1 || k > 4096 || n_out > 4096) return fail("linear: need n > 0, 1 <= k, n_out <= 4096");
+  Lin& q = op.q;
+  q.n = n_out; q.k_ref = k; identity_seg(q); q.finish_dims(); q.wn = false;
+  place_lin(q, a);
+  op.ldx = round_up(k, 16); op.ldy = round_up(n_out, 16);
+  op.xp = a.f((size_t)n * op.ldx);
+  op.yp = a.f((size_t)n * op.ldy);
+  if (backward) {
+    op.gp = a.f((size_t)n * op.ldy);
+    op.dxp = a.f((size_t)n * op.ldx);
+    long nch = n / 128;
+    if (nch < 1) nch = 1;
+    if (nch > 256) nch = 256;
+    op.nchunk = (int)nch;
+    op.part = a.f(round_up_sz((size_t)op.nchunk * q.npad * q.ldw, 64) + round_up_sz((size_t)op.nchunk * q.npad, 64));
+  }
+  a.f(1024);
+  return 0;
+}
+
+static void linear_prep(LinearOp& op, const float* W, const float* b, cnr_stream s) {
+  Lin& q = op.q;
+  PrepWeight p;
+  p.g = nullptr; p.v = W; p.b = b; p.n = q.n; p.k_ref = q.k_ref; p.nseg = q.nseg;
+  for (int i = 0; i < q.nseg; ++i) p.seg[i] = q.seg[i];
+  p.W = q.W; p.ldw = q.ldw; p.npad = q.npad; p.Wt = q.Wt; p.ldwt = q.ldwt; p.kpad = q.kpad; p.bias = q.bias; p.row_rot = 0;
+  be_prep_weights(&p, 1, s);
+  SplitJob sj[2] = {SplitJob{q.W, q.npad, q.ldw, q.Wp, q.Wps}, SplitJob{q.Wt, q.kpad, q.ldwt, q.Wtp, q.Wtps}};
+  be_split_planes_many(sj, 2, s);
+}
+
+// compact [n][c] -> padded [n][ld] with zero pad columns
+static void pad_in(float* dst, int ld, const float* src, int c, long n, cnr_stream s) {
+  be_copy_cols(dst, ld, src, c, c, n, s);
+  be_zero_cols(dst, ld, c, ld, n, s);
+}
+
 constexpr long kVcChunk = 1 << 16;
 
 __attribute__((unused)) static void copy_rgb_stub() {}
@@ -1399,6 +1446,74 @@ int cnr_mc_emit(const float* u, int32_t resolution, float threshold, const float
   if (!bound_min || !bound_max || !vertices || !triangles) return fail("null argument");
   be_mc_emit(v, bound_min, bound_max, vertices, triangles, (cnr_stream)stream);
   return check_backend("mc_emit");
+}
+
+
+size_t cnr_linear_scratch_bytes(int64_t n, int32_t k, int32_t n_out, int32_t backward) {
+  Arena a(nullptr);
+  LinearOp op;
+  if (linear_setup(n, k, n_out, backward != 0, a, op)) return 0;
+  return a.off;
+}
+
+int cnr_linear_forward(const float* x, int64_t n, int32_t k, const float* W, const float* b, int32_t n_out, int32_t relu, float* y, void* scratch,
+                       size_t scratch_bytes, void* stream) {
+  if (!x || !W || !y || !scratch) return fail("null argument");
+  cnr_stream s = (cnr_stream)stream;
+  Arena a(scratch);
+  LinearOp op;
+  if (linear_setup(n, k, n_out, false, a, op)) return -1;
+  if (a.off > scratch_bytes) return fail("linear scratch too small: need %zu bytes, got %zu", a.off, scratch_bytes);
+  Lin& q = op.q;
+  linear_prep(op, W, b, s);
+  pad_in(op.xp, op.ldx, x, k, n, s);
+  LayerGemm g;
+  g.A.kind = VK_DIRECT; g.A.a = op.xp; g.A.lda = op.ldx;
+  g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = n;
+  g.E.kind = relu ? EK_RELU : EK_STORE; g.E.bias = b ? q.bias : nullptr; g.E.n_out = q.n; g.E.o1 = op.yp; g.E.ld1 = op.ldy;
+  be_layer_gemm(g, s);
+  be_copy_cols(y, n_out, op.yp, op.ldy, n_out, n, s);
+  return check_backend("linear_forward");
+}
+
+int cnr_linear_backward(const float* x, const float* y, const float* dy, int64_t n, int32_t k, const float* W, int32_t n_out, int32_t relu,
+                        float* dx, float* dW, float* db, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!x || !dy || !W || !dW || !scratch || (relu && !y)) return fail("null argument");
+  cnr_stream s = (cnr_stream)stream;
+  Arena a(scratch);
+  LinearOp op;
+  if (linear_setup(n, k, n_out, true, a, op)) return -1;
+  if (a.off > scratch_bytes) return fail("linear scratch too small: need %zu bytes, got %zu", a.off, scratch_bytes);
+  Lin& q = op.q;
+  linear_prep(op, W, nullptr, s);
+  pad_in(op.xp, op.ldx, x, k, n, s);
+  pad_in(op.gp, op.ldy, dy, n_out, n, s);
+  View dz;    // cotangent of the pre-activation: dy gated by the ReLU output
+  dz.kind = VK_DIRECT; dz.a = op.gp; dz.lda = op.ldy;
+  if (relu) { pad_in(op.yp, op.ldy, y, n_out, n, s); dz.kind = VK_RELUGATE; dz.b = op.yp; dz.ldb = op.ldy; }
+  // weight and bias gradients: dW[n_out][k] = sum_pt dz (x) x, db = column sums of dz
+  DwGemm d;
+  d.npairs = 1; d.P = n; d.X[0] = dz; d.Y[0].kind = VK_DIRECT; d.Y[0].a = op.xp; d.Y[0].lda = op.ldx;
+  d.N = q.n; d.K = q.k_int; d.nchunk = op.nchunk; d.chunk_pts = round_up((int)((n + op.nchunk - 1) / op.nchunk), 16);
+  d.partial = op.part; d.Npad = q.npad; d.ldk = q.ldw;
+  float* csum = op.part + round_up_sz((size_t)op.nchunk * q.npad * q.ldw, 64);
+  d.colsum = csum; d.split_f16 = false;
+  be_dw_gemm(d, s);
+  FinishWeight f;
+  f.partial = op.part; f.nchunk = op.nchunk; f.npad = q.npad; f.ldk = q.ldw; f.colsum = db ? csum : nullptr; f.ncolsum = op.nchunk;
+  f.g = nullptr; f.v = W; f.n = q.n; f.k_ref = q.k_ref; f.nseg = q.nseg;
+  for (int i = 0; i < q.nseg; ++i) f.seg[i] = q.seg[i];
+  f.dg = nullptr; f.dv = dW; f.db = db; f.row_rot = 0;
+  be_finish_weights(&f, 1, s);
+  if (dx) {
+    LayerGemm g;
+    g.A = dz;
+    g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = n;
+    g.E.kind = EK_STORE; g.E.n_out = q.k_int; g.E.o1 = op.dxp; g.E.ld1 = op.ldx;
+    be_layer_gemm(g, s);
+    be_copy_cols(dx, k, op.dxp, op.ldx, k, n, s);
+  }
+  return check_backend("linear_backward");
 }
 
 size_t cnr_vertex_color_scratch_bytes(const cnr_config* cfg, int64_t n_points) {

@@ -19,6 +19,7 @@ enum ViewKind : int {
   VK_SIGMUL,       // softplus100'(a[row][col]) * b[row][col]                u_l = sp'(z_l) * v_l
   VK_SIGMUL_ROW,   // softplus100'(a[row][col]) * b[col]                     v_l is one broadcast row
   VK_CONST_COL0,   // col == hot ? 1 : 0 (hot = math_split, default 0)       u_top = unit vector of the sdf row (a must still be a valid pointer)
+  VK_RELUGATE,     // b[row][col] > 0 ? a[row][col] : 0                      cotangent of a ReLU output gated by that output (cnr_linear_backward)
 };
 
 struct View {
@@ -35,7 +36,7 @@ struct Raw4 { f4 a; f4 b; };
 CNR_HD Raw4 view_fetch4(const View& v, long row, int col) {
   Raw4 r;
   r.a = *reinterpret_cast<const f4*>(v.a + row * v.lda + col);
-  if (v.kind == VK_SIGMUL) r.b = *reinterpret_cast<const f4*>(v.b + row * v.ldb + col);
+  if (v.kind == VK_SIGMUL || v.kind == VK_RELUGATE) r.b = *reinterpret_cast<const f4*>(v.b + row * v.ldb + col);
   else if (v.kind == VK_SIGMUL_ROW) r.b = *reinterpret_cast<const f4*>(v.b + col);
   else { r.b.x = 0.f; r.b.y = 0.f; r.b.z = 0.f; r.b.w = 0.f; }   // (not a copy of r.a: that would make the caller wait for the load right here)
   return r;
@@ -57,6 +58,7 @@ CNR_HD float view_math1(const View& v, float a, float b, int col) {
     case VK_SOFTPLUS: return select_f32(col < v.math_split, softplus100(a), a);
     case VK_SIGMUL:
     case VK_SIGMUL_ROW: return softplus100_d1(a) * b;
+    case VK_RELUGATE: return b > 0.0f ? a : 0.0f;
     default: return col == (v.math_split == (1 << 30) ? 0 : v.math_split) ? 1.0f : 0.0f;
   }
 }
@@ -379,7 +381,7 @@ struct DwGemm {
 // noise at these sizes and are left out).  Used only for the roofline figures of the timing records.
 inline double view_bytes(const View& v, long P, int K) {
   switch (v.kind) {
-    case VK_SIGMUL: return 8.0 * (double)P * K;
+    case VK_SIGMUL: case VK_RELUGATE: return 8.0 * (double)P * K;
     case VK_CONST_COL0: return 0.0;
     default: return 4.0 * (double)P * K;
   }

@@ -297,6 +297,7 @@ class NeuSRenderer(nn.Module):
             self.nerf = NeRF()
         self._library_arg = library
         self._lib_obj = None
+        self.torch_background = False   # True: evaluate the NeRF++ background network with torch ops instead of the library's layer kernels
         self._ccfg = _lib.c_config(rcfg)
         self._order = None
 
@@ -432,6 +433,8 @@ class NeuSRenderer(nn.Module):
             z_vals = z_override.detach().reshape(R, rc.n_total).float()
         z_feed, _ = torch.sort(torch.cat([z_vals, z_out], dim=-1), dim=-1)
         sample_dist = 2.0 / self.n_samples
+        if self.nerf.library is None and not self.torch_background:
+            self.nerf.library = self._lib     # the background network's layers run on the render library's kernels (background.HipLinear)
         bg_alpha, bg_color = B.render_outside(self.nerf, rays_o, rays_d, z_feed, sample_dist)
         res = _RenderFunction.apply(self, rays_o, rays_d, near, far, None, z_vals, None, 0.0, 0.0, True, *params)
         color = rc.type == "Color_NeuS"

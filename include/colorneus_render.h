@@ -247,6 +247,17 @@ size_t cnr_vertex_color_scratch_bytes(const cnr_config* cfg, int64_t n_points);
 int cnr_vertex_color(const cnr_config* cfg, const float* const* params, const float* verts, int64_t n_points,
                      float* rgb, void* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- one plain fully-connected layer on the layer / weight-gradient kernels of the render path: y = act(x W^T + b), act = ReLU or none.
+ * The NeRF++ background network of NeuS (NeRF, fields.py:192-274; N_OUTSIDE > 0, NeuS.py:95-134) is a chain of nn.Linear (+ ReLU) layers;
+ * color-neus_amd/background.py evaluates each of them through these two entry points.  x [n][k], y / dy [n][n_out], W [n_out][k] and b [n_out]
+ * are compact row-major device fp32 (nn.Linear's layout); backward: dx (or NULL), dW [n_out][k], db (or NULL) are overwritten. */
+size_t cnr_linear_scratch_bytes(int64_t n, int32_t k, int32_t n_out, int32_t backward);
+int cnr_linear_forward(const float* x, int64_t n, int32_t k, const float* W, const float* b /* or NULL */, int32_t n_out, int32_t relu, float* y,
+                       void* scratch, size_t scratch_bytes, void* stream);
+int cnr_linear_backward(const float* x, const float* y /* the forward output (ReLU gate); may be NULL without ReLU */, const float* dy, int64_t n,
+                        int32_t k, const float* W, int32_t n_out, int32_t relu, float* dx, float* dW, float* db, void* scratch,
+                        size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,7 +78,9 @@ def test_g2_every_gradient_entry_against_live_float64_oracle(name, tag):
 @pytest.mark.parametrize("name", ["tiny_outside", "tiny_neus_outside"])
 @pytest.mark.parametrize("tag", ["det", "jit"])
 def test_nerfpp_background_fallback(name, tag):
-    """N_OUTSIDE = 8 (a19, fallback form): foreground on the HIP library, NeRF++ background + mixing in torch (background.py)."""
+    """N_OUTSIDE = 8 (a19 / f4): foreground on the HIP library; the NeRF++ background network's 12 linear layers on the library's layer and
+    weight-gradient kernels (cnr_linear_forward / cnr_linear_backward, background.HipLinear); encodings, concatenations and the inside /
+    outside alpha mixing in torch (background.py)."""
     fx, r, out, loss, grads, o, d = N.run_native(name, tag, None, DEV, fixed_z=True)
     for k in G.OUTPUT_KEYS:
         if f"{tag}:out_{k}" in fx:
