@@ -185,6 +185,18 @@ void be_dw_gemm(const DwGemm& g, cnr_stream s);
 // Layer launch g + the single-pair weight gradient d (X[0] = the launch's input view, Y[0] = the operand its epilogue derives from its side
 // inputs, see DwFuse in cnr_views.h) with d.partial / d.colsum laid out in kFdwSlots slots.  Callers test be_fdw_enabled() && fdw_shape_ok(g)
 // first; the backend may still run the two parts as separate launches (same results, same slots).
+// Backward of a <= 4-wide head (rgb / relight offset: nn.Linear(256, 3) after a ReLU) in ONE streaming launch instead of a K = 3 layer launch +
+// a weight-gradient strip launch that re-reads the same 1 KB/point: dout[pt][k] = aux[pt][k] > 0 ? sum_j W[j][k] dtop[pt][j] : 0 (the
+// EK_RELU_MASK epilogue), dW[j][k] = sum_pt dtop[pt][j] aux[pt][k], db[j] = sum_pt dtop[pt][j]; fp32 FMAs, fixed-order partial sums per slot.
+struct HeadBwd {
+  const float* dtop; int ldt;     // [P][ldt] cotangent of the head's output (n live columns)
+  const float* aux; int ldaux;    // [P][ldaux] the head's input = ReLU output of the layer below (K live columns)
+  const float* W; int ldw;        // [n][ldw] effective weights (natural orientation)
+  int n; int K; long P;           // n <= 4, K <= 256 (one thread per column)
+  float* dout; int ldo;           // [P][ldo] cotangent of the layer below (pre-activation)
+  float* partial; float* colsum; int npad, ldk, nslots;   // [nslots][npad][ldk], [nslots][npad]
+};
+void be_head_bwd(const HeadBwd& p, cnr_stream s);
 bool be_fdw_enabled();
 void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s);
 void be_prep_weight(const PrepWeight& p, cnr_stream s);

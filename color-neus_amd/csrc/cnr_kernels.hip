@@ -109,6 +109,76 @@ void be_copy_cols(float* dst, int ld_dst, const float* src, int ld_src, int ncol
   CNR_LAUNCH_CHECK("copy_cols");
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward of a 3-wide head: one pass over the 1 KB/point input of the head (see HeadBwd in cnr_backend.h).  One thread per column,
+// points of a slot in order (fixed summation order), 8 points in flight.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void head_bwd_kernel(const HeadBwd p, long pts_per_slot) {
+  // 64 column groups (4 columns, 16-byte accesses) x 8 row lanes; a row lane walks the points p0 + rl, p0 + rl + 8, ... of the slot, eight of
+  // them in flight; the row lanes are folded in a fixed order through LDS at the end
+  __shared__ float red[8][4][256];
+  const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6, k = cg * 4;
+  const long p0 = (long)blockIdx.x * pts_per_slot;
+  long p1 = p0 + pts_per_slot;
+  if (p1 > p.P) p1 = p.P;
+  const bool live = k < p.K;                      // (K is a multiple of 4 here: 256)
+  f4 w[4], acc[4];
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { acc[j] = z4; w[j] = (live && j < p.n) ? *reinterpret_cast<const f4*>(p.W + (long)j * p.ldw + k) : z4; }
+  for (long pt = p0 + rl; pt < p1; pt += 64) {
+    f4 a[8], d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long q = pt + 8 * u < p1 ? pt + 8 * u : p1 - 1;
+      a[u] = live ? *reinterpret_cast<const f4*>(p.aux + q * p.ldaux + k) : z4;
+      d[u] = *reinterpret_cast<const f4*>(p.dtop + q * p.ldt);     // (ldt is a multiple of 4; columns >= n are zero padding)
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (pt + 8 * u < p1) {
+        const float dj[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+        f4 v = z4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v.x = fmaf(w[j].x, dj[j], v.x); v.y = fmaf(w[j].y, dj[j], v.y); v.z = fmaf(w[j].z, dj[j], v.z); v.w = fmaf(w[j].w, dj[j], v.w);
+          acc[j].x = fmaf(dj[j], a[u].x, acc[j].x); acc[j].y = fmaf(dj[j], a[u].y, acc[j].y);
+          acc[j].z = fmaf(dj[j], a[u].z, acc[j].z); acc[j].w = fmaf(dj[j], a[u].w, acc[j].w);
+          cs[j] += dj[j];
+        }
+        f4 o;
+        o.x = a[u].x > 0.0f ? v.x : 0.0f; o.y = a[u].y > 0.0f ? v.y : 0.0f; o.z = a[u].z > 0.0f ? v.z : 0.0f; o.w = a[u].w > 0.0f ? v.w : 0.0f;
+        if (live) *reinterpret_cast<f4*>(p.dout + (pt + 8 * u) * p.ldo + k) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&red[rl][j][k]) = acc[j];
+  __shared__ float redc[8][4];
+  if (cg == 0) { for (int j = 0; j < 4; ++j) redc[rl][j] = cs[j]; }
+  __syncthreads();
+  float* out = p.partial + (long)blockIdx.x * p.npad * p.ldk;
+  for (int e = threadIdx.x; e < p.n * 256; e += 512) {
+    const int j = e >> 8, c = e & 255;
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sum += red[r][j][c];
+    if (c < p.ldk) out[(long)j * p.ldk + c] = sum;
+  }
+  if (p.colsum && threadIdx.x < p.n) {
+    float sum = 0.0f;
+    for (int r = 0; r < 8; ++r) sum += redc[r][threadIdx.x];
+    p.colsum[(long)blockIdx.x * p.npad + threadIdx.x] = sum;
+  }
+}
+void be_head_bwd(const HeadBwd& p, cnr_stream s) {
+  const long per = round_up((int)((p.P + p.nslots - 1) / p.nslots), 64);
+  TimingScope ts_("head_bwd", 2, p.n, p.P, p.K, p.n, 1, s, (double)p.P * (8.0 * p.K + 16.0));
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(p.nslots), dim3(512), 0, s, p, per);
+  CNR_LAUNCH_CHECK("head_bwd");
+}
+
 // ================================================================================================
 // point-wise kernels
 // ================================================================================================

@@ -115,6 +115,30 @@ CNR_PW(be_coltop_bwd, ColTopBwd, body_coltop_bwd, p.P)
 CNR_PW(be_gbar_finish, GbarFinish, body_gbar_finish, p.P)
 CNR_PW(be_pbar_finish, PbarFinish, body_pbar_finish, p.P)
 
+void be_head_bwd(const HeadBwd& p, cnr_stream) {
+  const long per = round_up((int)((p.P + p.nslots - 1) / p.nslots), 64);
+#pragma omp parallel for
+  for (int slot = 0; slot < p.nslots; ++slot) {
+    float* out = p.partial + (long)slot * p.npad * p.ldk;
+    for (int j = 0; j < p.n; ++j) {
+      for (int k = 0; k < p.ldk; ++k) out[(long)j * p.ldk + k] = 0.0f;
+      if (p.colsum) p.colsum[(long)slot * p.npad + j] = 0.0f;
+    }
+    const long p0 = slot * per, p1 = std::min(p.P, p0 + per);
+    for (long pt = p0; pt < p1; ++pt)
+      for (int k = 0; k < p.K; ++k) {
+        const float a = p.aux[pt * p.ldaux + k];
+        float v = 0.0f;
+        for (int j = 0; j < p.n; ++j) {
+          const float d = p.dtop[pt * p.ldt + j];
+          v = fmaf(p.W[(long)j * p.ldw + k], d, v);
+          out[(long)j * p.ldk + k] = fmaf(d, a, out[(long)j * p.ldk + k]);
+          if (k == 0 && p.colsum) p.colsum[(long)slot * p.npad + j] += d;
+        }
+        p.dout[pt * p.ldo + k] = a > 0.0f ? v : 0.0f;
+      }
+  }
+}
 bool be_fdw_enabled() { return getenv("CNR_NO_FDW") == nullptr; }
 void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse&, cnr_stream s) {
   be_dw_gemm(d, s);      // (first: EK_VBACK updates o1 in place, but neither dW operand is an output of this launch, so the order is free)

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -737,6 +738,21 @@ static void fused_into_region(const Lin& q, const LayerGemm& g, DwGemm& d, const
   be_layer_dw_gemm(g, d, f, s);
 }
 
+// backward of a narrow head (<= 4 outputs on a <= 256-wide ReLU layer) in one streaming launch: cotangent of the layer below + weight / bias gradient
+static bool head_bwd_ok(const Lin& q, const LayerGemm& g) {
+  static const bool off = getenv("CNR_NO_HEAD_BWD") != nullptr;   // debugging aid: layer launch + strip launch as before
+  return !off && q.n <= 4 && q.k_int == 256 && q.ldw == 256 && (g.E.ld1 & 3) == 0 && (g.E.ldaux & 3) == 0 && g.A.kind == VK_DIRECT && (g.A.lda & 3) == 0 && g.E.kind == EK_RELU_MASK &&
+         g.E.split >= q.k_int && g.E.aux != nullptr && g.E.o1 != nullptr;
+}
+static void run_head_bwd(const Lin& q, const LayerGemm& g, Bwd& b, const float* const* params, float* const* dparams, cnr_stream s) {
+  const DwRegion r = take_region(q, b);
+  HeadBwd h;
+  h.dtop = g.A.a; h.ldt = g.A.lda; h.aux = g.E.aux; h.ldaux = g.E.ldaux; h.W = q.W; h.ldw = q.ldw; h.n = q.n; h.K = q.k_int; h.P = g.P;
+  h.dout = g.E.o1; h.ldo = g.E.ld1; h.partial = r.part; h.colsum = r.csum; h.npad = q.npad; h.ldk = q.ldw; h.nslots = b.nchunk;
+  be_head_bwd(h, s);
+  finish_region(q, r, b.nchunk, b.nchunk, b, params, dparams);
+}
+
 static void run_dw(const Model& m, const Lin& q, DwGemm& g, Bwd& b, const float* const* params, float* const* dparams,
                    bool with_bias, cnr_stream s) {
   const DwRegion r = take_region(q, b);
@@ -819,6 +835,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       d.npairs = 1; d.P = P;
       d.X[0] = g.A; d.sy[0] = x.rsR[i];
       d.Y[0] = relight_input_view(m, i, x);
+      if (head_bwd_ok(q, g)) { run_head_bwd(q, g, b, params, dP, s); continue; }
       const DwRegion r = take_region(q, b);
       if (fdw && fdw_shape_ok(g) && x.rsR[i] && q.npad == 256 && q.ldw <= 320) {
         fused_into_region(q, g, d, x.rsR[i], 0, r, 0, b, true, s);
@@ -867,6 +884,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     d.npairs = 1; d.P = P;
     d.X[0] = g.A; d.sy[0] = x.rsC[l];
     d.Y[0] = color_input_view(m, l, x);
+    if (head_bwd_ok(q, g)) { run_head_bwd(q, g, b, params, dP, s); continue; }
     const DwRegion r = take_region(q, b);
     if (fdw && fdw_shape_ok(g) && x.rsC[l] && q.npad == 256 && q.ldw <= 320) {
       fused_into_region(q, g, d, x.rsC[l], 0, r, 0, b, true, s);
