@@ -71,7 +71,19 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
     part.N = w;   // (only used for the timing record; the kernel takes its extents from K, P and the epilogue)
     const bool k_ok = g.K <= 256 || (g.K <= 272 && ws_k17_supported(g));
     part.rs_out = c0 == 0 ? g.rs_out : nullptr;   // one launch per operand writes the row scales
-    if (!ws_off && ((ws_kinds >> g.E.kind) & 1) && g.Wp != nullptr && g.wscale != nullptr && w >= 96 && k_ok && (g.A.lda & 3) == 0) launch_layer_gemm_ws(part, round_up(g.N, 32), s);
+    const bool use_ws = !ws_off && ((ws_kinds >> g.E.kind) & 1) && g.Wp != nullptr && g.wscale != nullptr && w >= 96 && k_ok && (g.A.lda & 3) == 0;
+    // the row dot is formed by the weight-stationary kernels while they stage the rows (K <= 256, first column range); otherwise by a
+    // one-column launch of its own
+    const bool dot_native = use_ws && c0 == 0 && g.K <= 256 && g.E.kind == EK_SDF_TOP;
+    if (g.dot_w && !(dot_native)) part.dot_w = nullptr;
+    if (g.dot_w && c0 == 0 && !dot_native) {
+      LayerGemm t;
+      t.A = g.A; t.W = g.dot_w; t.ldw = g.ldw; t.N = 1; t.K = g.K; t.P = g.P; t.P_dev = g.P_dev;
+      t.E.kind = EK_STORE; t.E.n_out = 1; t.E.bias = g.dot_bias; t.E.scale = g.dot_scale; t.E.o1 = g.dot_out; t.E.ld1 = 1;
+      dispatch_layer_gemm(t, 1, s);
+    }
+    if (c0 != 0) part.dot_w = nullptr;
+    if (use_ws) launch_layer_gemm_ws(part, round_up(g.N, 32), s);
     else {
       dispatch_layer_gemm(part, (w + 31) / 32, s);
       if (part.rs_out && g.P > 0) hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, s, part);

@@ -27,6 +27,8 @@ constexpr int WS_TP = 32;
 constexpr int WS_THREADS = 512;
 constexpr int WS_TLD = 36;
 
+__device__ __forceinline__ float ws_dot4(const f4& a, const f4& b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
+
 __device__ __forceinline__ void ws_put4(const f4& v, float sc, unsigned char* dst, int aplane) {
   f16x4 h1, h2;
   float x;
@@ -101,6 +103,16 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   constexpr bool DEEP = PLAIN && !K17 && FULLK && (VK == VK_DIRECT || VK == VK_SOFTPLUS) && (EK == EK_STORE || EK == EK_RELU || EK == EK_SDF_TOP);
   Raw4 r0a, r1a, r2a, r3a, r4a, r0b, r1b, r2b, r3b, r4b;
   const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+  constexpr bool WS_DOT = (EK == EK_SDF_TOP || EK < 0);   // the row dot is compiled into the top SDF layer's instantiation (and the runtime-kind one)
+  f4 dw0 = z4, dw1 = z4, dw2 = z4, dw3 = z4;      // row-dot weights of this thread's columns (LayerGemm::dot_w; K <= 256 there)
+  float dot_b = 0.0f;
+  if (WS_DOT && g.dot_w) {
+    if (pv0) dw0 = *reinterpret_cast<const f4*>(g.dot_w + scol);
+    if (pv1) dw1 = *reinterpret_cast<const f4*>(g.dot_w + 64 + scol);
+    if (pv2) dw2 = *reinterpret_cast<const f4*>(g.dot_w + 128 + scol);
+    if (pv3) dw3 = *reinterpret_cast<const f4*>(g.dot_w + 192 + scol);
+    if (g.dot_bias) dot_b = g.dot_bias[0];
+  }
   r0a.a = z4; r0a.b = z4; r1a = r0a; r2a = r0a; r3a = r0a; r4a = r0a;
   r0b = r0a; r1b = r0a; r2b = r0a; r3b = r0a; r4b = r0a;
 #define WS_FETCH_SET(tile_, S_)                                                   \
@@ -130,9 +142,15 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     if (pv2) ws_put4(v2, sc, dst + 256, aplane);                                  \
     if (pv3) ws_put4(v3, sc, dst + 384, aplane);                                  \
     if (K17 && pv4) ws_put4(v4, sc, dst + 512, aplane);                           \
+    float dsum_ = 0.0f;                                                           \
+    if (WS_DOT && g.dot_w) {                                                                \
+      dsum_ = (ws_dot4(v0, dw0) + ws_dot4(v1, dw1)) + (ws_dot4(v2, dw2) + ws_dot4(v3, dw3)); \
+      _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) dsum_ += __shfl_xor(dsum_, d, 16); \
+    }                                                                             \
     if ((tid & 15) == 0) {                                                        \
       reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
       const long prow_ = WS_TILE(tile_) * WS_TP + srow;                                  \
+      if (WS_DOT && g.dot_w && prow_ < Pn) g.dot_out[prow_] = (dsum_ + dot_b) * g.dot_scale; \
       if (g.rs_out && prow_ < Pn) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); /* 0: all-zero row, NaN: non-finite row (must keep poisoning the weight gradient) */ \
     }                                                                             \
   }
@@ -368,6 +386,15 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
   constexpr bool DEEP = VK == VK_DIRECT && (EK == EK_STORE || EK == EK_RELU || EK == EK_SDF_TOP);
   Raw4 r0a, r1a, r2a, r3a, r0b, r1b, r2b, r3b;
   const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f4 dw0 = z4, dw1 = z4, dw2 = z4, dw3 = z4;      // row-dot weights (LayerGemm::dot_w): only the top SDF layer's instantiation carries them
+  float dot_b = 0.0f;
+  if (EK == EK_SDF_TOP && g.dot_w) {
+    dw0 = *reinterpret_cast<const f4*>(g.dot_w + scol);
+    dw1 = *reinterpret_cast<const f4*>(g.dot_w + 64 + scol);
+    dw2 = *reinterpret_cast<const f4*>(g.dot_w + 128 + scol);
+    dw3 = *reinterpret_cast<const f4*>(g.dot_w + 192 + scol);
+    if (g.dot_bias) dot_b = g.dot_bias[0];
+  }
   r0a.a = z4; r0a.b = z4; r1a = r0a; r2a = r0a; r3a = r0a;
   r0b = r0a; r1b = r0a; r2b = r0a; r3b = r0a;
   // (tile_ may run past the range: clamped, the redundant fetch / LDS tile of the last iterations is never used)
@@ -396,9 +423,15 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
     ws_put4(v1, sc, dst + 128, aplane);                                           \
     ws_put4(v2, sc, dst + 256, aplane);                                           \
     ws_put4(v3, sc, dst + 384, aplane);                                           \
+    float dsum_ = 0.0f;                                                           \
+    if (EK == EK_SDF_TOP && g.dot_w) {                                            \
+      dsum_ = (ws_dot4(v0, dw0) + ws_dot4(v1, dw1)) + (ws_dot4(v2, dw2) + ws_dot4(v3, dw3)); \
+      _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) dsum_ += __shfl_xor(dsum_, d, 16); \
+    }                                                                             \
     if ((tid & 15) == 0) {                                                        \
       reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
       const long prow_ = WSS_TILE((tile_) < tlast ? (tile_) : tlast) * WS_TP + srow; \
+      if (EK == EK_SDF_TOP && g.dot_w) g.dot_out[prow_] = (dsum_ + dot_b) * g.dot_scale; \
       if (g.rs_out) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); \
     }                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                            \
@@ -551,6 +584,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
 inline bool ws_stream_ok(const LayerGemm& g, int wrows) {
   static const bool off = getenv("CNR_WS_NOSTREAM") != nullptr;   // debugging aid: the general kernel for every launch
   if (off || g.K <= 240 || g.K > 256 || g.P_dev != nullptr || (g.P % WS_TP) != 0) return false;
+  if (g.dot_w != nullptr && g.E.kind != EK_SDF_TOP) return false;   // (the row dot lives in that instantiation of the stream form only)
   const int live = g.E.n_out + (g.E.tail_src ? g.E.tail_n : 0);
   if (g.col0 + 256 > wrows || g.col0 + 256 > live) return false;
   for (int c = g.col0; c < g.col0 + 256; c += 4) if (!epi_fast4(g.E, c)) return false;

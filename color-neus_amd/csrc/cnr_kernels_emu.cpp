@@ -62,6 +62,11 @@ void be_layer_gemm(const LayerGemm& g0, cnr_stream) {
       f4 v = view_eval4(g.A, row, k);
       arow[k] = v.x; arow[k + 1] = v.y; arow[k + 2] = v.z; arow[k + 3] = v.w;
     }
+    if (g.dot_w && g.first_col == 0) {   // row dot (LayerGemm::dot_*): the sdf row of the top SDF layer
+      float acc = 0.0f;
+      for (int k = 0; k < g.K; ++k) acc = fmaf(arow[k], g.dot_w[k], acc);
+      g.dot_out[row] = (acc + (g.dot_bias ? g.dot_bias[0] : 0.0f)) * g.dot_scale;
+    }
     int ncols = g.N;
     if (g.E.tail_src && g.E.n_out + g.E.tail_n > ncols) ncols = g.E.n_out + g.E.tail_n;
     for (int n = g.first_col; n < round_up(ncols, 32); ++n) {

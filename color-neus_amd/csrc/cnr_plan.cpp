@@ -454,9 +454,12 @@ static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, f
       g.E.kind = EK_STORE; g.E.n_out = q.n; g.E.bias = q.bias; g.E.o1 = Z[l]; g.E.ld1 = m.Hs;
       if (m.skip(l + 1)) { g.E.tail_src = E; g.E.ld_tail = kEmb; g.E.tail_n = m.emb; }   // next layer reads [h | e]
     } else if (feat_out) {
-      g.N = q.n;
-      g.E.kind = EK_SDF_TOP; g.E.n_out = q.n; g.E.bias = q.bias; g.E.scale = top_scale; g.E.split = m.F;
+      // internal row order [features (F) | sdf]: the F feature columns by the layer launch, the sdf row as a row dot formed while the launch
+      // stages its input rows (no second launch over the same rows)
+      g.N = m.F;
+      g.E.kind = EK_SDF_TOP; g.E.n_out = m.F; g.E.bias = q.bias; g.E.scale = top_scale; g.E.split = m.F;
       g.E.o1 = feat_out; g.E.ld1 = ld_feat; g.E.o2 = sdf_out;
+      g.dot_w = q.W + (long)m.F * q.ldw; g.dot_bias = q.bias + m.F; g.dot_scale = top_scale; g.dot_out = sdf_out;
     } else {   // value only: just the sdf row (last internal row)
       g.W = q.W + (long)m.F * q.ldw; g.N = 1; g.Wp = nullptr;
       g.E.kind = EK_STORE; g.E.n_out = 1; g.E.bias = q.bias + m.F; g.E.scale = top_scale; g.E.o1 = sdf_out; g.E.ld1 = 1;

@@ -353,6 +353,10 @@ struct LayerGemm {
   long wp_stride = 0;                   // elements between planes
   const float* wscale = nullptr;        // per W row: 1 / (power-of-two scale applied before the f16 split)
   const int* P_dev = nullptr; // optional device-side row count (<= P): compacted point lists whose length only the GPU knows
+  // optional row dot product formed while the input tile is staged (the 16 threads that stage a row hold all of it): the ONE extra output
+  // column of a 257-wide layer (the sdf row of the top SDF layer) without a second launch over the same rows:
+  //   dot_out[row] = (sum_k A[row][k] * dot_w[k] + dot_bias[0]) * dot_scale        (fp32 FMAs, fixed order)
+  const float* dot_w = nullptr; const float* dot_bias = nullptr; float dot_scale = 1.0f; float* dot_out = nullptr;
   float* rs_out = nullptr;    // optional [P]: the power-of-two scale that lifts each (prologue-applied) operand row into the top f16
                               // binade, 0 for an all-zero row; the weight-gradient GEMM re-uses it for the same operand
 };
