@@ -83,7 +83,7 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
       dispatch_layer_gemm(t, 1, s);
     }
     if (c0 != 0) part.dot_w = nullptr;
-    if (use_ws) launch_layer_gemm_ws(part, round_up(g.N, 32), s);
+    if (use_ws) launch_layer_gemm_ws(part, g.w_rows > 0 ? g.w_rows : round_up(g.N, 32), s);
     else {
       dispatch_layer_gemm(part, (w + 31) / 32, s);
       if (part.rs_out && g.P > 0) hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((g.P + 255) / 256)), dim3(256), 0, s, part);

@@ -38,6 +38,7 @@ struct Lin {
   int nseg = 0;
   Segment seg[4];
   int ldw = 0, npad = 0, ldwt = 0, kpad = 0;
+  int wpad = 0;                                   // rows of W / its planes / bias that exist (zero beyond n): npad, or more when a tail fill widens the launch
   bool wn = false;
   int row_rot = 0;            // internal row i = reference row (i + row_rot) % n
   int p_b = -1, p_g = -1, p_v = -1;
@@ -49,10 +50,11 @@ struct Lin {
   void finish_dims() {
     ldw = round_up(k_int, 16);
     npad = round_up(n, 32);
+    wpad = npad;
     ldwt = round_up(n, 16);
     kpad = round_up(k_int, 32);
   }
-  size_t bytes() const { return ((size_t)npad * ldw + (size_t)kpad * ldwt + npad) * sizeof(float); }
+  size_t bytes() const { return ((size_t)wpad * ldw + (size_t)kpad * ldwt + wpad) * sizeof(float); }
 };
 
 struct ParamInfo { std::string name; int rows, cols; };
@@ -140,6 +142,9 @@ static int build_model(const cnr_config* cfg, Model& m) {
     identity_seg(q);
     if (l == m.L) q.row_rot = 1;   // internal rows [features (F) | sdf]: the 256 feature columns stay 16-byte aligned
     q.finish_dims();
+    // the layer below a skip connection: its launches also write the embedding into the columns behind its own (tail fill); zero weight rows
+    // under those columns let every 32-column block of the launch run the same code (the stream form of the layer kernel)
+    if (l < m.L && m.skip(l + 1) && round_up(q.n + m.emb, 32) <= 256) q.wpad = round_up(q.n + m.emb, 32);
     add_linear_params(m, q, "sdf_network.lin" + std::to_string(l), c.sdf_weight_norm != 0);
     prev = out;
   }
@@ -242,12 +247,12 @@ struct Ctx {   // forward-saved state
 static int hr_ld(const Model& m, const Ctx& x, int i) { return i == m.c.rel_y_in_layer - 1 ? x.ldy : m.Hr; }
 
 static void place_lin(Lin& q, Arena& a) {
-  q.W = a.f((size_t)q.npad * q.ldw);
+  q.W = a.f((size_t)q.wpad * q.ldw);
   q.Wt = a.f((size_t)q.kpad * q.ldwt);
-  q.bias = a.f(q.npad);
-  q.Wp = reinterpret_cast<unsigned short*>(a.f((size_t)q.npad * q.ldw));
+  q.bias = a.f(q.wpad);
+  q.Wp = reinterpret_cast<unsigned short*>(a.f((size_t)q.wpad * q.ldw));
   q.Wtp = reinterpret_cast<unsigned short*>(a.f((size_t)q.kpad * q.ldwt));
-  q.Wps = a.f(q.npad > 256 ? q.npad : 256);   // (the fused kernels read 256 column scales; entries >= npad are never used)
+  q.Wps = a.f(q.wpad > 256 ? q.wpad : 256);   // (the fused kernels read 256 column scales; entries >= npad are never used)
   q.Wtps = a.f(q.kpad);
   q.Wf = (q.ldw <= 256) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldw / 16) * 2 * 64 * 8 / 2)) : nullptr;
 }
@@ -392,11 +397,11 @@ static void prep_all(Model& m, const float* const* params, cnr_stream s) {
     p.n = q.n; p.k_ref = q.k_ref;
     p.nseg = q.nseg;
     for (int i = 0; i < q.nseg; ++i) p.seg[i] = q.seg[i];
-    p.W = q.W; p.ldw = q.ldw; p.npad = q.npad;
+    p.W = q.W; p.ldw = q.ldw; p.npad = q.wpad;
     p.Wt = q.Wt; p.ldwt = q.ldwt; p.kpad = q.kpad;
     p.bias = q.bias; p.row_rot = q.row_rot;
     pw.push_back(p);
-    sj.push_back(SplitJob{q.W, q.npad, q.ldw, q.Wp, q.Wps});
+    sj.push_back(SplitJob{q.W, q.wpad, q.ldw, q.Wp, q.Wps});
     sj.push_back(SplitJob{q.Wt, q.kpad, q.ldwt, q.Wtp, q.Wtps});
   };
   for (auto& q : m.sdf) prep(q);
@@ -405,7 +410,7 @@ static void prep_all(Model& m, const float* const* params, cnr_stream s) {
   be_prep_weights(pw.data(), (int)pw.size(), s);            // effective weights of every layer: one launch
   be_split_planes_many(sj.data(), (int)sj.size(), s);       // their f16 planes (W and W^T): one launch
   std::vector<PackJob> pj;
-  for (auto& q : m.sdf) if (q.Wf) pj.push_back(PackJob{q.Wp, (long)q.npad * q.ldw, q.npad, q.ldw, q.Wf});
+  for (auto& q : m.sdf) if (q.Wf) pj.push_back(PackJob{q.Wp, (long)q.wpad * q.ldw, q.wpad, q.ldw, q.Wf});
   be_pack_frags_many(pj.data(), (int)pj.size(), s);         // fragment-major copies for the chain-fused kernels: one launch
 }
 
@@ -447,7 +452,7 @@ static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, f
     const Lin& q = m.sdf[l];
     LayerGemm g;
     g.A = sdf_input_view(m, l, E, Z);
-    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.K = q.k_int; g.P = n;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.wpad * q.ldw; g.w_rows = q.wpad; g.wscale = q.Wps; g.K = q.k_int; g.P = n;
     if (rs && (l < m.L || feat_out)) g.rs_out = rs[l];
     if (l < m.L) {
       g.N = q.n;
@@ -557,7 +562,7 @@ static void color_chain(const Model& m, long P, const Ctx& x, cnr_stream s, cons
     const Lin& q = m.col[l];
     LayerGemm g;
     g.A = color_input_view(m, l, x);
-    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.wpad * q.ldw; g.w_rows = q.wpad; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.bias = q.bias; g.E.n_out = q.n;
     if (!P_dev && (size_t)l < x.rsC.size()) g.rs_out = x.rsC[l];
     if (l + 1 < m.NC) { g.E.kind = EK_RELU; g.E.o1 = x.HC[l]; g.E.ld1 = m.Hc; }
@@ -582,7 +587,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
     const Lin& q = m.rel[0];
     LayerGemm g;
     g.A = relight_input_view(m, -1, x);
-    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.wpad * q.ldw; g.w_rows = q.wpad; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.kind = EK_RELU; g.E.bias = q.bias; g.E.n_out = q.n; g.E.o1 = x.HR[0]; g.E.ld1 = hr_ld(m, x, 0);
     be_layer_gemm(g, s);
   }
@@ -590,7 +595,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
     const Lin& q = m.rel[1 + i];
     LayerGemm g;
     g.A = relight_input_view(m, i, x);
-    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.wpad * q.ldw; g.w_rows = q.wpad; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P; g.P_dev = P_dev;
     g.E.bias = q.bias; g.E.n_out = q.n;
     if (!P_dev && (size_t)i < x.rsR.size()) g.rs_out = x.rsR[i];
     if (i + 1 < m.NR) { g.E.kind = EK_RELU; g.E.o1 = x.HR[i + 1]; g.E.ld1 = hr_ld(m, x, i + 1); }
@@ -921,7 +926,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     const Lin& q = m.sdf[l];
     LayerGemm g;
     g.A = qbar_view(l);
-    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P;
+    g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.wpad * q.ldw; g.w_rows = q.wpad; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = P;
     g.E.kind = EK_SWEEP; g.E.n_out = q.n; g.E.z = x.Z[l]; g.E.ldz = m.Hs;
     if (l == m.L - 1) { g.E.v = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; g.E.ldv = 0; g.E.vscale = inv_scale; }
     else { g.E.v = x.V[l]; g.E.ldv = m.Hs; }
@@ -1156,9 +1161,9 @@ static void linear_prep(LinearOp& op, const float* W, const float* b, cnr_stream
   PrepWeight p;
   p.g = nullptr; p.v = W; p.b = b; p.n = q.n; p.k_ref = q.k_ref; p.nseg = q.nseg;
   for (int i = 0; i < q.nseg; ++i) p.seg[i] = q.seg[i];
-  p.W = q.W; p.ldw = q.ldw; p.npad = q.npad; p.Wt = q.Wt; p.ldwt = q.ldwt; p.kpad = q.kpad; p.bias = q.bias; p.row_rot = 0;
+  p.W = q.W; p.ldw = q.ldw; p.npad = q.wpad; p.Wt = q.Wt; p.ldwt = q.ldwt; p.kpad = q.kpad; p.bias = q.bias; p.row_rot = 0;
   be_prep_weights(&p, 1, s);
-  SplitJob sj[2] = {SplitJob{q.W, q.npad, q.ldw, q.Wp, q.Wps}, SplitJob{q.Wt, q.kpad, q.ldwt, q.Wtp, q.Wtps}};
+  SplitJob sj[2] = {SplitJob{q.W, q.wpad, q.ldw, q.Wp, q.Wps}, SplitJob{q.Wt, q.kpad, q.ldwt, q.Wtp, q.Wtps}};
   be_split_planes_many(sj, 2, s);
 }
 
@@ -1490,7 +1495,7 @@ int cnr_linear_forward(const float* x, int64_t n, int32_t k, const float* W, con
   pad_in(op.xp, op.ldx, x, k, n, s);
   LayerGemm g;
   g.A.kind = VK_DIRECT; g.A.a = op.xp; g.A.lda = op.ldx;
-  g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = n;
+  g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.wpad * q.ldw; g.w_rows = q.wpad; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = n;
   g.E.kind = relu ? EK_RELU : EK_STORE; g.E.bias = b ? q.bias : nullptr; g.E.n_out = q.n; g.E.o1 = op.yp; g.E.ld1 = op.ldy;
   be_layer_gemm(g, s);
   be_copy_cols(y, n_out, op.yp, op.ldy, n_out, n, s);
@@ -1578,7 +1583,7 @@ int cnr_vertex_color(const cnr_config* cfg, const float* const* params, const fl
       const Lin& q = m.col[l];
       LayerGemm g;
       g.A = color_input_view(m, l, x);
-      g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.npad * q.ldw; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = cnt;
+      g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.wpad * q.ldw; g.w_rows = q.wpad; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = cnt;
       g.E.bias = q.bias; g.E.n_out = q.n;
       if (l + 1 < m.NC) { g.E.kind = EK_RELU; g.E.o1 = x.HC[l]; g.E.ld1 = m.Hc; }
       else { g.E.kind = m.c.col_squeeze_out ? EK_SIGMOID : EK_LINEAR_SIG; g.E.o1 = rgb + start * 3; g.E.ld1 = 3; }

@@ -186,7 +186,7 @@ CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
 // 4 consecutive accumulator columns (col % 4 == 0): 16-byte fast paths for the bandwidth-heavy kinds, element-wise otherwise
 // ---- 16-byte epilogue path, split into "is it applicable" / "side loads" / "math + stores" so that a kernel can issue the
 // side loads of several rows back to back (one memory round trip per tile instead of one per row group)
-struct EpiRaw4 { f4 a; f4 b; };
+struct EpiRaw4 { f4 a; f4 b; };   // (launches with a tail source: the elements of a at columns >= n_out hold the tail-fill values)
 
 // true when 4 consecutive columns starting at col (col % 4 == 0) take the 16-byte path; depends on the column only
 CNR_HD bool epi_fast4(const Epi& e, int col) {
@@ -215,8 +215,10 @@ CNR_HD EpiRaw4 epi_fetch4(const Epi& e, long row, int col) {
   r.a = zero; r.b = zero;
   switch (e.kind) {
     case EK_SWEEP:
-      r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
-      r.b = e.ldv ? *reinterpret_cast<const f4*>(e.v + row * e.ldv + col) : *reinterpret_cast<const f4*>(e.v + col);
+      if (col < e.n_out) {
+        r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
+        r.b = e.ldv ? *reinterpret_cast<const f4*>(e.v + row * e.ldv + col) : *reinterpret_cast<const f4*>(e.v + col);
+      }
       break;
     case EK_VBACK:
       if (col < e.split) {
@@ -228,6 +230,13 @@ CNR_HD EpiRaw4 epi_fetch4(const Epi& e, long row, int col) {
       r.a = *reinterpret_cast<const f4*>(e.aux + row * e.ldaux + col);
       break;
     default: break;
+  }
+  if (e.tail_src && col + 4 > e.n_out && (e.kind == EK_STORE || e.kind == EK_SWEEP)) {   // fetched with the other side inputs, ahead of use
+    const float* t = e.tail_src + row * e.ld_tail - e.n_out;
+    if (col >= e.n_out) r.a.x = t[col];
+    if (col + 1 >= e.n_out) r.a.y = t[col + 1];
+    if (col + 2 >= e.n_out) r.a.z = t[col + 2];
+    if (col + 3 >= e.n_out) r.a.w = t[col + 3];
   }
   return r;
 }
@@ -259,11 +268,10 @@ CNR_HD void epi_finish4(const Epi& e, long row, int col, const f4& acc, const f4
       f4 o;
       o.x = (acc.x + b.x) * e.scale; o.y = (acc.y + b.y) * e.scale; o.z = (acc.z + b.z) * e.scale; o.w = (acc.w + b.w) * e.scale;
       if (e.tail_src && col + 4 > e.n_out) {   // tail-fill columns (only the launches that materialise a skip concat have them)
-        const float* t = e.tail_src + row * e.ld_tail - e.n_out;
-        if (col >= e.n_out) o.x = t[col];
-        if (col + 1 >= e.n_out) o.y = t[col + 1];
-        if (col + 2 >= e.n_out) o.z = t[col + 2];
-        if (col + 3 >= e.n_out) o.w = t[col + 3];
+        if (col >= e.n_out) o.x = raw.a.x;
+        if (col + 1 >= e.n_out) o.y = raw.a.y;
+        if (col + 2 >= e.n_out) o.z = raw.a.z;
+        if (col + 3 >= e.n_out) o.w = raw.a.w;
       }
       *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + e.o1_off + col) = o;
     } break;
@@ -280,11 +288,10 @@ CNR_HD void epi_finish4(const Epi& e, long row, int col, const f4& acc, const f4
       o1.z = softplus100_d2(zz.z) * (vv.z * e.vscale) * acc.z; o2.z = softplus100_d1(zz.z) * acc.z;
       o1.w = softplus100_d2(zz.w) * (vv.w * e.vscale) * acc.w; o2.w = softplus100_d1(zz.w) * acc.w;
       if (e.tail_src && col + 4 > e.n_out) {
-        const float* t = e.tail_src + row * e.ld_tail - e.n_out;
-        if (col >= e.n_out) { o1.x = 0.f; o2.x = t[col]; }
-        if (col + 1 >= e.n_out) { o1.y = 0.f; o2.y = t[col + 1]; }
-        if (col + 2 >= e.n_out) { o1.z = 0.f; o2.z = t[col + 2]; }
-        if (col + 3 >= e.n_out) { o1.w = 0.f; o2.w = t[col + 3]; }
+        if (col >= e.n_out) { o1.x = 0.f; o2.x = raw.a.x; }
+        if (col + 1 >= e.n_out) { o1.y = 0.f; o2.y = raw.a.y; }
+        if (col + 2 >= e.n_out) { o1.z = 0.f; o2.z = raw.a.z; }
+        if (col + 3 >= e.n_out) { o1.w = 0.f; o2.w = raw.a.w; }
       }
       *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o1;
       *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + col) = o2;
@@ -351,6 +358,7 @@ struct LayerGemm {
   int first_col = 0;          // be_layer_gemm starts at this column (a multiple of 256): the columns below belong to another launch
   const unsigned short* Wp = nullptr;   // optional: W as two f16 planes (hi, lo) of the row-scaled weights, same [rows][ldw] layout each
   long wp_stride = 0;                   // elements between planes
+  int w_rows = 0;                       // rows of W / Wp that exist (zero rows beyond N); 0: round_up(N, 32)
   const float* wscale = nullptr;        // per W row: 1 / (power-of-two scale applied before the f16 split)
   const int* P_dev = nullptr; // optional device-side row count (<= P): compacted point lists whose length only the GPU knows
   // optional row dot product formed while the input tile is staged (the 16 threads that stage a row hold all of it): the ONE extra output
