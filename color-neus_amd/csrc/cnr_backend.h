@@ -33,6 +33,7 @@ struct FinishWeight {
   int nseg = 0; Segment seg[4];
   float* dg = nullptr; float* dv = nullptr; float* db = nullptr;   // outputs (dg null for plain Linear; dv = d weight)
   int row_rot = 0;            // see PrepWeight
+  int col_hi = 1 << 30, nchunk_hi = 0;   // columns >= col_hi are summed over nchunk_hi slots (strip columns filled by be_strip_bwd)
 };
 
 struct EmbedZ {   // E[r*m + j][0..kEmb) = PE(scale * (o_r + d_r * z[r*ldz + j])), optional coarse-z generation
@@ -197,6 +198,19 @@ struct HeadBwd {
   float* partial; float* colsum; int npad, ldk, nslots;   // [nslots][npad][ldk], [nslots][npad]
 };
 void be_head_bwd(const HeadBwd& p, cnr_stream s);
+// The few input columns beyond 256 of a 256-wide layer (relight y-layer: + rgb, colour layer 0: + p, g) in the backward pass, one streaming
+// pass over the layer's output cotangent instead of a narrow layer launch plus a weight-gradient strip launch:
+//   tail[pt][j]                    = tail_scale * sum_n dout[pt][n] * Wt[256 + j][n]          (cotangent of input column 256 + j)
+//   partial[slot][n][256 + j]      = sum over the slot's points of dout[pt][n] * y[pt][j]     (weight-gradient strip; zero for nt <= j < ldk - 256)
+struct StripBwd {
+  const float* dout; int ldo; long P;   // [P][ldo], 256 live columns (ldo % 4 == 0)
+  int nt;                               // extra input columns, 1..8
+  const float* Wt; int ldwt;            // transposed fp32 weights [k][ldwt]: row 256 + j is used
+  float* tail; int ldt; float tail_scale;   // [P][ldt] (null: cotangent not wanted)
+  const float* y; int ldy;              // [P][ldy]: column j = input column 256 + j of the layer
+  float* partial; int npad, ldk, nslots;    // [nslots][npad][ldk]
+};
+void be_strip_bwd(const StripBwd& p, cnr_stream s);
 bool be_fdw_enabled();
 void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s);
 void be_prep_weight(const PrepWeight& p, cnr_stream s);

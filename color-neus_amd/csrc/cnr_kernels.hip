@@ -179,6 +179,88 @@ void be_head_bwd(const HeadBwd& p, cnr_stream s) {
   CNR_LAUNCH_CHECK("head_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// strips of a (256 + nt)-input layer in the backward pass (see StripBwd in cnr_backend.h): one pass over the 1 KB/point cotangent.
+// A wave owns one point at a time (lane = 4-column group), PTS points in flight.  The PTS x NT partial dot products of a lane are summed
+// over the 64 lanes by a halving exchange (each step a lane gives away the half of its values that belongs to the other side of the
+// mask): 63 shuffles for 64 sums, lane L ends with the sum of index L = point (L / NT), column (L % NT).  Fixed order: deterministic.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512) void strip_bwd_kernel(const StripBwd p, long pts_per_slot) {
+  constexpr int PTS = 64 / NT;                    // points in flight per wave
+  extern __shared__ __attribute__((aligned(16))) float strip_red[];   // [8 waves][NT][256]
+  const int lane = threadIdx.x & 63, k = lane * 4;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long p0 = (long)blockIdx.x * pts_per_slot;
+  long p1 = p0 + pts_per_slot;
+  if (p1 > p.P) p1 = p.P;
+  const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f4 w[NT], acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { acc[j] = z4; w[j] = j < p.nt ? *reinterpret_cast<const f4*>(p.Wt + (long)(256 + j) * p.ldwt + k) : z4; }
+  const int yu = lane / NT, yj = lane % NT;       // the (point, column) whose y value this lane fetches and whose dot product it ends up with
+  for (long pt = p0 + (long)wv * PTS; pt < p1; pt += 8 * PTS) {
+    f4 d[PTS];
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+      const long q = pt + u < p1 ? pt + u : p1 - 1;
+      d[u] = *reinterpret_cast<const f4*>(p.dout + q * p.ldo + k);
+    }
+    const bool mine = pt + yu < p1 && yj < p.nt;
+    const float yl = mine ? p.y[(pt + yu) * p.ldy + yj] : 0.0f;
+    float v[64];
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float yv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yl), u * NT + j));   // 0 past the end / j >= nt
+        acc[j].x = fmaf(yv, d[u].x, acc[j].x); acc[j].y = fmaf(yv, d[u].y, acc[j].y);
+        acc[j].z = fmaf(yv, d[u].z, acc[j].z); acc[j].w = fmaf(yv, d[u].w, acc[j].w);
+        v[u * NT + j] = fmaf(d[u].w, w[j].w, fmaf(d[u].z, w[j].z, fmaf(d[u].y, w[j].y, d[u].x * w[j].x)));
+      }
+    }
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) {
+      const bool up = (lane & mk) != 0;
+#pragma unroll
+      for (int i = 0; i < mk; ++i) {
+        const float keep = up ? v[i + mk] : v[i];
+        const float send = up ? v[i] : v[i + mk];
+        v[i] = keep + __shfl_xor(send, mk);
+      }
+    }
+    if (p.tail && mine) p.tail[(pt + yu) * p.ldt + yj] = v[0] * p.tail_scale;
+  }
+  // fold the 8 waves in a fixed order; a slot row is [ .. 256 main columns (another launch) .. | nt strip columns | zero pad up to ldk ]
+#pragma unroll
+  for (int j = 0; j < NT; ++j) *reinterpret_cast<f4*>(strip_red + ((long)wv * NT + j) * 256 + k) = acc[j];
+  __syncthreads();
+  float* out = p.partial + (long)blockIdx.x * p.npad * p.ldk;
+  const int wcols = p.ldk - 256;
+  for (int e = threadIdx.x; e < 256 * wcols; e += 512) {
+    const int n = e / wcols, j = e - n * wcols;
+    float sum = 0.0f;
+    if (j < p.nt) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += strip_red[((long)r * NT + j) * 256 + n];
+    }
+    if (n < p.npad) out[(long)n * p.ldk + 256 + j] = sum;
+  }
+}
+template <int NT>
+static void launch_strip_bwd(const StripBwd& p, long per, cnr_stream s) {
+  static DeviceOnce attr_once;
+  const size_t lds = (size_t)8 * NT * 256 * sizeof(float);
+  if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&strip_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipLaunchKernelGGL((strip_bwd_kernel<NT>), dim3(p.nslots), dim3(512), lds, s, p, per);
+}
+void be_strip_bwd(const StripBwd& p, cnr_stream s) {
+  const long per = round_up((int)((p.P + p.nslots - 1) / p.nslots), 64);
+  TimingScope ts_("strip_bwd", 2, p.nt, p.P, 256, p.nt, 1, s, (double)p.P * (4.0 * 256 + 8.0 * p.nt));
+  if (p.nt <= 4) launch_strip_bwd<4>(p, per, s); else launch_strip_bwd<8>(p, per, s);
+  CNR_LAUNCH_CHECK("strip_bwd");
+}
+
 // ================================================================================================
 // point-wise kernels
 // ================================================================================================
@@ -487,14 +569,15 @@ __device__ __forceinline__ void finish_weight_row(const FinishWeight& p, const i
     const long cs = (long)p.npad * p.ldk;
     float s = 0.0f;
     int c = 0;
-    for (; c + 8 <= p.nchunk; c += 8) {
+    const int nch = j >= p.col_hi ? p.nchunk_hi : p.nchunk;   // (strip columns: their own slot count, see StripBwd)
+    for (; c + 8 <= nch; c += 8) {
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = src[(long)(c + q) * cs];
 #pragma unroll
       for (int q = 0; q < 8; ++q) s += v[q];
     }
-    for (; c < p.nchunk; ++c) s += src[(long)c * cs];
+    for (; c < nch; ++c) s += src[(long)c * cs];
     dwi[j] = s;
   }
   __syncthreads();

@@ -144,6 +144,27 @@ void be_head_bwd(const HeadBwd& p, cnr_stream) {
       }
   }
 }
+void be_strip_bwd(const StripBwd& p, cnr_stream) {
+  const long per = round_up((int)((p.P + p.nslots - 1) / p.nslots), 64);
+#pragma omp parallel for
+  for (int slot = 0; slot < p.nslots; ++slot) {
+    float* out = p.partial + (long)slot * p.npad * p.ldk;
+    for (int n = 0; n < 256 && n < p.npad; ++n)
+      for (int k = 256; k < p.ldk; ++k) out[(long)n * p.ldk + k] = 0.0f;
+    const long p0 = slot * per, p1 = std::min(p.P, p0 + per);
+    for (long pt = p0; pt < p1; ++pt)
+      for (int j = 0; j < p.nt; ++j) {
+        const float y = p.y[pt * p.ldy + j];
+        float dot = 0.0f;
+        for (int n = 0; n < 256; ++n) {
+          const float d = p.dout[pt * p.ldo + n];
+          dot = fmaf(d, p.Wt[(long)(256 + j) * p.ldwt + n], dot);
+          if (n < p.npad) out[(long)n * p.ldk + 256 + j] = fmaf(d, y, out[(long)n * p.ldk + 256 + j]);
+        }
+        if (p.tail) p.tail[pt * p.ldt + j] = dot * p.tail_scale;
+      }
+  }
+}
 bool be_fdw_enabled() { return getenv("CNR_NO_FDW") == nullptr; }
 void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse&, cnr_stream s) {
   be_dw_gemm(d, s);      // (first: EK_VBACK updates o1 in place, but neither dW operand is an output of this launch, so the order is free)
@@ -185,7 +206,8 @@ void be_finish_weight(const FinishWeight& p, cnr_stream) {
     const int nr = (n + p.row_rot) % p.n;
     for (int j = 0; j < p.ldk; ++j) {
       float s = 0.0f;
-      for (int c = 0; c < p.nchunk; ++c) s += p.partial[((long)c * p.npad + n) * p.ldk + j];
+      const int nch = j >= p.col_hi ? p.nchunk_hi : p.nchunk;
+      for (int c = 0; c < nch; ++c) s += p.partial[((long)c * p.npad + n) * p.ldk + j];
       dwi[j] = s;
     }
     for (int c = 0; c < p.k_ref; ++c) {

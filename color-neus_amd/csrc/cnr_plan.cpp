@@ -721,9 +721,10 @@ static void finish_region(const Lin& q, const DwRegion& r, int nslots, int ncols
   b.pending.push_back(f);
 }
 // separate weight-gradient GEMM into slots [slot0, slot0 + nchunk) of a region (bias column sums only for a group at slot 0)
-static void dw_into_region(const Lin& q, DwGemm& g, const DwRegion& r, int slot0, int nchunk, long P, bool with_bias, cnr_stream s) {
+static void dw_into_region(const Lin& q, DwGemm& g, const DwRegion& r, int slot0, int nchunk, long P, bool with_bias, cnr_stream s, int kmain = 0) {
   with_bias = with_bias && slot0 == 0;
-  g.N = q.n; g.K = q.k_int; g.nchunk = nchunk; g.chunk_pts = round_up((int)((P + nchunk - 1) / nchunk), 16);
+  g.N = q.n; g.K = kmain > 0 ? kmain : q.k_int;   // (kmain: the columns beyond it are formed by be_strip_bwd)
+  g.nchunk = nchunk; g.chunk_pts = round_up((int)((P + nchunk - 1) / nchunk), 16);
   g.partial = r.part + (size_t)slot0 * q.npad * q.ldw; g.Npad = q.npad; g.ldk = q.ldw; g.colsum = with_bias ? r.csum : nullptr;
   // split-f16 tiles need the row scales of every operand of the 256 x 256 tiles (the top SDF layer's unit-vector pair is dropped there)
   const int need = (g.npairs == 2 && g.X[1].kind == VK_CONST_COL0) ? 1 : g.npairs;
@@ -735,16 +736,39 @@ static void dw_into_region(const Lin& q, DwGemm& g, const DwRegion& r, int slot0
 // layer launch + its weight-gradient pair (d.X[0] / d.Y[0]: the pair as a plain weight-gradient GEMM -- what the CPU emulation and the HIP
 // backend's unfused fallback run; se = row scales of the epilogue-side operand) into slots [slot0, slot0 + b.fslots) of a region
 static void fused_into_region(const Lin& q, const LayerGemm& g, DwGemm& d, const float* se, int transposed, const DwRegion& r, int slot0, Bwd& b,
-                              bool with_bias, cnr_stream s) {
+                              bool with_bias, cnr_stream s, int kmain = 0) {
   with_bias = with_bias && slot0 == 0 && !transposed;
   DwFuse f;
   f.se = se; f.partial = r.part + (size_t)slot0 * q.npad * q.ldw; f.Npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? r.csum : nullptr;
   f.transposed = transposed; f.nslots = b.fslots;
-  d.npairs = 1; d.P = g.P; d.N = q.n; d.K = q.k_int; d.nchunk = b.fslots; d.chunk_pts = round_up((int)((g.P + b.fslots - 1) / b.fslots), 16);
+  d.npairs = 1; d.P = g.P; d.N = q.n; d.K = kmain > 0 ? kmain : q.k_int; d.nchunk = b.fslots; d.chunk_pts = round_up((int)((g.P + b.fslots - 1) / b.fslots), 16);
   d.partial = f.partial; d.Npad = q.npad; d.ldk = q.ldw; d.colsum = f.colsum;
   d.split_f16 = q.n > 32 && q.k_int > 64 && d.sx[0] && d.sy[0];
   be_layer_dw_gemm(g, d, f, s);
 }
+
+// A 256-wide layer with a few more input columns (relight y-layer: + rgb; colour layer 0: + p, g): the cotangent of those columns and their
+// weight-gradient strip in one streaming pass over the layer's output cotangent (be_strip_bwd) instead of a narrow layer launch + a strip
+// launch; the main launches then cover the 256 x 256 part only.
+static bool strip_bwd_ok(const Lin& q, const LayerGemm& g, const DwGemm& d) {
+  static const bool off = getenv("CNR_NO_STRIP_BWD") != nullptr;   // debugging aid: narrow layer launch + strip launch as before
+  const int nt = q.k_int - 256;
+  return !off && q.n == 256 && nt >= 1 && nt <= 8 && q.ldw >= 256 + nt && g.A.kind == VK_DIRECT && (g.A.lda & 3) == 0 && g.A.scale == 1.0f &&
+         (g.E.kind == EK_RELU_MASK || g.E.kind == EK_SPLIT) && g.E.split == 256 && g.E.bias == nullptr &&
+         d.Y[0].kind == VK_DIRECT && d.Y[0].scale == 1.0f && d.npairs == 1;
+}
+// narrows g to its 256 main columns and returns the strip launch (to be issued after the main launches; finish with finish_strip_region)
+static StripBwd take_strips(const Lin& q, LayerGemm& g, const DwGemm& d, const DwRegion& r, const Bwd& b) {
+  StripBwd sb;
+  sb.dout = g.A.a; sb.ldo = g.A.lda; sb.P = g.P; sb.nt = q.k_int - 256; sb.Wt = q.Wt; sb.ldwt = q.ldwt;
+  sb.tail = g.E.o2 ? g.E.o2 + (g.E.kind == EK_SPLIT ? g.E.o2_off : 0) : nullptr; sb.ldt = g.E.ld2;
+  sb.tail_scale = g.E.kind == EK_SPLIT ? g.E.scale : 1.0f;
+  sb.y = d.Y[0].a + 256; sb.ldy = d.Y[0].lda;
+  sb.partial = r.part; sb.npad = q.npad; sb.ldk = q.ldw; sb.nslots = b.nchunk;
+  g.N = 256; g.E.n_out = 256; g.E.o2 = nullptr;
+  return sb;
+}
+static void strip_columns_of_last_finish(Bwd& b) { b.pending.back().col_hi = 256; b.pending.back().nchunk_hi = b.nchunk; }
 
 // backward of a narrow head (<= 4 outputs on a <= 256-wide ReLU layer) in one streaming launch: cotangent of the layer below + weight / bias gradient
 static bool head_bwd_ok(const Lin& q, const LayerGemm& g) {
@@ -845,16 +869,23 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       d.Y[0] = relight_input_view(m, i, x);
       if (head_bwd_ok(q, g)) { run_head_bwd(q, g, b, params, dP, s); continue; }
       const DwRegion r = take_region(q, b);
+      const bool strips = strip_bwd_ok(q, g, d);
+      StripBwd sb;
+      if (strips) sb = take_strips(q, g, d, r, b);
+      const int kmain = strips ? 256 : 0;
       if (fdw && fdw_shape_ok(g) && x.rsR[i] && q.npad == 256 && q.ldw <= 320) {
-        fused_into_region(q, g, d, x.rsR[i], 0, r, 0, b, true, s);
+        fused_into_region(q, g, d, x.rsR[i], 0, r, 0, b, true, s, kmain);
+        if (strips) be_strip_bwd(sb, s);
         finish_region(q, r, b.fslots, b.fslots, b, params, dP);
       } else {
         if (q.n > 32) g.rs_out = b.rsD;
         be_layer_gemm(g, s);
         d.sx[0] = g.rs_out;
-        dw_into_region(q, d, r, 0, b.nchunk, P, true, s);
+        dw_into_region(q, d, r, 0, b.nchunk, P, true, s, kmain);
+        if (strips) be_strip_bwd(sb, s);
         finish_region(q, r, b.nchunk, b.nchunk, b, params, dP);
       }
+      if (strips) strip_columns_of_last_finish(b);
     }
     {
       const Lin& q = m.rel[0];
@@ -894,16 +925,23 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     d.Y[0] = color_input_view(m, l, x);
     if (head_bwd_ok(q, g)) { run_head_bwd(q, g, b, params, dP, s); continue; }
     const DwRegion r = take_region(q, b);
+    const bool strips = strip_bwd_ok(q, g, d);
+    StripBwd sb;
+    if (strips) sb = take_strips(q, g, d, r, b);
+    const int kmain = strips ? 256 : 0;
     if (fdw && fdw_shape_ok(g) && x.rsC[l] && q.npad == 256 && q.ldw <= 320) {
-      fused_into_region(q, g, d, x.rsC[l], 0, r, 0, b, true, s);
+      fused_into_region(q, g, d, x.rsC[l], 0, r, 0, b, true, s, kmain);
+      if (strips) be_strip_bwd(sb, s);
       finish_region(q, r, b.fslots, b.fslots, b, params, dP);
     } else {
       if (q.n > 32) g.rs_out = b.rsD;
       be_layer_gemm(g, s);
       d.sx[0] = g.rs_out;
-      dw_into_region(q, d, r, 0, b.nchunk, P, true, s);
+      dw_into_region(q, d, r, 0, b.nchunk, P, true, s, kmain);
+      if (strips) be_strip_bwd(sb, s);
       finish_region(q, r, b.nchunk, b.nchunk, b, params, dP);
     }
+    if (strips) strip_columns_of_last_finish(b);
   }
   // ---- 4. total d g and the tangent of the embedding
   GbarFinish gb;
