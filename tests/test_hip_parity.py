@@ -502,3 +502,24 @@ def test_fused_layer_dw_matches_separate_launches(tmp_path):
         elif not np.array_equal(a, b, equal_nan=True):
             bad.append((k, "not bit-identical"))
     assert not bad, bad
+
+
+def test_streaming_strip_and_head_backward_match_gemm_launches(tmp_path):
+    """strip_bwd_kernel (the input columns beyond 256 of the relight y-layer and of colour layer 0) and head_bwd_kernel (the 3-wide heads) are
+    streaming restatements of what the narrow layer GEMM + weight-gradient strip launches computed (CNR_NO_STRIP_BWD=1 / CNR_NO_HEAD_BWD=1,
+    child processes): same fp32 products in another summation order, so every output and gradient agrees to round-off of its own scale."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("stream", {}), ("gemm", {"CNR_NO_STRIP_BWD": "1", "CNR_NO_HEAD_BWD": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _STREAM_CHILD, root, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = dict(np.load(path))
+    assert set(res["stream"]) == set(res["gemm"])
+    bad = []
+    for k in sorted(res["stream"]):
+        a, b = res["stream"][k].astype(np.float64), res["gemm"][k].astype(np.float64)
+        e = float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-300)
+        if not e < 5e-6:
+            bad.append((k, e))
+    assert not bad, bad
