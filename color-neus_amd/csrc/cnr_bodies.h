@@ -5,8 +5,8 @@
 
 namespace cnr {
 
-// one (ray, sample) element of EmbedZ
-CNR_HD void body_embed_z(const EmbedZ& p, long idx) {
+// one (ray, sample) element of EmbedZ; `out`: where the kEmb-wide row goes (the HIP kernels stage rows in LDS and store them coalesced)
+CNR_HD void body_embed_z_rows(const EmbedZ& p, long idx, float* out, float*) {
   long r = idx / p.m;
   int j = (int)(idx - r * p.m);
   float zz;
@@ -20,14 +20,12 @@ CNR_HD void body_embed_z(const EmbedZ& p, long idx) {
   }
   float x[3];
   for (int c = 0; c < 3; ++c) x[c] = (p.o[r * 3 + c] + p.d[r * 3 + c] * zz) * p.scale;
-  float row[kEmb];
-  for (int c = 0; c < kEmb; ++c) row[c] = 0.0f;
-  pe_row(x, p.multires, row);
-  float* out = p.E + idx * kEmb;
-  for (int c = 0; c < kEmb; ++c) out[c] = row[c];
+  for (int c = 0; c < kEmb; ++c) out[c] = 0.0f;
+  pe_row(x, p.multires, out);   // (straight into the destination row: a local array indexed by the runtime multires would live in scratch memory)
 }
+CNR_HD void body_embed_z(const EmbedZ& p, long idx) { body_embed_z_rows(p, idx, p.E + idx * kEmb, nullptr); }
 
-CNR_HD void body_embed_pts(const EmbedPts& p, long i) {
+CNR_HD void body_embed_pts_rows(const EmbedPts& p, long i, float* e, float* a) {
   float pp[3];
   if (p.pts) {
     pp[0] = p.pts[i * 3]; pp[1] = p.pts[i * 3 + 1]; pp[2] = p.pts[i * 3 + 2];
@@ -40,19 +38,16 @@ CNR_HD void body_embed_pts(const EmbedPts& p, long i) {
     pp[2] = linspace_at(p.bmin[2], p.bmax[2], p.res, iz);
   }
   float x[3] = {pp[0] * p.scale, pp[1] * p.scale, pp[2] * p.scale};
-  float row[kEmb];
-  for (int c = 0; c < kEmb; ++c) row[c] = 0.0f;
-  pe_row(x, p.multires, row);
-  float* e = p.E + i * kEmb;
-  for (int c = 0; c < kEmb; ++c) e[c] = row[c];
+  for (int c = 0; c < kEmb; ++c) e[c] = 0.0f;
+  pe_row(x, p.multires, e);
   if (p.AUX) {
-    float* a = p.AUX + i * kAux;
     for (int c = 0; c < kAux; ++c) a[c] = 0.0f;
     a[0] = pp[0]; a[1] = pp[1]; a[2] = pp[2];
   }
 }
+CNR_HD void body_embed_pts(const EmbedPts& p, long i) { body_embed_pts_rows(p, i, p.E + i * kEmb, p.AUX ? p.AUX + i * kAux : nullptr); }
 
-CNR_HD void body_fine_setup(const FineSetup& p, long pt) {
+CNR_HD void body_fine_setup_rows(const FineSetup& p, long pt, float* e, float* a) {
   long r = pt / p.M;
   int j = (int)(pt - r * p.M);
   float z0 = p.z[r * p.M + j];
@@ -64,19 +59,14 @@ CNR_HD void body_fine_setup(const FineSetup& p, long pt) {
     pp[c] = p.o[r * 3 + c] + dd[c] * mid;
     x[c] = pp[c] * p.scale;
   }
-  float row[kEmb];
-  for (int c = 0; c < kEmb; ++c) row[c] = 0.0f;
-  pe_row(x, p.multires, row);
-  float* e = p.E + pt * kEmb;
-  for (int c = 0; c < kEmb; ++c) e[c] = row[c];
-  float aux[kAux];
-  for (int c = 0; c < kAux; ++c) aux[c] = 0.0f;
-  aux[0] = pp[0]; aux[1] = pp[1]; aux[2] = pp[2];
-  if (p.multires_view > 0) pe_row(dd, p.multires_view, aux + 6);
-  else { aux[6] = dd[0]; aux[7] = dd[1]; aux[8] = dd[2]; }
-  float* a = p.AUX + pt * kAux;
-  for (int c = 0; c < kAux; ++c) a[c] = aux[c];
+  for (int c = 0; c < kEmb; ++c) e[c] = 0.0f;
+  pe_row(x, p.multires, e);
+  for (int c = 0; c < kAux; ++c) a[c] = 0.0f;
+  a[0] = pp[0]; a[1] = pp[1]; a[2] = pp[2];
+  if (p.multires_view > 0) pe_row(dd, p.multires_view, a + 6);
+  else { a[6] = dd[0]; a[7] = dd[1]; a[8] = dd[2]; }
 }
+CNR_HD void body_fine_setup(const FineSetup& p, long pt) { body_fine_setup_rows(p, pt, p.E + pt * kEmb, p.AUX + pt * kAux); }
 
 // g = scale * J^T ce with J = d PE / d x0; E holds sin/cos of the encoding
 CNR_HD void body_grad_finish(const GradFinish& p, long pt) {

@@ -19,9 +19,10 @@ CNR_HD void pe_row(const float x[3], int multires, float* out /* 3 + 6*multires 
   float f = 1.0f;
   for (int k = 0; k < multires; ++k) {
     for (int c = 0; c < 3; ++c) {
-      float a = x[c] * f;
-      out[3 + 6 * k + c] = sinf(a);
-      out[6 + 6 * k + c] = cosf(a);
+      float a = x[c] * f, sn, cs;
+      sincosf(a, &sn, &cs);   // (one argument reduction for the pair)
+      out[3 + 6 * k + c] = sn;
+      out[6 + 6 * k + c] = cs;
     }
     f *= 2.0f;
   }
