@@ -212,6 +212,7 @@ struct StripBwd {
 };
 void be_strip_bwd(const StripBwd& p, cnr_stream s);
 bool be_fdw_enabled();
+bool be_fdw_xrow();          // DwFuse::xrow_mode / LayerGemm::k_extra are available in be_layer_dw_gemm
 void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s);
 void be_prep_weight(const PrepWeight& p, cnr_stream s);
 // fp32 matrix [rows][ld] -> two f16 planes of the row-scaled matrix (x * 2^e = hi + lo, 22 significand bits) + 1/2^e per row,

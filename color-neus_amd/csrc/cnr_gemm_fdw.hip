@@ -73,7 +73,9 @@ __device__ __forceinline__ float fd_sel4(const f4& v, int j) {   // v[j] for a p
 // DP: the P waves keep the epilogue side inputs of TWO tiles in flight (tile i + 2 is requested while tile i is finished);
 // DD: the D waves keep two input tiles in flight (tile i + 3 is requested when tile i + 1 has been converted).
 // NKB: k16 blocks of the layer product (16; 14 for the 217-wide SDF layer in front of the skip connection, whose pad columns are zero)
-template <int EK, bool DP, bool DD, int NKB = 16>
+// XR: DwFuse::xrow_mode (0 none; 1 column sums of the o2 output of an EK_SWEEP launch; 2 EK_VBACK launch with k_extra: rank-one update of the
+// product by A column 256 and the row of that column's products with Ep) -- the sdf row of the 257-wide top SDF layer, see cnr_plan.cpp
+template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0>
 __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, const DwFuse f, int tiles_per_range, int dbg) {
   LayerGemm g = g_in;
   g.A.kind = VK_DIRECT; g.E.kind = EK; g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30;
@@ -108,6 +110,12 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     float* T = reinterpret_cast<float*>(smem + FD_OFF_T + wave * FD_TBYTES);
     const int jrot = (lane & 7) >> 1;                    // rotation of the 2-byte Ep' stores over a lane's 4 columns (LDS banks)
     int G = FD_GBIG;
+    f4 wr1 = {0.f, 0.f, 0.f, 0.f}, xacc = {0.f, 0.f, 0.f, 0.f};   // XR: column 256 of this lane's 4 weight rows; the extra row's sums
+    float xb = 0.0f;
+    if constexpr (XR == 2) {
+      wr1.x = g.W[(long)(ecol + 0) * g.ldw + 256]; wr1.y = g.W[(long)(ecol + 1) * g.ldw + 256];
+      wr1.z = g.W[(long)(ecol + 2) * g.ldw + 256]; wr1.w = g.W[(long)(ecol + 3) * g.ldw + 256];
+    }
     // one tile: product, epilogue, Ep' tile; `ern` holds this tile's side inputs and receives those of tile i + ahead (clamped to the range)
     auto p_tile = [&](const int i, const int ab, EpiRaw4 (&ern)[4], const int ahead) {
       const long t = t0 + i;
@@ -116,6 +124,11 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         const int* qi = info + ab * 4;
         int m = qi[0]; m = qi[1] < m ? qi[1] : m; m = qi[2] < m ? qi[2] : m; m = qi[3] < m ? qi[3] : m;
         if (m < FD_GBIG && m + 1 < G) G = m + 1;
+      }
+      float zq[4] = {0.f, 0.f, 0.f, 0.f};                // XR == 2: A[row][256] of this lane's 4 rows (requested before the product, used after it)
+      if constexpr (XR == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zq[q] = g.A.a[(t * FD_TP + (lane >> 3) + 8 * q) * g.A.lda + 256];
       }
       f32x16 acc;
 #pragma unroll
@@ -148,6 +161,16 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         f4 v = *reinterpret_cast<const f4*>(T + rr * FD_TLD + cc);
         v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
         f4 ep = fd_ep4<EK>(g.E, ern[q]);
+        if constexpr (XR == 2) {
+          const float zs = zq[q];
+          v.x = fmaf(zs, wr1.x, v.x); v.y = fmaf(zs, wr1.y, v.y); v.z = fmaf(zs, wr1.z, v.z); v.w = fmaf(zs, wr1.w, v.w);
+          xacc.x = fmaf(zs, ep.x, xacc.x); xacc.y = fmaf(zs, ep.y, xacc.y); xacc.z = fmaf(zs, ep.z, xacc.z); xacc.w = fmaf(zs, ep.w, xacc.w);
+          xb += zs;
+        }
+        if constexpr (XR == 1) {   // the o2 values of the sweep epilogue (same expression as in epi_finish4_plain)
+          xacc.x += softplus100_d1(ern[q].a.x) * v.x; xacc.y += softplus100_d1(ern[q].a.y) * v.y;
+          xacc.z += softplus100_d1(ern[q].a.z) * v.z; xacc.w += softplus100_d1(ern[q].a.w) * v.w;
+        }
         epi_finish4_plain<EK>(g.E, row, ecol, v, bias4, ern[q]);
         ern[q] = epi_fetch4_plain<EK>(g.E, tn * FD_TP + rr, ecol);
         const float ys = fd_yscale(ssr[rr], G);
@@ -193,6 +216,22 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
           cnr_lds_barrier();
         }
       }
+    }
+    if constexpr (XR != 0) {
+      // the extra row of this (range, half): fold the 8 row lanes (lane >> 3) in a fixed order; lanes 0..7 then hold this wave's 32 columns
+#pragma unroll
+      for (int d = 8; d <= 32; d <<= 1) {
+        xacc.x += __shfl_xor(xacc.x, d); xacc.y += __shfl_xor(xacc.y, d); xacc.z += __shfl_xor(xacc.z, d); xacc.w += __shfl_xor(xacc.w, d);
+        xb += __shfl_xor(xb, d);
+      }
+      if (lane < 8) {
+        float* xr = f.xrow + (long)range * f.xrow_stride + ecol;
+        f4 o;
+        o.x = xacc.x * f.xrow_scale; o.y = xacc.y * f.xrow_scale; o.z = xacc.z * f.xrow_scale; o.w = xacc.w * f.xrow_scale;
+        if constexpr (XR == 2) { const f4 old = *reinterpret_cast<const f4*>(xr); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *reinterpret_cast<f4*>(xr) = o;
+      }
+      if (XR == 2 && f.xbias != nullptr && half == 0 && wave == 0 && lane == 0) f.xbias[(long)range * f.xbias_stride] = xb;   // (every column lane of the wave saw the same rows)
     }
   } else {
     // ================================================================ D waves
@@ -414,16 +453,16 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
   }
 }
 
-template <int EK, bool DP, bool DD, int NKB = 16>
+template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0>
 static void launch_fdw_v(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
   static DeviceOnce attr_once;
   if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD, NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD, NKB, XR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = g.P / FD_TP;
   const int tpr = (int)((ntiles + f.nslots - 1) / f.nslots);
   TimingScope ts_("layer_dw", 0, 200 + EK, g.P, 256, g.K, 2, s, fdw_bytes(g, f));   // pairs = 2: the layer product + the weight-gradient product
   static const int dbg = getenv("CNR_FDW_DBG") ? atoi(getenv("CNR_FDW_DBG")) : 0;   // ablation switches (timing experiments only: results are wrong)
-  hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD, NKB>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
+  hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD, NKB, XR>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
 }
 template <int EK>
 static void launch_fdw(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
@@ -440,17 +479,28 @@ bool be_fdw_enabled() {
   static const bool off = getenv("CNR_NO_FDW") != nullptr;   // debugging aid: separate layer and weight-gradient launches everywhere
   return !off;
 }
+bool be_fdw_xrow() {   // the fused launches can carry DwFuse::xrow_mode (not when their slots are filled by the separate kernels)
+  static const bool split_env = getenv("CNR_FDW_SPLIT") != nullptr;
+  return be_fdw_enabled() && !split_env;
+}
 
 void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s) {
   static const bool split_env = getenv("CNR_FDW_SPLIT") != nullptr;   // debugging aid: the same slots filled by the two separate kernels
   const bool slots_ok = f.se != nullptr && f.nslots >= 8 && (f.nslots & 7) == 0 && f.nslots <= kFdwSlots;
-  if (split_env || !slots_ok || !fdw_shape_ok(g) || f.Npad < 224 || f.Npad > 256 || f.ldk < 256 || f.ldk > 320) {
+  if (split_env || !slots_ok || !fdw_shape_ok(g) || f.Npad < 224 || f.Npad > 288 || f.ldk < 256 || f.ldk > 320) {
+    if (f.xrow_mode != 0 || g.k_extra != 0) { if (g_first_error == hipSuccess) { g_first_error = hipErrorInvalidValue; g_first_error_where = "layer_dw: the extra-row form needs the fused launch (callers test be_fdw_xrow() and the shape)"; } return; }
     be_dw_gemm(d, s);
     be_layer_gemm(g, s);
     return;
   }
+  if ((f.xrow_mode != 0 || g.k_extra != 0) && !((f.xrow_mode == 2 && g.E.kind == EK_VBACK && g.k_extra == 1 && g.K == 256) || (f.xrow_mode == 1 && g.E.kind == EK_SWEEP && g.k_extra == 0 && g.K > 240))) {
+    if (g_first_error == hipSuccess) { g_first_error = hipErrorInvalidValue; g_first_error_where = "layer_dw: unsupported extra-row request"; }
+    return;
+  }
   // the fused launch covers output columns [0, 256) and the 256 x 256 main tile of the weight gradient
-  if (g.K <= 224) launch_fdw_v<EK_VBACK, false, false, 14>(g, f, s);
+  if (f.xrow_mode == 2 && g.E.kind == EK_VBACK && g.k_extra == 1 && g.K == 256) launch_fdw_v<EK_VBACK, false, false, 16, 2>(g, f, s);
+  else if (f.xrow_mode == 1 && g.E.kind == EK_SWEEP && g.K > 240) launch_fdw_v<EK_SWEEP, false, false, 16, 1>(g, f, s);
+  else if (g.K <= 224) launch_fdw_v<EK_VBACK, false, false, 14>(g, f, s);
   else switch (g.E.kind) {
     case EK_RELU_MASK: launch_fdw<EK_RELU_MASK>(g, f, s); break;
     case EK_VBACK: launch_fdw<EK_VBACK>(g, f, s); break;

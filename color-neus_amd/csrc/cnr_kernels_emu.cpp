@@ -54,6 +54,7 @@ void be_copy_cols(float* dst, int ld_dst, const float* src, int ld_src, int ncol
 void be_layer_gemm(const LayerGemm& g0, cnr_stream) {
   LayerGemm g = g0;
   if (g.P_dev) g.P = *g.P_dev;
+  g.K += g.k_extra;   // (the rank-one form is a speed matter of the fused HIP launch)
   const int kp = round_up(g.K, 4);
   std::vector<float> arow(kp + 4);
 #pragma omp parallel for firstprivate(arow)
@@ -166,9 +167,29 @@ void be_strip_bwd(const StripBwd& p, cnr_stream) {
   }
 }
 bool be_fdw_enabled() { return getenv("CNR_NO_FDW") == nullptr; }
-void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse&, cnr_stream s) {
+bool be_fdw_xrow() { return be_fdw_enabled(); }
+void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s) {
+  // xrow_mode 2: the plain weight-gradient GEMM below forms the extra row itself (d.N covers it) but zero-fills the slots first: keep what
+  // the mode-1 launch left there and add it back
+  std::vector<float> keep;
+  if (f.xrow_mode == 2) {
+    keep.resize((size_t)f.nslots * 256);
+    for (int c = 0; c < f.nslots; ++c) memcpy(&keep[(size_t)c * 256], f.xrow + (long)c * f.xrow_stride, 256 * sizeof(float));
+  }
   be_dw_gemm(d, s);      // (first: EK_VBACK updates o1 in place, but neither dW operand is an output of this launch, so the order is free)
   be_layer_gemm(g, s);
+  if (f.xrow_mode == 2)
+    for (int c = 0; c < f.nslots; ++c)
+      for (int k = 0; k < 256; ++k) f.xrow[(long)c * f.xrow_stride + k] += keep[(size_t)c * 256 + k];
+  if (f.xrow_mode == 1)   // column sums of the o2 output over the point slices of d
+    for (int c = 0; c < f.nslots; ++c) {
+      const long p0 = c * d.chunk_pts, p1 = std::min(d.P, p0 + d.chunk_pts);
+      for (int k = 0; k < 256; ++k) {
+        float sum = 0.0f;
+        for (long pt = p0; pt < p1; ++pt) sum += g.E.o2[pt * g.E.ld2 + k];
+        f.xrow[(long)c * f.xrow_stride + k] = sum * f.xrow_scale;
+      }
+    }
 }
 
 static int seg_src_of(const Segment* seg, int nseg, int j) {

@@ -736,9 +736,10 @@ static void dw_into_region(const Lin& q, DwGemm& g, const DwRegion& r, int slot0
 // layer launch + its weight-gradient pair (d.X[0] / d.Y[0]: the pair as a plain weight-gradient GEMM -- what the CPU emulation and the HIP
 // backend's unfused fallback run; se = row scales of the epilogue-side operand) into slots [slot0, slot0 + b.fslots) of a region
 static void fused_into_region(const Lin& q, const LayerGemm& g, DwGemm& d, const float* se, int transposed, const DwRegion& r, int slot0, Bwd& b,
-                              bool with_bias, cnr_stream s, int kmain = 0) {
+                              bool with_bias, cnr_stream s, int kmain = 0, const DwFuse* xrow = nullptr) {
   with_bias = with_bias && slot0 == 0 && !transposed;
   DwFuse f;
+  if (xrow) f = *xrow;   // (the extra-row request; everything else is set below)
   f.se = se; f.partial = r.part + (size_t)slot0 * q.npad * q.ldw; f.Npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? r.csum : nullptr;
   f.transposed = transposed; f.nslots = b.fslots;
   d.npairs = 1; d.P = g.P; d.N = q.n; d.K = kmain > 0 ? kmain : q.k_int; d.nchunk = b.fslots; d.chunk_pts = round_up((int)((g.P + b.fslots - 1) / b.fslots), 16);
@@ -1012,11 +1013,27 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     if (fdw && sq && l >= 1 && l < m.L && x.rsY[l] && ok(vback_gemm(l))) fuse_v[l] = 1;
     if (fdw && sq && l < m.L && x.rsX1[l] && ok(sweep_gemm(l))) fuse_g[l] = 1;
   }
+  // The top layer (F features + the sdf row, F == 256 = its input width) without launches of its own: its value-backward launch takes the
+  // sdf column of the cotangent as a rank-one update of the 256-wide product (k_extra) and forms the main 256 x 256 weight gradient like any
+  // other layer; the sdf ROW of the weight gradient is made of values two launches hold anyway -- the gradient-chain pair's unit vector
+  // makes it inv_scale * column sums of VB[L-1], the o2 output of the sweep launch of layer L-1 (xrow_mode 1), and the value pair adds
+  // sum zbar_sdf[pt] * softplus(z_{L-1})[pt][:], whose factors the value-backward launch has in its epilogue (xrow_mode 2).
+  const Lin& qtop = m.sdf[m.L];
+  LayerGemm gtop = vback_gemm(m.L);
+  gtop.K = 256; gtop.k_extra = 1;
+  static const bool no_top = getenv("CNR_NO_TOP_FUSE") != nullptr;   // debugging aid: the top layer as three launches of its own
+  const bool top_fused = !no_top && fdw && be_fdw_xrow() && m.L >= 2 && fuse_g[m.L - 1] && m.F == 256 && qtop.n == 257 && qtop.k_int == 256 &&
+                         qtop.ldw == 256 && qtop.npad <= 288 && x.ldztop >= 260 && x.rsY[m.L] && !m.skip(m.L) && fdw_shape_ok(gtop);
+  if (top_fused) fuse_v[m.L] = 1;
+  DwFuse xrow1, xrow2;
+  xrow1.xrow_mode = 1; xrow1.xrow = sreg[m.L].part + (size_t)256 * qtop.ldw; xrow1.xrow_stride = (long)qtop.npad * qtop.ldw; xrow1.xrow_scale = inv_scale;
+  xrow2 = xrow1;
+  xrow2.xrow_mode = 2; xrow2.xrow_scale = 1.0f; xrow2.xbias = sreg[m.L].csum + 256; xrow2.xbias_stride = qtop.npad;
   // slot groups of a region: the value pair first (it carries the bias column sums), the gradient-chain pair behind it; a pair takes
   // fslots slots when it is fused and nchunk slots as a separate GEMM (one workgroup per slot: fewer would leave CUs idle); when neither is
   // fused one launch over nchunk slots forms both
   auto value_slots = [&](int l) { return fuse_v[l] ? b.fslots : b.nchunk; };
-  auto grad_slots = [&](int l) { return fuse_g[l] ? b.fslots : (fuse_v[l] ? b.nchunk : 0); };
+  auto grad_slots = [&](int l) { return (l == m.L && top_fused) ? 0 : fuse_g[l] ? b.fslots : (fuse_v[l] ? b.nchunk : 0); };
   for (int l = 0; l < m.L; ++l) {
     const Lin& q = m.sdf[l];
     LayerGemm g = sweep_gemm(l);
@@ -1025,7 +1042,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       d.npairs = 1; d.P = P;
       grad_pair(l, d, 0);
       d.sy[0] = nullptr;   // (a fused launch does not need qbar_l's row scales; the unfused fallback then takes the split-bf16 tiles)
-      fused_into_region(q, g, d, x.rsX1[l], 1, sreg[l], value_slots(l), b, false, s);
+      fused_into_region(q, g, d, x.rsX1[l], 1, sreg[l], value_slots(l), b, false, s, 0, (top_fused && l == m.L - 1) ? &xrow1 : nullptr);
     } else {
       g.rs_out = b.rsY1[l];
       be_layer_gemm(g, s);
@@ -1034,13 +1051,14 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   // ---- 6. value-path backward through the SDF net (in place: Z2[l] becomes the total cotangent of z_l)
   for (int l = m.L; l >= 1; --l) {
     const Lin& q = m.sdf[l];
-    LayerGemm g = vback_gemm(l);
+    const bool top = l == m.L && top_fused;
+    LayerGemm g = top ? gtop : vback_gemm(l);
     if (fuse_v[l]) {
       DwGemm d;
       d.npairs = 1; d.P = P;
       value_pair(l, d);
       d.sx[0] = nullptr;
-      fused_into_region(q, g, d, x.rsY[l], 0, sreg[l], 0, b, true, s);
+      fused_into_region(q, g, d, x.rsY[l], 0, sreg[l], 0, b, true, s, 0, top ? &xrow2 : nullptr);
     } else {
       g.rs_out = b.rsX0[l];
       be_layer_gemm(g, s);
@@ -1069,7 +1087,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       d.npairs = 1; d.P = P;
       value_pair(l, d);
       dw_into_region(q, d, r, 0, value_slots(l), P, true, s);
-    } else if (!fuse_g[l]) {                 // the gradient-chain pair alone, behind the fused value pair
+    } else if (!fuse_g[l] && !(l == m.L && top_fused)) {   // the gradient-chain pair alone, behind the fused value pair
       DwGemm d;
       d.npairs = 1; d.P = P;
       grad_pair(l, d, 0);

@@ -359,6 +359,8 @@ struct LayerGemm {
   const unsigned short* Wp = nullptr;   // optional: W as two f16 planes (hi, lo) of the row-scaled weights, same [rows][ldw] layout each
   long wp_stride = 0;                   // elements between planes
   int w_rows = 0;                       // rows of W / Wp that exist (zero rows beyond N); 0: round_up(N, 32)
+  int k_extra = 0;                      // 1: the contraction has one more index K (A column K, W column K): a launch may take it as a rank-one update
+                                        // of the product in its epilogue (fused layer + weight-gradient launch of the 257-wide top SDF layer); others add it to K
   const float* wscale = nullptr;        // per W row: 1 / (power-of-two scale applied before the f16 split)
   const int* P_dev = nullptr; // optional device-side row count (<= P): compacted point lists whose length only the GPU knows
   // optional row dot product formed while the input tile is staged (the 16 threads that stage a row hold all of it): the ONE extra output
@@ -434,6 +436,13 @@ struct DwFuse {
   float* colsum = nullptr;    // optional [nslots][Npad]: column sums of S (bias gradient); only with transposed == 0
   int transposed = 0;         // 0: dW[n = column of S][k = column of Ep] ; 1: dW[n = column of Ep][k = column of S]
   int nslots = 0;             // point ranges = partial-sum slots of this launch: a multiple of 8, <= kFdwSlots
+  // One extra weight-gradient row formed from values the epilogue holds anyway: the sdf row (internal row 256) of the 257-wide top SDF layer.
+  //   xrow_mode 1 (EK_SWEEP launch of the layer below):   xrow[range][c]  = xrow_scale * sum over the range's points of o2[pt][c]
+  //   xrow_mode 2 (EK_VBACK launch with k_extra == 1):    xrow[range][c] += sum of A[pt][K] * Ep[pt][c];  xbias[range] = sum of A[pt][K]
+  // (mode 1 runs first and writes every slot row in full; mode 2 adds to it).  xrow + range * xrow_stride, 256 floats; xbias + range * xbias_stride.
+  int xrow_mode = 0;
+  float* xrow = nullptr; long xrow_stride = 0; float xrow_scale = 1.0f;
+  float* xbias = nullptr; long xbias_stride = 0;
 };
 
 // structural conditions of the fused kernel: a plain 256 -> 256 launch on full 32-point tiles whose epilogue takes the 16-byte path everywhere

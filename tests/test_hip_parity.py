@@ -482,8 +482,10 @@ def test_stream_form_of_the_layer_kernel_is_bit_identical(tmp_path):
 
 def test_fused_layer_dw_matches_separate_launches(tmp_path):
     """layer_dw_kernel (cnr_gemm_fdw.hip: a backward layer launch that also forms the weight gradient of its layer on chip) against the
-    separate layer + weight-gradient launches (CNR_NO_FDW=1, child processes): outputs and input gradients are the same arithmetic and must
-    agree to the bit; weight gradients differ only in the summation order over points and the power-of-two exponent of the split."""
+    separate layer + weight-gradient launches (CNR_NO_FDW=1, child processes): outputs are the same arithmetic and must agree to the bit;
+    weight gradients differ only in the summation order over points and the power-of-two exponent of the split, and the ray gradients only
+    through the top SDF layer, whose fused value-backward launch takes the sdf column of the cotangent as an fp32 rank-one update instead of a
+    257th contraction index of the split-f16 product (round-off of one term)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for tag, extra in (("fused", {}), ("separate", {"CNR_NO_FDW": "1"})):
@@ -495,7 +497,7 @@ def test_fused_layer_dw_matches_separate_launches(tmp_path):
     bad = []
     for k in sorted(res["fused"]):
         a, b = res["fused"][k].astype(np.float64), res["separate"][k].astype(np.float64)
-        if k.startswith("g:"):
+        if k.startswith("g:") or k in ("d_o", "d_d"):
             e = float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-300)
             if not e < 5e-6:
                 bad.append((k, e))
