@@ -75,10 +75,12 @@ __device__ __forceinline__ float fd_sel4(const f4& v, int j) {   // v[j] for a p
 // NKB: k16 blocks of the layer product (16; 14 for the 217-wide SDF layer in front of the skip connection, whose pad columns are zero)
 // XR: DwFuse::xrow_mode (0 none; 1 column sums of the o2 output of an EK_SWEEP launch; 2 EK_VBACK launch with k_extra: rank-one update of the
 // product by A column 256 and the row of that column's products with Ep) -- the sdf row of the 257-wide top SDF layer, see cnr_plan.cpp
-template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0>
+// TAILF: the epilogue keeps its tail fill (sweep launch of the layer below a skip connection) and runs the general 16-byte epilogue code
+template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0, bool TAILF = false>
 __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, const DwFuse f, int tiles_per_range, int dbg) {
   LayerGemm g = g_in;
-  g.A.kind = VK_DIRECT; g.E.kind = EK; g.E.tail_src = nullptr; g.E.tail_n = 0; g.E.split = 1 << 30;
+  g.A.kind = VK_DIRECT; g.E.kind = EK; g.E.split = 1 << 30;
+  if (!TAILF) { g.E.tail_src = nullptr; g.E.tail_n = 0; }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // blocks b and b + 8 (same XCD under the observed round-robin placement: a speed matter only) are the two column halves of one range
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
           xacc.x += softplus100_d1(ern[q].a.x) * v.x; xacc.y += softplus100_d1(ern[q].a.y) * v.y;
           xacc.z += softplus100_d1(ern[q].a.z) * v.z; xacc.w += softplus100_d1(ern[q].a.w) * v.w;
         }
-        epi_finish4_plain<EK>(g.E, row, ecol, v, bias4, ern[q]);
-        ern[q] = epi_fetch4_plain<EK>(g.E, tn * FD_TP + rr, ecol);
+        epi_finish4_sel<EK, TAILF>(g.E, row, ecol, v, bias4, ern[q]);
+        ern[q] = epi_fetch4_sel<EK, TAILF>(g.E, tn * FD_TP + rr, ecol);
         const float ys = fd_yscale(ssr[rr], G);
         ep.x *= ys; ep.y *= ys; ep.z *= ys; ep.w *= ys;
         unsigned char* yrow = Yb + (wave * 32 + cc) * FD_YLD + rr * 2;
@@ -194,8 +196,8 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     EpiRaw4 ernA[4], ernB[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      ernA[q] = epi_fetch4_plain<EK>(g.E, t0 * FD_TP + (lane >> 3) + 8 * q, ecol);   // (a range past the end is clamped to tile 0 of the launch: loaded, never used)
-      if (DP) ernB[q] = epi_fetch4_plain<EK>(g.E, (t0 + (1 < nlast ? 1 : nlast)) * FD_TP + (lane >> 3) + 8 * q, ecol);
+      ernA[q] = epi_fetch4_sel<EK, TAILF>(g.E, t0 * FD_TP + (lane >> 3) + 8 * q, ecol);   // (a range past the end is clamped to tile 0 of the launch: loaded, never used)
+      if (DP) ernB[q] = epi_fetch4_sel<EK, TAILF>(g.E, (t0 + (1 < nlast ? 1 : nlast)) * FD_TP + (lane >> 3) + 8 * q, ecol);
     }
     cnr_lds_barrier();   // tile 0 staged
     int ab = 0;
@@ -453,16 +455,16 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
   }
 }
 
-template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0>
+template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0, bool TAILF = false>
 static void launch_fdw_v(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
   static DeviceOnce attr_once;
   if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD, NKB, XR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD, NKB, XR, TAILF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = g.P / FD_TP;
   const int tpr = (int)((ntiles + f.nslots - 1) / f.nslots);
   TimingScope ts_("layer_dw", 0, 200 + EK, g.P, 256, g.K, 2, s, fdw_bytes(g, f));   // pairs = 2: the layer product + the weight-gradient product
   static const int dbg = getenv("CNR_FDW_DBG") ? atoi(getenv("CNR_FDW_DBG")) : 0;   // ablation switches (timing experiments only: results are wrong)
-  hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD, NKB, XR>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
+  hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD, NKB, XR, TAILF>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
 }
 template <int EK>
 static void launch_fdw(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
@@ -500,6 +502,7 @@ void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_
   // the fused launch covers output columns [0, 256) and the 256 x 256 main tile of the weight gradient
   if (f.xrow_mode == 2 && g.E.kind == EK_VBACK && g.k_extra == 1 && g.K == 256) launch_fdw_v<EK_VBACK, false, false, 16, 2>(g, f, s);
   else if (f.xrow_mode == 1 && g.E.kind == EK_SWEEP && g.K > 240) launch_fdw_v<EK_SWEEP, false, false, 16, 1>(g, f, s);
+  else if (g.E.kind == EK_SWEEP && g.E.tail_src != nullptr) launch_fdw_v<EK_SWEEP, false, false, 16, 0, true>(g, f, s);
   else if (g.K <= 224) launch_fdw_v<EK_VBACK, false, false, 14>(g, f, s);
   else switch (g.E.kind) {
     case EK_RELU_MASK: launch_fdw<EK_RELU_MASK>(g, f, s); break;

@@ -455,7 +455,11 @@ inline bool fdw_shape_ok(const LayerGemm& g) {
   if (!(g.K > 240 && g.K <= 256) && !(e.kind == EK_VBACK && g.K > 208 && g.K <= 224 && g.ldw >= 224)) return false;
   // the first 256 output columns are plain (no tail fill, no split point below 256); further columns (N > 256, EK_RELU_MASK only: the
   // relight y-layer) go to the narrow launch that follows
-  if (e.tail_src != nullptr || e.n_out < 256 || e.split < 256 || g.N < 256) return false;
+  // ... or, for the sweep launch of the layer below a skip connection, n_out live columns + the tail fill up to column 256 (zero weight rows
+  // under the tail columns: w_rows >= 256); that launch runs the general 16-byte epilogue code
+  const bool tail_form = e.kind == EK_SWEEP && e.tail_src != nullptr && e.n_out + e.tail_n == 256 && e.n_out >= 192 && g.w_rows >= 256 &&
+                         g.N == e.n_out && e.split == (1 << 30) && e.ldv != 0;
+  if (!tail_form && (e.tail_src != nullptr || e.n_out < 256 || e.split < 256 || g.N < 256)) return false;
   if (g.N > 256 && e.kind != EK_RELU_MASK) return false;
   switch (e.kind) {
     case EK_RELU_MASK: return ((e.ld1 | e.ldaux) & 3) == 0 && e.aux != nullptr;
