@@ -71,7 +71,8 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
     part.N = w;   // (only used for the timing record; the kernel takes its extents from K, P and the epilogue)
     const bool k_ok = g.K <= 256 || (g.K <= 272 && ws_k17_supported(g));
     part.rs_out = c0 == 0 ? g.rs_out : nullptr;   // one launch per operand writes the row scales
-    const bool use_ws = !ws_off && ((ws_kinds >> g.E.kind) & 1) && g.Wp != nullptr && g.wscale != nullptr && w >= 96 && k_ok && (g.A.lda & 3) == 0;
+    static const int ws_minw = getenv("CNR_WS_MINW") ? atoi(getenv("CNR_WS_MINW")) : 96;   // tuning knob: narrower launches take the FP32-MFMA kernel
+    const bool use_ws = !ws_off && ((ws_kinds >> g.E.kind) & 1) && g.Wp != nullptr && g.wscale != nullptr && w >= ws_minw && k_ok && (g.A.lda & 3) == 0;
     // the row dot is formed by the weight-stationary kernels while they stage the rows (K <= 256, first column range); otherwise by a
     // one-column launch of its own
     const bool dot_native = use_ws && c0 == 0 && g.K <= 256 && g.E.kind == EK_SDF_TOP;
