@@ -198,6 +198,15 @@ struct HeadBwd {
   float* partial; float* colsum; int npad, ldk, nslots;   // [nslots][npad][ldk], [nslots][npad]
 };
 void be_head_bwd(const HeadBwd& p, cnr_stream s);
+// Forward pass of a narrow head (<= 4 outputs) on a 256-wide activation: y[pt][j] = sum_c h[pt][c] * W[j][c], through the head's epilogue E
+// (epi_apply, columns 0..15: bias, sigmoid / relight, pad-column handling).  One streaming pass; a launch of the FP32-MFMA layer kernel
+// spends a 32-column tile on the 3 columns.
+struct HeadFwd {
+  const float* h; int ldh; long P; const int* P_dev;   // [P][ldh], 256 live columns (ldh % 4 == 0); P_dev: optional device-side row count
+  const float* W; int ldw; int n;                       // [n][ldw] effective weights
+  Epi E;
+};
+void be_head_fwd(const HeadFwd& p, cnr_stream s);
 // The few input columns beyond 256 of a 256-wide layer (relight y-layer: + rgb, colour layer 0: + p, g) in the backward pass, one streaming
 // pass over the layer's output cotangent instead of a narrow layer launch plus a weight-gradient strip launch:
 //   tail[pt][j]                    = tail_scale * sum_n dout[pt][n] * Wt[256 + j][n]          (cotangent of input column 256 + j)

@@ -247,6 +247,58 @@ __global__ __launch_bounds__(512) void strip_bwd_kernel(const StripBwd p, long p
     if (n < p.npad) out[(long)n * p.ldk + 256 + j] = sum;
   }
 }
+// forward of a narrow head (see HeadFwd): a wave owns 16 points at a time (lane = 4-column group), the 16 x 4 partial dot products of a lane
+// are summed over the 64 lanes by the halving exchange of strip_bwd_kernel; lane L then applies the head's epilogue to point L / 4, column L % 4
+// (and to the pad columns 4.., which epi_apply zero-fills where the epilogue kind asks for it).
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwd p) {
+  const int lane = threadIdx.x & 63, k = lane * 4;
+  const long P = p.P_dev ? (long)*p.P_dev : p.P;
+  const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f4 w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = j < p.n ? *reinterpret_cast<const f4*>(p.W + (long)j * p.ldw + k) : z4;
+  const long wave_id = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (long)gridDim.x * 4;
+  for (long pt = wave_id * 16; pt < P; pt += nwaves * 16) {
+    f4 d[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const long q = pt + u < P ? pt + u : P - 1;
+      d[u] = *reinterpret_cast<const f4*>(p.h + q * p.ldh + k);
+    }
+    float v[64];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[u * 4 + j] = fmaf(d[u].w, w[j].w, fmaf(d[u].z, w[j].z, fmaf(d[u].y, w[j].y, d[u].x * w[j].x)));
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) {
+      const bool up = (lane & mk) != 0;
+#pragma unroll
+      for (int i = 0; i < mk; ++i) {
+        const float keep = up ? v[i + mk] : v[i];
+        const float send = up ? v[i] : v[i + mk];
+        v[i] = keep + __shfl_xor(send, mk);
+      }
+    }
+    const long row = pt + (lane >> 2);
+    if (row < P) {
+      const int j = lane & 3;
+      epi_apply(p.E, row, j, v[0]);
+      epi_apply(p.E, row, j + 4, 0.0f);
+      epi_apply(p.E, row, j + 8, 0.0f);
+      epi_apply(p.E, row, j + 12, 0.0f);
+    }
+  }
+}
+void be_head_fwd(const HeadFwd& p, cnr_stream s) {
+  if (p.P <= 0) return;
+  long blocks = (p.P + 63) / 64;          // 4 waves x 16 points per block and trip
+  if (blocks > 2048) blocks = 2048;
+  TimingScope ts_("head_fwd", 2, p.n, p.P, p.n, 256, 1, s, (double)p.P * (4.0 * 256 + 32.0));
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("head_fwd");
+}
+
 template <int NT>
 static void launch_strip_bwd(const StripBwd& p, long per, cnr_stream s) {
   static DeviceOnce attr_once;

@@ -145,6 +145,16 @@ void be_head_bwd(const HeadBwd& p, cnr_stream) {
       }
   }
 }
+void be_head_fwd(const HeadFwd& p, cnr_stream) {
+  const long P = p.P_dev ? (long)*p.P_dev : p.P;
+#pragma omp parallel for
+  for (long row = 0; row < P; ++row)
+    for (int j = 0; j < 16; ++j) {
+      float acc = 0.0f;
+      if (j < p.n) for (int c = 0; c < 256; ++c) acc = fmaf(p.h[row * p.ldh + c], p.W[(long)j * p.ldw + c], acc);
+      epi_apply(p.E, row, j, acc);
+    }
+}
 void be_strip_bwd(const StripBwd& p, cnr_stream) {
   const long per = round_up((int)((p.P + p.nslots - 1) / p.nslots), 64);
 #pragma omp parallel for

@@ -557,6 +557,16 @@ static View color_input_view(const Model& m, int l, const Ctx& x) {
   return v;
 }
 
+// a narrow head (rgb, relight delta) on a 256-wide hidden layer: one streaming pass instead of a 32-column tile of the FP32-MFMA layer kernel
+static bool head_fwd(const Lin& q, const LayerGemm& g, cnr_stream s) {
+  static const bool off = getenv("CNR_NO_HEAD_FWD") != nullptr;   // debugging aid: the layer kernel for the heads
+  if (off || q.n > 4 || q.k_int != 256 || g.A.kind != VK_DIRECT || g.A.scale != 1.0f || (g.A.lda & 3) != 0 || (q.ldw & 3) != 0 || g.E.tail_src != nullptr) return false;
+  HeadFwd h;
+  h.h = g.A.a; h.ldh = g.A.lda; h.P = g.P; h.P_dev = g.P_dev; h.W = q.W; h.ldw = q.ldw; h.n = q.n; h.E = g.E;
+  be_head_fwd(h, s);
+  return true;
+}
+
 static void color_chain(const Model& m, long P, const Ctx& x, cnr_stream s, const int* P_dev = nullptr) {
   for (int l = 0; l < m.NC; ++l) {
     const Lin& q = m.col[l];
@@ -570,6 +580,7 @@ static void color_chain(const Model& m, long P, const Ctx& x, cnr_stream s, cons
       g.E.kind = m.c.col_squeeze_out ? EK_SIGMOID : EK_LINEAR_SIG; g.E.o1 = x.gcol; g.E.ld1 = 4;
       if (m.has_relight) { g.E.o2 = x.hry; g.E.ld2 = x.ldy; g.E.o2_off = m.Hr; }   // relight y-layer input tail [.. | rgb | 0]
     }
+    if (l + 1 == m.NC && head_fwd(q, g, s)) continue;
     be_layer_gemm(g, s);
   }
 }
@@ -603,6 +614,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
       g.E.kind = EK_RELIGHT_TOP; g.E.o1 = delta_out; g.E.ld1 = 3; g.E.o2 = x.relit; g.E.ld2 = 4;
       g.E.aux = x.gcol; g.E.ldaux = 4; g.E.inv_sigmoid = m.c.rel_inv_sigmoid;
     }
+    if (i + 1 == m.NR && head_fwd(q, g, s)) continue;
     be_layer_gemm(g, s);
   }
 }
