@@ -262,6 +262,14 @@ struct LossArgs {
 constexpr int kLossBlocks = 256;
 void be_loss_sums(const LossArgs& a, float* partial /* [kLossBlocks][4] */, float* sums /* [4] */, cnr_stream s);
 void be_loss_grads(const LossArgs& a, const float* coef, float* d_color, float* d_wsum, float* d_drel, cnr_stream s);
+struct LossScalars {   // see cnr_loss_combine / cnr_loss_coef in the ABI header; the constants are formed in double on the host and rounded once
+  float lf, le, lm, lr;                 // lambdas
+  float Rg, den_rgb, den_rel;           // n_rays_global, 3 Rg, 3 Rg M
+  float c_rgb, c_bce, c_rel;            // lambda_fine * (1 | 2) / (3 Rg), lambda_mask / Rg, lambda_relight * 2 / (3 Rg M)
+  int use_mask, use_relight;
+};
+void be_loss_combine(const LossScalars& c, const float* sums, const float* gerr, float* out6, cnr_stream s);
+void be_loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, cnr_stream s);
 // per-parameter gradient clip + Adam over up to kAdamBatch tensors per launch (clip_gradient + torch.optim.Adam, net_utils.py:174-184, :88)
 constexpr int kAdamBatch = 64;
 constexpr int kAdamChunk = 4096;   // elements per workgroup: a tensor is cut into ceil(n / kAdamChunk) chunks

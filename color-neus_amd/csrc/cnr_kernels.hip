@@ -783,6 +783,16 @@ __global__ __launch_bounds__(256) void loss_grads_kernel(const LossArgs a, const
   if (d_drel)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_rel; i += stride) d_drel[i] = c_rel * ((a.include_mask && a.mask) ? a.mask[i / per_ray] : 1.0f);
 }
+__global__ void loss_combine_kernel(const LossScalars c, const float* sums, const float* gerr, float* out) { if (threadIdx.x == 0 && blockIdx.x == 0) loss_combine(c, sums, gerr, out); }
+__global__ void loss_coef_kernel(const LossScalars c, const float* g_loss, const float* mean_rel, float* coef) { if (threadIdx.x == 0 && blockIdx.x == 0) loss_coef(c, g_loss, mean_rel, coef); }
+void be_loss_combine(const LossScalars& c, const float* sums, const float* gerr, float* out6, cnr_stream s) {
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, s, c, sums, gerr, out6);
+  CNR_LAUNCH_CHECK("loss_combine");
+}
+void be_loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, cnr_stream s) {
+  hipLaunchKernelGGL(loss_coef_kernel, dim3(1), dim3(64), 0, s, c, g_loss, mean_rel, coef4);
+  CNR_LAUNCH_CHECK("loss_coef");
+}
 void be_loss_grads(const LossArgs& a, const float* coef, float* d_color, float* d_wsum, float* d_drel, cnr_stream s) {
   TimingScope ts_("loss_grads", 2, 0, a.R, 0, 0, 0, s);
   hipLaunchKernelGGL(loss_grads_kernel, dim3(1024), dim3(256), 0, s, a, coef, d_color, d_wsum, d_drel);

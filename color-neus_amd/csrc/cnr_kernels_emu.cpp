@@ -35,6 +35,8 @@ void be_loss_sums(const LossArgs& a, float* partial, float* sums, cnr_stream) {
   }
   sums[0] = (float)s_rgb; sums[1] = (float)s_bce; sums[2] = (float)s_rel; sums[3] = 0.f;
 }
+void be_loss_combine(const LossScalars& c, const float* sums, const float* gerr, float* out6, cnr_stream) { loss_combine(c, sums, gerr, out6); }
+void be_loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, cnr_stream) { loss_coef(c, g_loss, mean_rel, coef4); }
 void be_loss_grads(const LossArgs& a, const float* coef, float* d_color, float* d_wsum, float* d_drel, cnr_stream) {
   for (long i = 0; i < a.R * 3; ++i) d_color[i] = coef[0] * loss_rgb_grad(a.color[i], a.gt[i], a.rgb_l1);
   if (d_wsum) for (long r = 0; r < a.R; ++r) d_wsum[r] = a.mask ? coef[1] * loss_bce_grad(a.wsum[r], a.mask[r]) : 0.0f;

@@ -17,4 +17,22 @@ CNR_HD float loss_bce_grad(float ws, float m) {   // clip passes the gradient on
   return -m / ws + (1.0f - m) / (1.0f - ws);
 }
 
+// the scalar arithmetic of compute_loss around the two reduction phases (fp32, operation order of NeuS_Trainer.py:146-171)
+CNR_HD void loss_combine(const LossScalars& c, const float* sums, const float* gerr, float* out) {
+  const float rgb = sums[0] / c.den_rgb;
+  const float eik = gerr[0];
+  float loss = c.lf * rgb + c.le * eik;
+  float mask = 0.0f, rel = 0.0f, mean_rel = 0.0f;
+  if (c.use_mask) { mask = sums[1] / c.Rg; loss = loss + c.lm * mask; }
+  if (c.use_relight) { mean_rel = sums[2] / c.den_rel; rel = mean_rel * mean_rel; loss = loss + c.lr * rel; }
+  out[0] = loss; out[1] = rgb; out[2] = eik; out[3] = mask; out[4] = rel; out[5] = mean_rel;
+}
+CNR_HD void loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef) {
+  const float g = g_loss[0];
+  coef[0] = g * c.c_rgb;
+  coef[1] = c.use_mask ? g * c.c_bce : 0.0f;
+  coef[2] = c.use_relight ? g * c.c_rel * mean_rel[0] : 0.0f;
+  coef[3] = g * c.le;
+}
+
 }  // namespace cnr

@@ -1369,6 +1369,37 @@ int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const fl
   return check_backend("loss_grads");
 }
 
+static int loss_scalars(const cnr_loss_config* cfg, float n_rays_global, int32_t n_samples, int32_t use_mask, int32_t use_relight, LossScalars& c) {
+  if (!cfg) return fail("null argument");
+  if (!(n_rays_global > 0.0f) || n_samples < 1) return fail("loss: n_rays_global and n_samples must be positive");
+  const double Rg = (double)n_rays_global, M = (double)n_samples;
+  c.lf = cfg->lambda_fine; c.le = cfg->lambda_eikonal; c.lm = cfg->lambda_mask; c.lr = cfg->lambda_relight;
+  c.Rg = (float)Rg; c.den_rgb = (float)(Rg * 3.0); c.den_rel = (float)(Rg * M * 3.0);
+  c.c_rgb = (float)((double)cfg->lambda_fine * (cfg->rgb_l1 ? 1.0 : 2.0) / (Rg * 3.0));
+  c.c_bce = (float)((double)cfg->lambda_mask / Rg);
+  c.c_rel = (float)((double)cfg->lambda_relight * 2.0 / (Rg * M * 3.0));
+  c.use_mask = use_mask != 0; c.use_relight = use_relight != 0;
+  return 0;
+}
+
+int cnr_loss_combine(const cnr_loss_config* cfg, const float* sums, const float* gradient_error, float n_rays_global, int32_t n_samples,
+                     int32_t use_mask, int32_t use_relight, float* out, void* stream) {
+  LossScalars c;
+  if (loss_scalars(cfg, n_rays_global, n_samples, use_mask, use_relight, c)) return -1;
+  if (!sums || !gradient_error || !out) return fail("null argument");
+  be_loss_combine(c, sums, gradient_error, out, (cnr_stream)stream);
+  return check_backend("loss_combine");
+}
+
+int cnr_loss_coef(const cnr_loss_config* cfg, const float* g_loss, const float* mean_rel, float n_rays_global, int32_t n_samples,
+                  int32_t use_mask, int32_t use_relight, float* coef, void* stream) {
+  LossScalars c;
+  if (loss_scalars(cfg, n_rays_global, n_samples, use_mask, use_relight, c)) return -1;
+  if (!g_loss || !coef || (use_relight && !mean_rel)) return fail("null argument");
+  be_loss_coef(c, g_loss, mean_rel, coef, (cnr_stream)stream);
+  return check_backend("loss_coef");
+}
+
 static int gen_rays_args(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
                          int32_t normalize, int32_t opengl, const float* origin, float radius, GenRays& g) {
   if (!c2w || !focal) return fail("null argument");

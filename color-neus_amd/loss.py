@@ -71,6 +71,21 @@ class _FusedLoss(torch.autograd.Function):
         world = dist.get_world_size(group) if (dist.is_initialized() and n_rays_global is not None) else 1
         Rg = float(n_rays_global if n_rays_global is not None else R)
         eik_factor = None
+        use_mask, use_rel = (lam_m != 0 and mask is not None), (lam_r != 0 and drel is not None)
+        if world == 1 and gerr.dtype == torch.float32 and gerr.device == dev:
+            # single process: the scalar tail of the objective in one launch of the library (cnr_loss_combine) instead of a dozen torch ops
+            out6 = torch.empty(6, dtype=torch.float32, device=dev)
+            lib.check(lib.lib.cnr_loss_combine(_C.byref(lcfg), _p(sums), _p(gerr.detach().reshape(-1).contiguous()), Rg, int(M), int(use_mask), int(use_rel),
+                                               _p(out6), _stream(color_c)), "cnr_loss_combine")
+            loss, rgb_loss, eik, mask_out, rel_out, mean_rel = out6.unbind(0)
+            ctx.lib, ctx.lcfg, ctx.lambdas, ctx.Rg, ctx.M = lib, lcfg, lambdas, Rg, M
+            ctx.has = (use_mask, use_rel, False)
+            ctx.fused_scalars = True
+            ctx.shapes = (color.shape, wsum.shape, tuple(drel.shape) if drel is not None else None)
+            ctx.save_for_backward(color_c, wsum_c, gt_c, mask_c if mask_c is not None else torch.empty(0, device=dev), mean_rel, mean_rel)
+            ctx.mark_non_differentiable(rgb_loss, eik, mask_out, rel_out)
+            return loss, rgb_loss, eik, mask_out, rel_out
+        ctx.fused_scalars = False
         if world > 1:
             stats = torch.cat([sums[:3], eik_sums.detach().reshape(-1)[:2].to(torch.float32)])
             den_loc = stats[4].clone()
@@ -121,10 +136,15 @@ class _FusedLoss(torch.autograd.Function):
         mask_t = mask_c if mask_c.numel() else None
         # coefficients on the device from the (device-resident) upstream gradient: no host -> device copy, hence no host stall
         g = g_loss.to(torch.float32)
-        c_rgb = lam_f * (1.0 if lcfg.rgb_l1 else 2.0) / (Rg * 3.0)
-        c_bce = (lam_m / Rg) if has_mask else 0.0
-        c_rel = (lam_r * 2.0 / (Rg * M * 3.0)) if has_rel else 0.0
-        coef = torch.stack([g * c_rgb, g * c_bce, g * c_rel * mean_rel, g * 0.0])
+        if ctx.fused_scalars:   # one launch (cnr_loss_coef); coef[3] = d loss / d gradient_error
+            coef = torch.empty(4, dtype=torch.float32, device=dev)
+            lib.check(lib.lib.cnr_loss_coef(_C.byref(lcfg), _p(g.reshape(-1).contiguous()), _p(mean_rel), Rg, int(M), int(has_mask), int(has_rel),
+                                            _p(coef), _stream(color_c)), "cnr_loss_coef")
+        else:
+            c_rgb = lam_f * (1.0 if lcfg.rgb_l1 else 2.0) / (Rg * 3.0)
+            c_bce = (lam_m / Rg) if has_mask else 0.0
+            c_rel = (lam_r * 2.0 / (Rg * M * 3.0)) if has_rel else 0.0
+            coef = torch.stack([g * c_rgb, g * c_bce, g * c_rel * mean_rel, g * 0.0])
         d_color = torch.empty_like(color_c)
         d_wsum = torch.empty(R, dtype=torch.float32, device=dev)
         lib.check(lib.lib.cnr_loss_grads(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(gt_c), _p(mask_t if has_mask or lcfg.include_mask else None),
@@ -135,7 +155,7 @@ class _FusedLoss(torch.autograd.Function):
             # backward as an expanded (stride-0) view -- its compositor backward takes the per-ray vector, no [R][M][3] buffer is written
             per_ray = coef[2] * mask_t if (lcfg.include_mask and mask_t is not None) else coef[2].expand(R)
             d_drel = per_ray.reshape(R, 1, 1).expand(ctx.shapes[2]) if len(ctx.shapes[2]) == 3 else per_ray.reshape(ctx.shapes[2])
-        d_gerr = g_loss * lam_e * eik_factor
+        d_gerr = coef[3].reshape(g_loss.shape) if ctx.fused_scalars else g_loss * lam_e * eik_factor
         return (None, None, None, None, None, d_color.reshape(ctx.shapes[0]), d_wsum.reshape(ctx.shapes[1]), d_gerr, None, d_drel, None, None, None)
 
 

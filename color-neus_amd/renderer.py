@@ -84,6 +84,7 @@ class _RenderFunction(torch.autograd.Function):
         # z is an affine function of near / far only without importance sampling (NeuS.py:311-313; with it z is built under no_grad, :343)
         ctx.nearfar_need_grad = (near.requires_grad or far.requires_grad) and cfg.n_importance == 0 and z_override is None
         ctx.nearfar_shapes = (near.shape, far.shape)
+        ctx.set_materialize_grads(False)   # outputs the loss does not use arrive as None in backward (which passes NULL), not as zero tensors
         ctx.mark_non_differentiable(out["inside_sphere"], out["z_vals"], out["eik_sums"])
         ctx.sample_names = [k for k in _SAMPLE_OUT if out[k] is not None]
         ctx.diff_names = [k for k in _OUT_DIFF + ["delta_relight_ray_sum"] if out.get(k) is not None]

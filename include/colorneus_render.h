@@ -146,6 +146,18 @@ int cnr_loss_sums_ray(const cnr_loss_config* cfg, const float* color_fine, const
 int cnr_loss_grads(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* rgb_gt, const float* mask,
                    int64_t n_rays, int32_t n_samples, const float* coef /* device [4] */, float* d_color_fine, float* d_weight_sum,
                    float* d_delta_relight /* or NULL */, void* stream);
+/* The scalar arithmetic around the two phases on the device, one launch each (single-process runs; a ray-sharded run all-reduces the sums
+ * in between and keeps these few operations in the host language).  fp32, the operation order of NeuS_Trainer.compute_loss:
+ *   cnr_loss_combine: out[1] = rgb = sums[0] / (3 Rg); out[2] = eikonal = gradient_error[0]; out[3] = mask = sums[1] / Rg (0 unless use_mask);
+ *                     out[5] = mean_rel = sums[2] / (3 Rg M); out[4] = relight = mean_rel^2 (0 unless use_relight);
+ *                     out[0] = loss = lambda_fine * rgb + lambda_eikonal * eikonal (+ lambda_mask * mask) (+ lambda_relight * relight)
+ *   cnr_loss_coef:    the coefficients of cnr_loss_grads from the upstream gradient g = g_loss[0]:
+ *                     coef[0] = g * lambda_fine * (1 for L1, 2 for MSE) / (3 Rg); coef[1] = g * lambda_mask / Rg (0 unless use_mask);
+ *                     coef[2] = g * lambda_relight * 2 / (3 Rg M) * mean_rel[0] (0 unless use_relight); coef[3] = g * lambda_eikonal = d loss / d gradient_error */
+int cnr_loss_combine(const cnr_loss_config* cfg, const float* sums /* device [4] */, const float* gradient_error /* device [1] */,
+                     float n_rays_global, int32_t n_samples, int32_t use_mask, int32_t use_relight, float* out /* device [6] */, void* stream);
+int cnr_loss_coef(const cnr_loss_config* cfg, const float* g_loss /* device [1] */, const float* mean_rel /* device [1] */,
+                  float n_rays_global, int32_t n_samples, int32_t use_mask, int32_t use_relight, float* coef /* device [4] */, void* stream);
 
 /* ---- ray generation for the selected pixels, the producer right in front of the path (NeuS_Trainer.render, NeuS_Trainer.py:104-120):
  * get_rays_multicam / get_rays_at (lib/models/tools/ray_utils.py:16-119) evaluated ONLY for the chosen pixels (the reference builds the
