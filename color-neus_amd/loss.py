@@ -53,6 +53,7 @@ class _FusedLoss(torch.autograd.Function):
     def forward(ctx, lib, lcfg, lambdas, n_rays_global, group, color, wsum, gerr, eik_sums, drel, gt, mask, n_samples_=0):
         from ._lib import CnrLossConfig  # noqa: F401
         lam_f, lam_e, lam_m, lam_r = lambdas
+        ctx.set_materialize_grads(False)   # (the four logging outputs are non-differentiable: no zero tensors for them in backward)
         R = color.shape[0]
         per_ray = drel is not None and drel.dim() == 1    # [R] sums over samples and rgb (renderer training_outputs="loss_only")
         M = (n_samples_ if per_ray else drel.shape[1]) if drel is not None else 1
