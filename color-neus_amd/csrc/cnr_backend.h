@@ -67,6 +67,13 @@ struct MergeZ {     // NeuS.py:183-197
   const float* new_z; const float* new_sdf; int m;   // new_sdf null on the last step (sdf not updated)
 };
 
+struct SamplerStep {   // one launch per up-sampling iteration: [merge of the previous iteration] + up_sample + [PE rows of the new samples]
+  int do_merge; MergeZ g;          // cat_z_vals of the previous iteration's new samples (its new_z / new_sdf are read before u.new_z is rewritten)
+  UpSample u;                      // on the merged row (u.n = g.n + g.m after a merge); u.w_in must be null
+  int do_embed; float* E; float scale; int multires;   // E[(ray * u.m + j)][kEmb] = PE(scale * (o + d * new_z[j])) like EmbedZ
+};
+void be_sampler_step(const SamplerStep& p, cnr_stream s);
+
 struct FineSetup {  // Color_NeuS.py:41-50: section midpoints, PE input of the SDF net, auxiliary inputs
   const float* o; const float* d; const float* z; long R; int M; float sample_dist;
   float scale; int multires; int multires_view;

@@ -969,6 +969,135 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeZ p) {
     }
   }
 }
+// merge (previous iteration) + up_sample + embedding of the new samples for one ray per wavefront: the arithmetic of merge_kernel,
+// upsample_kernel and the EmbedZ body, with the merged row handed over in LDS instead of through three launches
+__global__ __launch_bounds__(256) void sampler_step_kernel(const SamplerStep p) {
+  __shared__ float sh[4][7][kMaxRaySamples];
+  __shared__ float shn[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long ray = (long)blockIdx.x * 4 + wave;
+  const bool active = ray < p.u.R;
+  if (!active) ray = p.u.R - 1;
+  float* zs = sh[wave][0]; float* ss = sh[wave][1]; float* cs = sh[wave][2]; float* rs = sh[wave][3]; float* as = sh[wave][4];
+  float* zo = sh[wave][5]; float* so = sh[wave][6]; float* nz = shn[wave][0]; float* ns = shn[wave][1];
+  const UpSample& u = p.u;
+  const int n = u.n, nsec = u.n - 1;
+  float o[3], d[3];
+  for (int c = 0; c < 3; ++c) { o[c] = u.o[ray * 3 + c]; d[c] = u.d[ray * 3 + c]; }
+  if (p.do_merge) {
+    const MergeZ& g = p.g;   // (with new_sdf: the fused form is only used between two up-sampling iterations)
+    for (int i = lane; i < g.n; i += 64) { zo[i] = g.z[ray * g.ldz + i]; so[i] = g.sdf_in[ray * g.lds_in + i]; }
+    for (int j = lane; j < g.m; j += 64) { nz[j] = g.new_z[ray * g.m + j]; ns[j] = g.new_sdf[ray * g.m + j]; }
+    __syncthreads();
+    for (int i = lane; i < g.n; i += 64) {   // old sample i: stable position = i + #(new < z_i)
+      const float z = zo[i];
+      int cnt = 0;
+      for (int j = 0; j < g.m; ++j) cnt += nz[j] < z ? 1 : 0;
+      zs[i + cnt] = z; ss[i + cnt] = so[i];
+    }
+    for (int j = lane; j < g.m; j += 64) {   // new sample j: position = j + #(old <= new_j), new samples keep their order
+      const float z = nz[j];
+      int lo = 0, hi = g.n;
+      while (lo < hi) { int mid = (lo + hi) >> 1; if (zo[mid] > z) hi = mid; else lo = mid + 1; }
+      int rank = 0;
+      for (int q2 = 0; q2 < g.m; ++q2) rank += (nz[q2] < z || (nz[q2] == z && q2 < j)) ? 1 : 0;
+      zs[lo + rank] = z; ss[lo + rank] = ns[j];
+    }
+    __syncthreads();
+    if (active)
+      for (int i = lane; i < n; i += 64) { g.z[ray * g.ldz + i] = zs[i]; g.sdf_out[ray * g.lds_out + i] = ss[i]; }
+  } else {
+    for (int i = lane; i < n; i += 64) { zs[i] = u.z[ray * u.ldz + i]; ss[i] = u.sdf[ray * u.lds + i]; }
+    __syncthreads();
+  }
+  for (int i = lane; i < n; i += 64) {
+    const float z = zs[i];
+    const float x = o[0] + d[0] * z, y = o[1] + d[1] * z, w = o[2] + d[2] * z;
+    rs[i] = sqrtf(x * x + y * y + w * w);
+  }
+  __syncthreads();
+  for (int i = lane; i < nsec; i += 64) cs[i] = (ss[i + 1] - ss[i]) / (zs[i + 1] - zs[i] + 1e-5f);
+  __syncthreads();
+  for (int i = lane; i < nsec; i += 64) {
+    float prev = i > 0 ? cs[i - 1] : 0.0f;
+    float c = fminf(prev, cs[i]);
+    c = fminf(fmaxf(c, -1e3f), 0.0f);
+    const bool inside = rs[i] < 1.0f || rs[i + 1] < 1.0f;
+    c = inside ? c : c * 0.0f;
+    as[i] = upsample_alpha(ss[i], ss[i + 1], zs[i], zs[i + 1], c, u.inv_s);
+  }
+  __syncthreads();
+  float carry = 1.0f, part = 0.0f;
+  for (int base = 0; base < nsec; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < nsec;
+    const float a = ok ? as[i] : 0.0f;
+    const float f = ok ? 1.0f - a + 1e-7f : 1.0f;
+    const float incl = wave_scan_incl_mul(f, lane);
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.0f;
+    const float w = a * (carry * excl) + 1e-5f;
+    if (ok) { as[i] = w; part += w; }
+    carry = carry * __shfl(incl, 63);
+  }
+  const float total = wave_sum(part);
+  __syncthreads();
+  float csum = 0.0f;
+  for (int base = 0; base < nsec; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < nsec;
+    const float pdf = ok ? as[i] / total : 0.0f;
+    const float incl = wave_scan_incl_add(pdf, lane);
+    if (ok) cs[i + 1] = csum + incl;
+    csum = csum + __shfl(incl, 63);
+  }
+  if (lane == 0) cs[0] = 0.0f;
+  __syncthreads();
+  if (lane < u.m) {
+    const float uu = linspace_at(0.5f / (float)u.m, 1.0f - 0.5f / (float)u.m, u.m, lane);
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (cs[mid] > uu) hi = mid; else lo = mid + 1; }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < n - 1 ? lo : n - 1;
+    const float c0 = cs[below], c1 = cs[above];
+    const float b0 = zs[below], b1 = zs[above];
+    float den = c1 - c0;
+    if (den < 1e-5f) den = 1.0f;
+    const float t = (uu - c0) / den;
+    const float znew = b0 + t * (b1 - b0);
+    nz[lane] = znew;
+    if (active) u.new_z[ray * u.m + lane] = znew;
+  }
+  if (p.do_embed) {
+    __syncthreads();
+    if (active) {
+      // triples of the kEmb-wide rows of the u.m new samples (one contiguous piece of E): triple 0 = x, 1 + 2k = sin(2^k x), 2 + 2k = cos(2^k x)
+      const int ntr = kEmb / 3;
+      for (int idx = lane; idx < u.m * ntr; idx += 64) {
+        const int j = idx / ntr, t = idx - j * ntr;
+        const float z = nz[j];
+        float v[3];
+        const int k = t > 0 ? (t - 1) >> 1 : 0;
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float x = (o[c] + d[c] * z) * p.scale;
+          float sn, cn;
+          sincosf(x * f, &sn, &cn);
+          v[c] = t == 0 ? x : (t <= 2 * p.multires ? ((t & 1) ? sn : cn) : 0.0f);
+        }
+        float* e = p.E + (ray * u.m + j) * kEmb + 3 * t;
+        e[0] = v[0]; e[1] = v[1]; e[2] = v[2];
+      }
+    }
+  }
+}
+void be_sampler_step(const SamplerStep& p, cnr_stream s) {
+  TimingScope ts_("sampler_step", 2, 0, p.u.R, 0, 0, 0, s, (double)p.u.R * (8.0 * p.u.n + 24.0 + 4.0 * p.u.m + (p.do_embed ? 4.0 * kEmb * p.u.m : 0.0)));
+  hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((p.u.R + 3) / 4)), dim3(256), 0, s, p);
+  CNR_LAUNCH_CHECK("sampler_step");
+}
+
 void be_merge(const MergeZ& p, cnr_stream s) {
   TimingScope ts_("merge", 2, 0, p.R, 0, 0, 0, s, (double)p.R * (p.new_sdf ? 2.0 : 1.0) * (4.0 * p.n + 4.0 * p.m + 4.0 * (p.n + p.m)));
   hipLaunchKernelGGL(merge_kernel, dim3((unsigned)((p.R + 3) / 4)), dim3(256), 0, s, p);

@@ -157,6 +157,16 @@ void be_head_fwd(const HeadFwd& p, cnr_stream) {
       epi_apply(p.E, row, j, acc);
     }
 }
+void be_sampler_step(const SamplerStep& p, cnr_stream s) {   // the three steps one after the other (the fused launch is a speed matter)
+  if (p.do_merge) be_merge(p.g, s);
+  be_upsample(p.u, s);
+  if (p.do_embed) {
+    EmbedZ e;
+    e.o = p.u.o; e.d = p.u.d; e.R = p.u.R; e.m = p.u.m; e.z = p.u.new_z; e.ldz = p.u.m; e.make_z = 0;
+    e.near_ = nullptr; e.far_ = nullptr; e.t_rand = nullptr; e.scale = p.scale; e.multires = p.multires; e.E = p.E;
+    be_embed_z(e, s);
+  }
+}
 void be_strip_bwd(const StripBwd& p, cnr_stream) {
   const long per = round_up((int)((p.P + p.nslots - 1) / p.nslots), 64);
 #pragma omp parallel for

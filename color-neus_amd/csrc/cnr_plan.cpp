@@ -486,23 +486,31 @@ static void run_sampler(const Model& m, const cnr_render_inputs* in, float* z, C
   sdf_chain(m, R * m.S, x.sE, Zp, x.s_sdf0, nullptr, 0, 1.0f / scale, s);
   const int mnew = m.I / m.K;
   int n = m.S;
+  static const bool unfused = getenv("CNR_NO_SAMPLER_FUSE") != nullptr;   // debugging aid: merge / up_sample / embedding as launches of their own
+  MergeZ prev;   // the merge of iteration i - 1 rides on the launch of iteration i
   for (int i = 0; i < m.K; ++i) {
     const bool last = i + 1 == m.K;
     UpSample u;
     u.o = in->rays_o; u.d = in->rays_d; u.R = R; u.z = z; u.ldz = m.M;
     u.sdf = i == 0 ? x.s_sdf0 : x.s_sdf; u.lds = i == 0 ? m.S : m.M; u.n = n; u.m = mnew;
     u.inv_s = 64.0f * (float)(1 << i); u.new_z = x.s_newz;
-    be_upsample(u, s);
-    if (!last) {
-      EmbedZ e2 = e;
-      e2.m = mnew; e2.z = x.s_newz; e2.ldz = mnew; e2.make_z = 0;
-      be_embed_z(e2, s);
-      sdf_chain(m, R * mnew, x.sE, Zp, x.s_newsdf, nullptr, 0, 1.0f / scale, s);
+    EmbedZ e2 = e;
+    e2.m = mnew; e2.z = x.s_newz; e2.ldz = mnew; e2.make_z = 0;
+    if (!unfused && mnew <= 64) {
+      SamplerStep st;
+      st.do_merge = i > 0; st.g = prev; st.u = u; st.do_embed = !last; st.E = x.sE; st.scale = scale; st.multires = m.c.sdf_multires;
+      be_sampler_step(st, s);
+    } else {
+      if (i > 0) be_merge(prev, s);
+      be_upsample(u, s);
+      if (!last) be_embed_z(e2, s);
     }
+    if (!last) sdf_chain(m, R * mnew, x.sE, Zp, x.s_newsdf, nullptr, 0, 1.0f / scale, s);
     MergeZ g;
     g.R = R; g.z = z; g.ldz = m.M; g.sdf_in = i == 0 ? x.s_sdf0 : x.s_sdf; g.lds_in = i == 0 ? m.S : m.M;
     g.sdf_out = x.s_sdf; g.lds_out = m.M; g.n = n; g.new_z = x.s_newz; g.new_sdf = last ? nullptr : x.s_newsdf; g.m = mnew;
-    be_merge(g, s);
+    if (last) be_merge(g, s);
+    prev = g;
     n += mnew;
   }
 }

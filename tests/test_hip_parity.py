@@ -525,3 +525,34 @@ def test_streaming_strip_and_head_backward_match_gemm_launches(tmp_path):
         if not e < 5e-6:
             bad.append((k, e))
     assert not bad, bad
+
+
+_SAMPLER_CHILD = r"""
+import sys, os
+root, out = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np, torch
+import _native as N
+res = {}
+for name in ("dtu_sharp", "tiny_sharp"):
+    fx, r, o_, loss, grads, o, d = N.run_native(name, "det", None, torch.device("cuda:0"), fixed_z=False)
+    res.update({name + ":out:" + k: v.detach().cpu().numpy() for k, v in o_.items() if torch.is_tensor(v)})
+    res.update({name + ":g:" + k: v.detach().cpu().numpy() for k, v in grads.items()})
+np.savez(out, **res)
+"""
+
+
+def test_fused_sampler_step_is_bit_identical(tmp_path):
+    """sampler_step_kernel (merge of the previous iteration + up_sample + embedding of the new samples in one launch per iteration) against
+    the three launches it replaces (CNR_NO_SAMPLER_FUSE=1, child processes): same arithmetic on the same values -> z_vals, every output and
+    every gradient agree to the bit."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("fused", {}), ("separate", {"CNR_NO_SAMPLER_FUSE": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _SAMPLER_CHILD, root, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = dict(np.load(path))
+    assert set(res["fused"]) == set(res["separate"]) and any(k.endswith("out:z_vals") for k in res["fused"])
+    for k in sorted(res["fused"]):
+        assert np.array_equal(res["fused"][k], res["separate"][k], equal_nan=True), k
