@@ -76,11 +76,26 @@ __device__ __forceinline__ float fd_sel4(const f4& v, int j) {   // v[j] for a p
 // XR: DwFuse::xrow_mode (0 none; 1 column sums of the o2 output of an EK_SWEEP launch; 2 EK_VBACK launch with k_extra: rank-one update of the
 // product by A column 256 and the row of that column's products with Ep) -- the sdf row of the 257-wide top SDF layer, see cnr_plan.cpp
 // TAILF: the epilogue keeps its tail fill (sweep launch of the layer below a skip connection) and runs the general 16-byte epilogue code
-template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0, bool TAILF = false>
+// SPLITF: the value-backward epilogue keeps its split point (layer fed by a skip connection; see fdw_shape_ok), general 16-byte epilogue code
+template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0, bool TAILF = false, bool SPLITF = false>
 __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, const DwFuse f, int tiles_per_range, int dbg) {
   LayerGemm g = g_in;
-  g.A.kind = VK_DIRECT; g.E.kind = EK; g.E.split = 1 << 30;
+  g.A.kind = VK_DIRECT; g.E.kind = EK;
+  if (!SPLITF) g.E.split = 1 << 30;
   if (!TAILF) { g.E.tail_src = nullptr; g.E.tail_n = 0; }
+  constexpr bool GENF = TAILF || SPLITF;
+  // side inputs of 4 columns: the split form needs z in every column (beyond the split point it is the epilogue-side operand itself)
+  auto fetch_side = [&](long row, int col) {
+    if constexpr (SPLITF) {
+      EpiRaw4 r;
+      const f4 zero = {0.f, 0.f, 0.f, 0.f};
+      r.a = *reinterpret_cast<const f4*>(g.E.z + row * g.E.ldz + col);
+      r.b = col < g.E.split ? *reinterpret_cast<const f4*>(g.E.o1 + row * g.E.ld1 + col) : zero;
+      return r;
+    } else {
+      return epi_fetch4_sel<EK, GENF>(g.E, row, col);
+    }
+  };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // blocks b and b + 8 (same XCD under the observed round-robin placement: a speed matter only) are the two column halves of one range
@@ -163,6 +178,12 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         f4 v = *reinterpret_cast<const f4*>(T + rr * FD_TLD + cc);
         v.x *= rsc * wsc.x; v.y *= rsc * wsc.y; v.z *= rsc * wsc.z; v.w *= rsc * wsc.w;
         f4 ep = fd_ep4<EK>(g.E, ern[q]);
+        if constexpr (SPLITF) {   // [softplus(z) | z] * vscale: the layer's forward input as its view forms it
+          const f4 zz = ern[q].a;
+          const int sp = g.E.split - ecol;
+          ep.x = (sp > 0 ? ep.x : zz.x) * g.E.vscale; ep.y = (sp > 1 ? ep.y : zz.y) * g.E.vscale;
+          ep.z = (sp > 2 ? ep.z : zz.z) * g.E.vscale; ep.w = (sp > 3 ? ep.w : zz.w) * g.E.vscale;
+        }
         if constexpr (XR == 2) {
           const float zs = zq[q];
           v.x = fmaf(zs, wr1.x, v.x); v.y = fmaf(zs, wr1.y, v.y); v.z = fmaf(zs, wr1.z, v.z); v.w = fmaf(zs, wr1.w, v.w);
@@ -173,8 +194,8 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
           xacc.x += softplus100_d1(ern[q].a.x) * v.x; xacc.y += softplus100_d1(ern[q].a.y) * v.y;
           xacc.z += softplus100_d1(ern[q].a.z) * v.z; xacc.w += softplus100_d1(ern[q].a.w) * v.w;
         }
-        epi_finish4_sel<EK, TAILF>(g.E, row, ecol, v, bias4, ern[q]);
-        ern[q] = epi_fetch4_sel<EK, TAILF>(g.E, tn * FD_TP + rr, ecol);
+        epi_finish4_sel<EK, GENF>(g.E, row, ecol, v, bias4, ern[q]);
+        ern[q] = fetch_side(tn * FD_TP + rr, ecol);
         const float ys = fd_yscale(ssr[rr], G);
         ep.x *= ys; ep.y *= ys; ep.z *= ys; ep.w *= ys;
         unsigned char* yrow = Yb + (wave * 32 + cc) * FD_YLD + rr * 2;
@@ -196,8 +217,8 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     EpiRaw4 ernA[4], ernB[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      ernA[q] = epi_fetch4_sel<EK, TAILF>(g.E, t0 * FD_TP + (lane >> 3) + 8 * q, ecol);   // (a range past the end is clamped to tile 0 of the launch: loaded, never used)
-      if (DP) ernB[q] = epi_fetch4_sel<EK, TAILF>(g.E, (t0 + (1 < nlast ? 1 : nlast)) * FD_TP + (lane >> 3) + 8 * q, ecol);
+      ernA[q] = fetch_side(t0 * FD_TP + (lane >> 3) + 8 * q, ecol);   // (a range past the end is clamped to tile 0 of the launch: loaded, never used)
+      if (DP) ernB[q] = fetch_side((t0 + (1 < nlast ? 1 : nlast)) * FD_TP + (lane >> 3) + 8 * q, ecol);
     }
     cnr_lds_barrier();   // tile 0 staged
     int ab = 0;
@@ -455,16 +476,16 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
   }
 }
 
-template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0, bool TAILF = false>
+template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0, bool TAILF = false, bool SPLITF = false>
 static void launch_fdw_v(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
   static DeviceOnce attr_once;
   if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD, NKB, XR, TAILF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_dw_kernel<EK, DP, DD, NKB, XR, TAILF, SPLITF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = g.P / FD_TP;
   const int tpr = (int)((ntiles + f.nslots - 1) / f.nslots);
   TimingScope ts_("layer_dw", 0, 200 + EK, g.P, 256, g.K, 2, s, fdw_bytes(g, f));   // pairs = 2: the layer product + the weight-gradient product
   static const int dbg = getenv("CNR_FDW_DBG") ? atoi(getenv("CNR_FDW_DBG")) : 0;   // ablation switches (timing experiments only: results are wrong)
-  hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD, NKB, XR, TAILF>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
+  hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD, NKB, XR, TAILF, SPLITF>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
 }
 template <int EK>
 static void launch_fdw(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
@@ -503,6 +524,7 @@ void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_
   if (f.xrow_mode == 2 && g.E.kind == EK_VBACK && g.k_extra == 1 && g.K == 256) launch_fdw_v<EK_VBACK, false, false, 16, 2>(g, f, s);
   else if (f.xrow_mode == 1 && g.E.kind == EK_SWEEP && g.K > 240) launch_fdw_v<EK_SWEEP, false, false, 16, 1>(g, f, s);
   else if (g.E.kind == EK_SWEEP && g.E.tail_src != nullptr) launch_fdw_v<EK_SWEEP, false, false, 16, 0, true>(g, f, s);
+  else if (g.E.kind == EK_VBACK && g.E.split < 256) launch_fdw_v<EK_VBACK, false, false, 16, 0, false, true>(g, f, s);
   else if (g.K <= 224) launch_fdw_v<EK_VBACK, false, false, 14>(g, f, s);
   else switch (g.E.kind) {
     case EK_RELU_MASK: launch_fdw<EK_RELU_MASK>(g, f, s); break;

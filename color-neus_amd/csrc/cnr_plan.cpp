@@ -1000,7 +1000,8 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     else { g.A.kind = VK_DIRECT; g.A.a = b.Z2[l]; g.A.lda = m.Hs; }
     g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
     g.E.kind = EK_VBACK; g.E.n_out = q.k_int; g.E.z = x.Z[l - 1]; g.E.ldz = m.Hs; g.E.o1 = b.Z2[l - 1]; g.E.ld1 = m.Hs;
-    if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; g.E.o2_off = skip_off(m); }
+    if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; g.E.o2_off = skip_off(m);
+                     g.E.vscale = kInvSqrt2; }   // (vscale: the scale of the layer's input view, for the fused launch's epilogue-side operand)
     return g;
   };
   // value pair of layer l: X = zbar_l, Y = the layer's forward input

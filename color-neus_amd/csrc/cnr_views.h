@@ -459,7 +459,12 @@ inline bool fdw_shape_ok(const LayerGemm& g) {
   // under the tail columns: w_rows >= 256); that launch runs the general 16-byte epilogue code
   const bool tail_form = e.kind == EK_SWEEP && e.tail_src != nullptr && e.n_out + e.tail_n == 256 && e.n_out >= 192 && g.w_rows >= 256 &&
                          g.N == e.n_out && e.split == (1 << 30) && e.ldv != 0;
-  if (!tail_form && (e.tail_src != nullptr || e.n_out < 256 || e.split < 256 || g.N < 256)) return false;
+  // ... or, for the value-backward launch of the layer fed by a skip connection, a split point inside the 256 columns: the columns below it are
+  // the hidden part (value-backward epilogue), those at and beyond it the embedding part (plain store to o2, whose 16-byte groups line up:
+  // o2_off == split % 4); the epilogue-side operand is then [softplus(z) | z] * vscale, the layer's forward input as its view forms it
+  const bool split_form = e.kind == EK_VBACK && e.tail_src == nullptr && e.n_out == 256 && g.N == 256 && e.split >= 192 && e.split < 256 &&
+                          ((e.o2_off - e.split) & 3) == 0 && (e.ld2 & 3) == 0 && g.K > 240;
+  if (!tail_form && !split_form && (e.tail_src != nullptr || e.n_out < 256 || e.split < 256 || g.N < 256)) return false;
   if (g.N > 256 && e.kind != EK_RELU_MASK) return false;
   switch (e.kind) {
     case EK_RELU_MASK: return ((e.ld1 | e.ldaux) & 3) == 0 && e.aux != nullptr;
