@@ -54,7 +54,7 @@ __device__ __forceinline__ float fd_yscale(float sx, int G) {
 template <int EK>
 __device__ __forceinline__ f4 fd_ep4(const Epi& e, const EpiRaw4& raw) {
   f4 r;
-  if constexpr (EK == EK_RELU_MASK) {
+  if constexpr (EK == EK_RELU_MASK || EK == EK_SPLIT) {
     r = raw.a;
   } else if constexpr (EK == EK_VBACK) {
     r.x = softplus100(raw.a.x); r.y = softplus100(raw.a.y); r.z = softplus100(raw.a.z); r.w = softplus100(raw.a.w);
@@ -91,6 +91,11 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
       const f4 zero = {0.f, 0.f, 0.f, 0.f};
       r.a = *reinterpret_cast<const f4*>(g.E.z + row * g.E.ldz + col);
       r.b = col < g.E.split ? *reinterpret_cast<const f4*>(g.E.o1 + row * g.E.ld1 + col) : zero;
+      return r;
+    } else if constexpr (EK == EK_SPLIT) {   // no epilogue side input: only the epilogue-side operand (aux)
+      EpiRaw4 r;
+      r.a = *reinterpret_cast<const f4*>(g.E.aux + row * g.E.ldaux + col);
+      r.b = r.a;
       return r;
     } else {
       return epi_fetch4_sel<EK, GENF>(g.E, row, col);
@@ -532,6 +537,7 @@ void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_
   else switch (g.E.kind) {
     case EK_RELU_MASK: launch_fdw<EK_RELU_MASK>(g, f, s); break;
     case EK_VBACK: launch_fdw<EK_VBACK>(g, f, s); break;
+    case EK_SPLIT: launch_fdw_v<EK_SPLIT, false, false>(g, f, s); break;
     default: launch_fdw<EK_SWEEP>(g, f, s); break;
   }
   CNR_LAUNCH_CHECK("layer_dw");

@@ -939,6 +939,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     } else {   // cotangent of [feat | aux]: feat part lands in ZTOP[., 0:F] (the sdf cotangent sits in column F), aux part in dAUXc
       g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.split = m.F; g.E.o1 = b.ZTOP; g.E.ld1 = x.ldztop; g.E.o1_off = 0;
       g.E.o2 = b.dAUXc; g.E.ld2 = kAux;
+      g.E.aux = x.featx; g.E.ldaux = x.ldfx;   // (the layer's forward input: the epilogue-side operand of the fused launch)
     }
     DwGemm d;
     d.npairs = 1; d.P = P;

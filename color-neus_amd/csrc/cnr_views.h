@@ -450,7 +450,9 @@ inline bool fdw_shape_ok(const LayerGemm& g) {
   const Epi& e = g.E;
   if (g.A.kind != VK_DIRECT || (g.A.lda & 3) != 0 || g.col0 != 0 || g.first_col != 0 || g.P_dev != nullptr) return false;
   if (g.P <= 0 || (g.P % 32) != 0 || g.Wp == nullptr || g.wscale == nullptr) return false;
-  if (e.kind != EK_RELU_MASK && e.kind != EK_VBACK && e.kind != EK_SWEEP) return false;
+  // (EK_SPLIT: colour layer 0 -- a plain scaled store; its epilogue has no side input, so the epilogue-side operand, the layer's forward
+  // input, is named by aux / ldaux)
+  if (e.kind != EK_RELU_MASK && e.kind != EK_VBACK && e.kind != EK_SWEEP && e.kind != EK_SPLIT) return false;
   // contraction: 16 k16 blocks, or 14 for the value-backward launch of the 217-wide layer (its pad columns are zero, its weight planes 224 wide)
   if (!(g.K > 240 && g.K <= 256) && !(e.kind == EK_VBACK && g.K > 208 && g.K <= 224 && g.ldw >= 224)) return false;
   // the first 256 output columns are plain (no tail fill, no split point below 256); further columns (N > 256, EK_RELU_MASK only: the
@@ -468,12 +470,14 @@ inline bool fdw_shape_ok(const LayerGemm& g) {
   if (g.N > 256 && e.kind != EK_RELU_MASK) return false;
   switch (e.kind) {
     case EK_RELU_MASK: return ((e.ld1 | e.ldaux) & 3) == 0 && e.aux != nullptr;
+    case EK_SPLIT: return ((e.ld1 | e.ldaux | e.o1_off) & 3) == 0 && e.aux != nullptr && e.o1 != nullptr && e.bias == nullptr;
     case EK_VBACK: return ((e.ld1 | e.ldz) & 3) == 0;
     default: return ((e.ld1 | e.ld2 | e.ldz | e.ldv) & 3) == 0 && e.o2 != nullptr;
   }
 }
 inline double fdw_bytes(const LayerGemm& g, const DwFuse& f) {   // the layer launch's operands + the partial sums; S counted once (its second read is an L2 hit)
-  return layer_gemm_bytes(g) + 4.0 * f.nslots * (double)f.Npad * f.ldk;
+  // (EK_SPLIT has no epilogue side input: its epilogue-side operand, aux, is an extra read of the fused launch)
+  return layer_gemm_bytes(g) + (g.E.kind == EK_SPLIT ? 4.0 * (double)g.P * 256 : 0.0) + 4.0 * f.nslots * (double)f.Npad * f.ldk;
 }
 
 inline double dw_gemm_bytes(const DwGemm& g, int n, int k) {
