@@ -366,5 +366,10 @@ void be_timing_enable(int on);
 int be_timing_collect(KernelTiming* out, int max_records);   // synchronises the recorded events, returns #records, resets
 const char* be_name();
 int be_check_last_error(char* msg, size_t n);   // 0 ok
+// Named ranges for profilers (rocprofv3 --marker-trace): roctxRangePush / Pop of librocprofiler-sdk-roctx / libroctx64, loaded on first use
+// when CNR_ROCTX=1 (no link dependency; without the variable or the library these are no-ops)
+void be_range_push(const char* name);
+void be_range_pop();
+struct RangeScope { explicit RangeScope(const char* name) { be_range_push(name); } ~RangeScope() { be_range_pop(); } };
 
 }  // namespace cnr

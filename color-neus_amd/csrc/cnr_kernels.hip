@@ -10,6 +10,7 @@
 //   upsample / merge / composite_fwd / composite_bwd: one wavefront per ray, ray state staged in LDS
 //   point-wise kernels: positional encodings, PE Jacobians, weight preparation (weight-norm) and its backward
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <vector>
@@ -68,6 +69,26 @@ int be_timing_collect(KernelTiming* out, int max_records) {
   g_timing.clear();
   return n;
 }
+
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+  Roctx() {
+    if (!getenv("CNR_ROCTX")) return;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+      if (!h) continue;
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void be_range_push(const char* name) { if (roctx().push) (void)roctx().push(name); }
+void be_range_pop() { if (roctx().pop) (void)roctx().pop(); }
 
 int be_check_last_error(char* msg, size_t n) {
   if (g_first_error == hipSuccess) return 0;

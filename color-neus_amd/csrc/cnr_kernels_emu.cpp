@@ -23,6 +23,8 @@ void be_finish_weights(const FinishWeight* f, int count, cnr_stream s) { for (in
 void be_timing_enable(int) {}
 int be_timing_collect(KernelTiming*, int) { return 0; }
 int be_check_last_error(char*, size_t) { return 0; }
+void be_range_push(const char*) {}
+void be_range_pop() {}
 void be_memset_zero(void* p, size_t bytes, cnr_stream) { memset(p, 0, bytes); }
 void be_loss_sums(const LossArgs& a, float* partial, float* sums, cnr_stream) {
   (void)partial;

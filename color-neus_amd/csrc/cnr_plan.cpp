@@ -655,18 +655,20 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   const long P = R * m.M;
   const float scale = m.c.sdf_scale;
 
-  prep_all(m, params, s);
+  RangeScope range_fwd("cnr_render_forward");
+  { RangeScope r_("weights"); prep_all(m, params, s); }
   if (in->z_vals_override) {
     if (in->z_vals_override != out->z_vals) return fail("z_vals_override must alias outputs.z_vals (copy it there first)");
   } else {
+    RangeScope r_("sampler");
     run_sampler(m, in, out->z_vals, x, s);
   }
   FineSetup fs;
   fs.o = in->rays_o; fs.d = in->rays_d; fs.z = out->z_vals; fs.R = R; fs.M = m.M; fs.sample_dist = 2.0f / (float)m.S;
   fs.scale = scale; fs.multires = m.c.sdf_multires; fs.multires_view = m.mv; fs.E = x.E; fs.AUX = x.AUX;
   be_fine_setup(fs, s);
-  sdf_chain(m, P, x.E, x.Z.data(), x.sdf, x.featx, x.ldfx, 1.0f / scale, s, x.rsY.data());
-  sdf_grad_chain(m, P, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s, x.rsX1.data());
+  { RangeScope r_("sdf value chain"); sdf_chain(m, P, x.E, x.Z.data(), x.sdf, x.featx, x.ldfx, 1.0f / scale, s, x.rsY.data()); }
+  { RangeScope r_("sdf gradient chain"); sdf_grad_chain(m, P, x.E, x.Z.data(), x.V.data(), x.CE0, x.CES, s, x.rsX1.data()); }
   GradFinish gf;
   gf.featx = x.featx; gf.ldfx = x.ldfx; gf.F = m.F;
   gf.P = P; gf.E = x.E; gf.ce0 = x.CE0; gf.ces = has_skip(m) ? x.CES + skip_off(m) : nullptr; gf.scale = scale; gf.multires = m.c.sdf_multires;
@@ -708,9 +710,11 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
     sc.delta = m.has_relight ? out->delta_relight : nullptr;
     be_prune_scatter(sc, s);
   } else {
+    RangeScope r_("colour + relight chains");
     color_chain(m, P, x, s);
     if (m.has_relight) relight_chain(m, P, x, delta_out, s);
   }
+  RangeScope r_comp("compositor");
   be_composite_fwd(cf, s);
   ReduceEik re;
   re.partial = x.eik_partial; re.R = R; re.sums = x.eik_sums; re.sums_out = out->eik_sums; re.gradient_error = out->gradient_error;
@@ -850,6 +854,8 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   float* const* dP = gi->d_params;
   const bool skipnet = has_skip(m);
 
+  RangeScope range_bwd("cnr_render_backward");
+  be_range_push("compositor backward");
   // ---- 1. compositor backward
   be_zero_cols(b.ZTOP, x.ldztop, m.F + 1, x.ldztop, P, s);   // pad columns of [feat cotangent | sdf cotangent | 0]: every other column is written below
   CompositeBwd cb;
@@ -871,6 +877,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   vf.partial = b.dinvs; vf.R = R; vf.variance = params[m.p_variance]; vf.d_variance = dP[m.p_variance];
   be_variance_finish(vf, s);
 
+  be_range_pop(); be_range_push("relight chain backward");
   // ---- 2. relight chain backward
   const bool fdw = be_fdw_enabled();   // layer launch + weight gradient in one launch where the shape allows (cnr_gemm_fdw.hip)
   if (m.has_relight) {
@@ -922,6 +929,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       run_dw(m, q, d, b, params, dP, true, s);
     }
   }
+  be_range_pop(); be_range_push("colour chain backward");
   // ---- 3. colour chain backward
   ColTopBwd ct;
   ct.P = P; ct.gc_a = b.gc_a; ct.gc_b = m.has_relight ? b.gc_b : nullptr; ct.gcolor = x.gcol; ct.squeeze = m.c.col_squeeze_out;
@@ -965,6 +973,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     }
     if (strips) strip_columns_of_last_finish(b);
   }
+  be_range_pop(); be_range_push("sdf second-order sweep");
   // ---- 4. total d g and the tangent of the embedding
   GbarFinish gb;
   gb.P = P; gb.gbar_alpha = b.gbar_a; gb.daux_c = b.dAUXc; gb.daux_r = m.has_relight ? b.dAUXr : nullptr; gb.E = x.E; gb.scale = scale;
@@ -1070,6 +1079,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       be_layer_gemm(g, s);
     }
   }
+  be_range_pop(); be_range_push("sdf value backward");
   // ---- 6. value-path backward through the SDF net (in place: Z2[l] becomes the total cotangent of z_l)
   for (int l = m.L; l >= 1; --l) {
     const Lin& q = m.sdf[l];
@@ -1094,6 +1104,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = b.ebar0; g.E.ld1 = kEmb;
     be_layer_gemm(g, s);
   }
+  be_range_pop(); be_range_push("weight gradients: leftovers + finish");
   // ---- 7. SDF weight gradients that were not formed inside a layer launch: value pair (zbar_l, input_l) + gradient-chain pair (u_l, qbar_l)
   for (int l = 0; l <= m.L; ++l) {
     const Lin& q = m.sdf[l];
@@ -1118,6 +1129,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     finish_region(q, r, value_slots(l) + grad_slots(l), value_slots(l), b, params, dP);
   }
   flush_dw(b, s);   // all partial-sum reductions + weight-norm backward in one launch
+  be_range_pop();
   // ---- 8. d rays (camera refinement configs)
   if (rays_grad) {
     PbarFinish pf;
