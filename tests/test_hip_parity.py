@@ -488,21 +488,22 @@ def test_fused_layer_dw_matches_separate_launches(tmp_path):
     257th contraction index of the split-f16 product (round-off of one term)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, extra in (("fused", {}), ("separate", {"CNR_NO_FDW": "1"})):
+    for tag, extra in (("fused", {}), ("separate", {"CNR_NO_FDW": "1"}), ("top_unfused", {"CNR_NO_TOP_FUSE": "1"})):
         path = str(tmp_path / (tag + ".npz"))
         r = subprocess.run([sys.executable, "-c", _STREAM_CHILD, root, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         res[tag] = dict(np.load(path))
-    assert set(res["fused"]) == set(res["separate"])
     bad = []
-    for k in sorted(res["fused"]):
-        a, b = res["fused"][k].astype(np.float64), res["separate"][k].astype(np.float64)
-        if k.startswith("g:") or k in ("d_o", "d_d"):
-            e = float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-300)
-            if not e < 5e-6:
-                bad.append((k, e))
-        elif not np.array_equal(a, b, equal_nan=True):
-            bad.append((k, "not bit-identical"))
+    for other in ("separate", "top_unfused"):   # (top_unfused: only the top SDF layer's backward as launches of its own, everything else fused)
+        assert set(res["fused"]) == set(res[other])
+        for k in sorted(res["fused"]):
+            a, b = res["fused"][k].astype(np.float64), res[other][k].astype(np.float64)
+            if k.startswith("g:") or k in ("d_o", "d_d"):
+                e = float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-300)
+                if not e < 5e-6:
+                    bad.append((other, k, e))
+            elif not np.array_equal(a, b, equal_nan=True):
+                bad.append((other, k, "not bit-identical"))
     assert not bad, bad
 
 
