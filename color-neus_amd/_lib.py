@@ -146,7 +146,7 @@ class RenderLibrary:
         L.cnr_timing_enable.argtypes = [C.c_int]
         L.cnr_timing_enable.restype = None
         L.cnr_timing_collect.argtypes = [C.POINTER(CnrKernelTiming), C.c_int]
-        if L.cnr_abi_version() != 3:
+        if L.cnr_abi_version() != 4:
             raise RuntimeError("colorneus library ABI mismatch")
 
     @property

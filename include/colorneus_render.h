@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CNR_ABI_VERSION 3
+#define CNR_ABI_VERSION 4
 
 typedef struct cnr_config {
   int32_t type;              /* 0 = NeuS (NeuS.py:68), 1 = Color_NeuS (Color_NeuS.py:10) */
