@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-loss-only", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the contract CPU baseline (16 was the fastest of {8,16,32,64,128} on the 2x64-core bench host)")
@@ -130,13 +131,13 @@ def main():
 
     torch.manual_seed(2)   # jitter stream (CPU generator, like the reference)
 
-    def step(i, r=None, alt=None):
+    def step(i, r=None, alt=None, outputs="dict"):
         r = R if r is None else r
         rg = r * world
         o, d, near, far, gt, mask = batch(i, r)
         rnd, params, opt = alt if alt is not None else (renderer, params0, opt0)
         M = rnd.rcfg.n_total
-        out = rnd(o, d, near, far)
+        out = rnd(o, d, near, far, training_outputs=outputs)
         if args.torch_loss:    # the torch restatement of compute_loss (and its sharded counterpart)
             if world == 1:
                 loss, _ = cn.compute_loss(out, gt, mask)
@@ -161,9 +162,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed(nsteps, warmup, r=None, alt=None, per_step=None):
+    def timed(nsteps, warmup, r=None, alt=None, per_step=None, outputs="dict"):
         for i in range(warmup):
-            step(i, r, alt)
+            step(i, r, alt, outputs)
         sync()
         # per-step HIP events on the stream every kernel of the step is launched on (torch's current stream): nsteps + 1 marks
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)] if per_step is not None else None
@@ -171,7 +172,7 @@ def main():
         for i in range(nsteps):
             if marks:
                 marks[i].record()
-            loss = step(warmup + i, r, alt)
+            loss = step(warmup + i, r, alt, outputs)
         if marks:
             marks[nsteps].record()
         sync()
@@ -266,7 +267,7 @@ def main():
         # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed summary
         # of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py)
         traffic, tfile = None, None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             cand = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic_%drays.json" % (rnd, R))
             if os.path.exists(cand):
                 t = json.load(open(cand))["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
@@ -277,7 +278,7 @@ def main():
                      "algorithmic_bytes_per_launch": round(dom[3] / dom[2]), "launches_per_step": dom[2] // nrep,
                      "share_of_kernel_time": round(dom[0] / tot_ms, 3)})
         result["roofline"] = roof
-        always = ("upsample", "merge", "composite_fwd", "composite_bwd", "chain_sdf_value", "clip_adam")   # north_star evidence: sampler / compositor GB/s
+        always = ("sampler_step", "upsample", "merge", "composite_fwd", "composite_bwd", "chain_sdf_value", "chain_fwd", "clip_adam")   # north_star evidence: sampler / compositor GB/s
         top = sorted(agg.items(), key=lambda kv: -kv[1][0])
         keep = [kv for i, kv in enumerate(top) if i < 8 or kv[0] in always]
         result["kernel_breakdown"] = [{"kernel": k, "ms_per_step": round(v[0] / nrep, 4),
@@ -300,6 +301,13 @@ def main():
             dts, _ = timed(n, 5, r)
             small[str(r)] = round(r * world * n / dts, 1)
         result["small_batch"] = {"unit": "rays/s", "rays_per_step_per_gpu": small}
+        # launches of a 512-ray step (the fixed per-launch costs are what separates the small-batch rate from the 4096-ray rate)
+        if rank == 0 and world == 1:
+            lib.timing_enable(True)
+            step(0, 512)
+            torch.cuda.synchronize(dev)
+            result["small_batch"]["launches_per_step_512"] = len(lib.timing_collect())
+            lib.timing_enable(False)
         # BASELINE config 2 as written: DTU network, 512 rays per batch x 64 samples, no importance sampling
         cfg2 = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0, n_samples=64, n_importance=0)
         r2 = cn.ColorNeuSRenderer(cfg2).to(dev)
@@ -310,6 +318,17 @@ def main():
         n = max(20, min(args.steps, 60))
         dts, _ = timed(n, 5, 512, alt)
         result["small_batch"]["c2_512rays_x_64samples_no_importance"] = round(512 * world * n / dts, 1)
+
+    # ---- the same step with training_outputs="loss_only" (no [R][M][3] dict tensors, the relight term from per-ray sums of
+    # the compositor); not the default because the reference's trainer consumes the dict
+    if not args.no_loss_only and not args.torch_loss:
+        lo = {}
+        for r in sorted({R, 1024}):
+            n = max(20, min(args.steps, 60))
+            dts, _ = timed(n, 5, r, outputs="loss_only")
+            lo[str(r)] = round(r * world * n / dts, 1)
+        result["loss_only"] = {"unit": "rays/s", "rays_per_step_per_gpu": lo,
+                               "note": "same step (fwd + fused loss + bwd + clip + Adam) with renderer(..., training_outputs='loss_only')"}
 
     # ---- inference use of the path (validate_image, NeuS_Trainer.py:216-277): forward only, EVAL-style chunks, without / with the
     # early-termination compaction (colour / relight stacks only on samples with weight >= eps: ballot + popcount compaction, inference only)
@@ -359,36 +378,46 @@ def main():
                         "note": "extract_fields / extract_geometry / extract_color (NeuS.py:14-64) on the device; vertex colours include the H2D / D2H of the caller's numpy arrays"}
         del u, mv, mt
 
-    # ---- the plain-PyTorch restatement on the same GPU (the 'reference single-GPU PyTorch' stand-in), bounded sample
+    # ---- the plain-PyTorch restatement on the same GPU (the 'reference single-GPU PyTorch' stand-in) on the SURVEY 8d protocol:
+    # R in {512, 1024, 4096}, 3 warm-up + 20 timed iterations each, HIP events around every iteration on the launch stream, median
     if not args.no_torch_gpu_baseline and rank == 0:
         from oracle import colorneus_oracle as O
         ocfg = O.dtu_config()
         P = {k: v.detach().clone().requires_grad_(True) for k, v in renderer.state_dict().items()}
-        Rt = 1024   # the reference's N_RAYS
-        o, d, near, far, gt, mask = [x[:Rt] for x in batch(0, max(R, Rt))]
+        nt_, per_r = 20, {}
+        for Rt in (512, 1024, 4096):
+            o, d, near, far, gt, mask = [x[:Rt] for x in batch(0, max(R, Rt))]
 
-        def tstep():
-            t_rand = torch.rand(Rt, 1).to(dev)
-            out = O.render(P, ocfg, o, d, near, far, t_rand=t_rand, reference_ops=True)
-            l, _ = O.compute_loss(out, gt, mask)
-            for p in P.values():
-                p.grad = None
-            l.backward()
-        for _ in range(2):
-            tstep()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        nt_ = 6
-        for _ in range(nt_):
-            tstep()
-        torch.cuda.synchronize(dev)
-        tv = Rt * nt_ / (time.perf_counter() - t1)
-        result["torch_gpu_baseline"] = {"value": round(tv, 1), "unit": "rays/s",
-                                        "sample": "%d iterations of %d rays x 128 samples, plain PyTorch-ROCm ops, the oracle restatement in its reference_ops mode "
-                                                  "(normals by a second SDF forward + autograd.grad(create_graph=True) like fields.py:105-115), fwd+bwd, no optimiser" % (nt_, Rt),
+            def tstep():
+                t_rand = torch.rand(Rt, 1).to(dev)
+                out = O.render(P, ocfg, o, d, near, far, t_rand=t_rand, reference_ops=True)
+                l, _ = O.compute_loss(out, gt, mask)
+                for p in P.values():
+                    p.grad = None
+                l.backward()
+            for _ in range(3):
+                tstep()
+            torch.cuda.synchronize(dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(nt_ + 1)]
+            for i in range(nt_):
+                ev[i].record()
+                tstep()
+            ev[nt_].record()
+            torch.cuda.synchronize(dev)
+            ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(nt_))
+            per_r[str(Rt)] = {"rays_per_s": round(Rt / (ts[nt_ // 2] * 1e-3), 1), "median_ms": round(ts[nt_ // 2], 2),
+                              "p10_ms": round(ts[nt_ // 10], 2), "p90_ms": round(ts[(9 * nt_) // 10], 2)}
+            del o, d, near, far, gt, mask
+            torch.cuda.empty_cache()
+        tv = max(v["rays_per_s"] for v in per_r.values())      # the stand-in's best batch size is what the >= 10x target divides by
+        sb = result.get("small_batch", {}).get("rays_per_step_per_gpu", {})
+        native = {"4096": value / world if R == 4096 else None, "1024": sb.get("1024"), "512": sb.get("512")}
+        result["torch_gpu_baseline"] = {"value": round(tv, 1), "unit": "rays/s", "per_batch": per_r,
+                                        "sample": "3 warm-up + %d timed iterations at each of 512 / 1024 / 4096 rays x 128 samples (HIP events per iteration, median), plain "
+                                                  "PyTorch-ROCm ops, the oracle restatement in its reference_ops mode (normals by a second SDF forward + "
+                                                  "autograd.grad(create_graph=True) like fields.py:105-115), fwd+bwd, no optimiser" % nt_,
                                         "speedup_at_4096": round(value / world / tv, 2) if R == 4096 else None,
-                                        "speedup_at_equal_batch": round(result.get("small_batch", {}).get("rays_per_step_per_gpu", {}).get("1024", 0.0) / world / tv, 2)
-                                        if not args.no_small_batch else None}
+                                        "speedup_at_equal_batch": {k: round(native[k] / per_r[k]["rays_per_s"], 2) for k in per_r if native.get(k)}}
 
     # ---- CPU baseline: the oracle on the host cores, bounded samples (rank 0, N=1 only)
     if not args.no_cpu_baseline and rank == 0 and world == 1:

@@ -42,7 +42,7 @@ class CnrOutGrads(C.Structure):
 
 
 class CnrKernelTiming(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("kind", C.c_int32), ("nt", C.c_int32), ("P", C.c_long), ("N", C.c_int32),
+    _fields_ = [("name", C.c_char * 32), ("kind", C.c_int32), ("nt", C.c_int32), ("P", C.c_int64), ("N", C.c_int32),
                 ("K", C.c_int32), ("pairs", C.c_int32), ("ms", C.c_float), ("bytes", C.c_double)]
 
 

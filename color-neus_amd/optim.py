@@ -76,6 +76,13 @@ class ClipAdam(torch.optim.Optimizer):
                 st["exp_avg"] = torch.zeros(total, dtype=torch.float32, device=dev)
                 st["exp_avg_sq"] = torch.zeros(total, dtype=torch.float32, device=dev)
                 st["steps"] = [0] * len(allp)
+            if "steps" not in st and "step" in st:
+                # state saved by an earlier build: one step count for the group, moments laid out over the parameters that had gradients.
+                # Loadable when that was every parameter of the group (the renderer's case); otherwise the offsets are not recoverable.
+                if st["exp_avg"].numel() != total:
+                    raise RuntimeError("ClipAdam: cannot migrate a state_dict of the earlier layout whose moments cover only a subset of the "
+                                       "group's parameters (%d of %d elements); restart the optimiser state" % (st["exp_avg"].numel(), total))
+                st["steps"] = [int(st.pop("step"))] * len(allp)
             if st["exp_avg"].numel() != total or len(st["steps"]) != len(allp):
                 raise RuntimeError("ClipAdam: the parameter list of a group changed after the first step")
             b1, b2 = group["betas"]

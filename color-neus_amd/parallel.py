@@ -55,6 +55,14 @@ def sharded_render_image(renderer, rays_o, rays_d, near, far, chunk=1024, group=
     only its own chunks."""
     rank, world = _world(group)
     n = rays_o.shape[0]
+    # row widths of the keys a rank may gather: a rank that owns no chunk must still present a buffer of the right shape to the collective
+    m = int(renderer.rcfg.n_total) if hasattr(renderer, "rcfg") else None
+    widths = {"color_fine": 3, "global_color": 3, "depth": 1, "weight_sum": 1, "weight_max": 1, "s_val": 1}
+    if m is not None:
+        widths.update({"weights": m, "cdf_fine": m, "inside_sphere": m, "z_vals": m, "gradients": 3 * m, "delta_relight": 3 * m})
+    unknown = [k for k in keys if k not in widths]
+    if unknown:
+        raise ValueError(f"sharded_render_image: no per-ray width known for keys {unknown} (gatherable: {sorted(widths)})")
     nchunks = (n + chunk - 1) // chunk
     per = (nchunks + world - 1) // world
     c0, c1 = min(rank * per, nchunks), min((rank + 1) * per, nchunks)
@@ -76,8 +84,9 @@ def sharded_render_image(renderer, rays_o, rays_d, near, far, chunk=1024, group=
     counts = [min(cnt, max(0, n - min(r * per, nchunks) * chunk)) for r, cnt in enumerate(counts)]
     res = {}
     for k in keys:
-        width = {"color_fine": 3}.get(k, 1)
-        local = torch.cat(parts[k], 0) if parts[k] else torch.empty(0, width, dtype=torch.float32, device=rays_o.device)
+        local = torch.cat(parts[k], 0) if parts[k] else torch.empty(0, widths[k], dtype=torch.float32, device=rays_o.device)
+        if local.shape[1] != widths[k]:
+            raise RuntimeError(f"sharded_render_image: key {k} has {local.shape[1]} columns per ray, expected {widths[k]}")
         res[k] = _gather_rows(local, counts, dst, group)
     return res if rank == dst else None
 

@@ -9,6 +9,7 @@ Learnable poses and focal lengths (config/Color_NeuS_iho.yml:18-20) get their gr
 Pixel choice consumes the torch CPU generator exactly like the reference (same calls, same order), so a seeded run picks the same
 pixels: that is the only part left in torch -- it IS the reference's random stream."""
 import ctypes as C
+import os
 import warnings
 
 import torch
@@ -49,6 +50,9 @@ def choose_pixels(n_rays, pixels_per_image, device, mask=None, mask_rate=0.9):
     return chosen[torch.randperm(chosen.shape[0])]
 
 
+_CHECK_INDICES = os.environ.get("CNR_CHECK_INDICES", "0") not in ("", "0")
+
+
 class _GenRays(torch.autograd.Function):
     """autograd edge around cnr_gen_rays / cnr_gen_rays_backward."""
 
@@ -57,17 +61,23 @@ class _GenRays(torch.autograd.Function):
         dev = c2w.device
         c2w_c = c2w.detach().reshape(-1, 4, 4).contiguous().float()
         focal_c = focal.detach().reshape(-1).contiguous().float().to(dev)
-        # every operand is dereferenced on c2w's device: move host-resident batches there (the reference's torch ops would raise a device
-        # mismatch; a raw pointer would be a GPU memory fault) and keep the index list inside the image stack
-        img = image.detach().to(dev).contiguous().float() if image is not None else None
-        msk = mask.detach().to(dev).contiguous().float() if mask is not None else None
+        # every operand is dereferenced on c2w's device.  The image / mask stacks must already live there: moving a host-resident stack
+        # (about 1 GB for DTU) on every step would be a silent per-step upload, so that is an error like the device mismatch the reference's
+        # torch ops would raise; the small operands (focal, origin, the index list) are moved.
+        for name, t in (("image", image), ("mask", mask)):
+            if t is not None and t.device != dev:
+                raise ValueError(f"{name} is on {t.device} but c2w is on {dev}: keep the image / mask stacks on the device that generates the rays")
+        img = image.detach().contiguous().float() if image is not None else None
+        msk = mask.detach().contiguous().float() if mask is not None else None
         org = origin.detach().reshape(-1).contiguous().float().to(dev) if origin is not None else None
         idx = pix_idx.to(dev).contiguous().to(torch.int64) if pix_idx is not None else None
         n_cams = c2w_c.shape[0]
         for name, t in (("image", img), ("mask", msk)):
             if t is not None and t.shape[0] != n_cams:
                 raise ValueError(f"{name} holds {t.shape[0]} cameras but c2w holds {n_cams}")
-        if idx is not None and idx.numel() > 0 and __debug__:
+        # range check of caller-supplied indices: two device-to-host syncs, so only on request (CNR_CHECK_INDICES=1 or check_indices=True
+        # of the public functions); the indices of choose_pixels are in range by construction
+        if idx is not None and idx.numel() > 0 and _CHECK_INDICES:
             lo, hi = int(idx.min()), int(idx.max())
             if lo < 0 or hi >= n_cams * H * W:
                 raise IndexError(f"pixel index range [{lo}, {hi}] outside [0, {n_cams * H * W})")

@@ -119,3 +119,36 @@ def test_clip_adam_intermittent_gradients_emu():
 @pytest.mark.gpu
 def test_clip_adam_intermittent_gradients_hip():
     _run_intermittent(None, "cuda:0")
+
+
+@pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
+def test_clip_adam_loads_state_of_the_previous_layout():
+    """A state_dict saved by the build whose group state held ONE ``step`` count (and no ``steps`` list) resumes: the moments cover every
+    parameter of the group there, so the per-parameter step counts are that count; a layout whose moments cover only a subset is refused
+    with a clear message instead of a KeyError."""
+    g = torch.Generator().manual_seed(4)
+    ps = [torch.randn(40, 7, generator=g).requires_grad_(True), torch.randn(9, generator=g).requires_grad_(True)]
+    a = cn.ClipAdam(ps, lr=1e-3, max_norm=1.0, library=N.EMU_LIB)
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g)
+    a.step(); a.step()
+    sd = a.state_dict()
+    st = sd["state"][0]
+    old = {"exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone(), "step": 2}   # the earlier layout
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    b = cn.ClipAdam(qs, lr=1e-3, max_norm=1.0, library=N.EMU_LIB)
+    b.load_state_dict({"state": {0: old}, "param_groups": sd["param_groups"]})
+    for p, q in zip(ps, qs):
+        gr = torch.randn(p.shape, generator=g)
+        p.grad, q.grad = gr.clone(), gr.clone()
+    a.step(); b.step()
+    for p, q in zip(ps, qs):
+        assert torch.equal(p.detach(), q.detach())
+    assert b.state[qs[0]]["steps"] == [3, 3]
+    c = cn.ClipAdam([q.detach().clone().requires_grad_(True) for q in qs], lr=1e-3, library=N.EMU_LIB)
+    c.load_state_dict({"state": {0: {"exp_avg": old["exp_avg"][:280].clone(), "exp_avg_sq": old["exp_avg_sq"][:280].clone(), "step": 2}},
+                       "param_groups": sd["param_groups"]})
+    for q in c.param_groups[0]["params"]:
+        q.grad = torch.zeros_like(q)
+    with pytest.raises(RuntimeError, match="earlier layout"):
+        c.step()

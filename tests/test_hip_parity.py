@@ -87,7 +87,7 @@ def test_nerfpp_background_fallback(name, tag):
             ref = fx[f"{tag}:out_{k}"]
             assert G.relerr(out[k].detach().cpu().reshape(ref.shape), ref) < TOL, k
     assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
-    bad = G.check_param_grads(fx, tag, grads)   # (torch fallback for the background: loose gate, see _golden.py)
+    bad = G.check_param_grads(fx, tag, grads, strict=True)   # every tensor, nerf.* included: the HIP gate (1 % outliers, 5e-4 cap)
     assert not bad, bad
 
 
@@ -168,9 +168,11 @@ def test_against_oracle_larger_batch():
     out2 = r(o.to(DEV), d.to(DEV), near.to(DEV), far.to(DEV), z_vals=z32.to(DEV))      # G2 at identical z
     # per-sample weights/cdf at inv_s = 665 are not reproducible to 1e-4 in fp32 by ANY implementation: the plain-torch fp32
     # evaluation of the same algorithm (= the reference's arithmetic) is 1.3e-4 away from float64 on this very input.
-    loose = {"weights": 5e-4, "weight_max": 5e-4, "cdf_fine": 5e-4}
+    # Their tolerance is therefore calibrated per tensor: 3 x the float32 oracle's own distance from float64 on this input, at least 1e-4, at most 5e-4.
+    o32 = O.render(P, ocfg, o, d, near, far, z_vals=z32)
+    cal = {k: min(5e-4, max(TOL, 3.0 * G.relerr(o32[k].detach().double(), oo[k].detach()))) for k in ("weights", "weight_max", "cdf_fine")}
     errs = {k: G.relerr(out2[k].detach().cpu().reshape(oo[k].shape), oo[k].detach()) for k in G.OUTPUT_KEYS}
-    bad = {k: e for k, e in errs.items() if not e < loose.get(k, TOL)}
+    bad = {k: (e, cal.get(k, TOL)) for k, e in errs.items() if not e < cal.get(k, TOL)}
     assert not bad, bad
 
 
@@ -402,7 +404,9 @@ def test_full_size_properties_4096_rays():
     _, g_b = run(allr[2048:])
     for k, g in g_all.items():
         err = float((g - (g_a[k] + g_b[k])).abs().max())
-        assert err <= 1e-3 * float(g.abs().max()), (k, err, float(g.abs().max()))   # own scale per tensor
+        # own scale per tensor; measured 2.1e-6 at worst (tools/gate_probe.py: only the summation order over the point ranges and the power-of-two
+        # exponent of the weight-gradient accumulators differ between the whole batch and its halves)
+        assert err <= 1e-5 * float(g.abs().max()), (k, err, float(g.abs().max()))
     # (3) determinism
     _, g_again = run(allr)
     for k, g in g_all.items():

@@ -12,11 +12,15 @@ export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=lib
 # leaks: CPython itself never frees its interned objects; what matters here is out-of-bounds / use-after-free / UB in the library
 export ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1" UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"
 export OMP_NUM_THREADS=4
+TESTS="tests/test_host_emu.py tests/test_edge_batches.py tests/test_sharded_gloo.py tests/test_sampler_functions.py tests/test_marching_cubes.py tests/test_fused_loss.py tests/test_linear_op.py"
 {
   echo "# build $(git -C "$R" rev-parse --short HEAD); g++ $(g++ -dumpversion); -fsanitize=address,undefined on cnr_plan.cpp + cnr_kernels_emu.cpp"
-  echo "# python -m pytest tests/test_host_emu.py tests/test_edge_batches.py tests/test_sharded_gloo.py tests/test_sampler_functions.py tests/test_marching_cubes.py -m 'not gpu'"
-  cd "$R" && python -m pytest tests/test_host_emu.py tests/test_edge_batches.py tests/test_sharded_gloo.py tests/test_sampler_functions.py tests/test_marching_cubes.py \
-      -q -x -m "not gpu" -p no:cacheprovider 2>&1 | grep -v "Warning\|warn" | tail -15
-  echo "# exit status of pytest: ${PIPESTATUS[0]}"
+  echo "# python -m pytest $TESTS -m 'not gpu'"
+  cd "$R" && python -m pytest $TESTS -q -x -m "not gpu" -p no:cacheprovider 2>&1 | grep -v "Warning\|warn" | tail -15
+  ST=${PIPESTATUS[0]}
+  echo "# exit status of pytest: $ST"
+  echo "$ST" > "$LOG.status"
 } > "$LOG" 2>&1
 cat "$LOG"
+ST=$(cat "$LOG.status"); rm -f "$LOG.status"
+exit "$ST"
