@@ -1,0 +1,78 @@
+// Device helpers shared by the chain-fused kernels (cnr_chain.hip: value-only SDF chain; cnr_chain_fwd.hip: the saving forward chains).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cnr_backend.h"
+#include "cnr_hip_util.h"
+#include "cnr_gemm_int.h"
+
+namespace cnr {
+
+constexpr int CH_ALD = 256 * 2 + 16;   // bytes per LDS row of one plane (+16: conflict-free ds_read_b128 of the fragments)
+
+// ------------------------------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------------------------------
+// exact power-of-two scale that lifts a row's largest |element| into the top f16 binade (same rule as WS_PUT_SET in cnr_gemm_ws.h)
+__device__ __forceinline__ float chain_row_scale(float mx) {
+  float sc = 1.0f;
+  if (mx > 0.0f && mx < 3.0e38f) {
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 126;   // frexpf exponent (subnormals land below the clamp)
+    if (e < -100) e = -100;
+    sc = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+  }
+  return sc;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global access (s_waitcnt
+// vmcnt(0)), i.e. it would wait for the weight blocks prefetched for the next layer at both barriers of every layer.  Global data
+// written by one wave is never read by another wave of the same launch, so no global ordering is needed.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two elements per VALU issue).  The epilogue of a layer runs
+// with every wave of the workgroup in the same phase (the barriers keep MFMA and epilogue phases in lockstep), so its VALU
+// instruction count is wall time: measured on 2 M points, 6.57 ms = 3.44 ms of MFMA + 3.13 ms of everything else.
+// (tools/probes/overlap_probe.hip: VALU work of one wave does hide behind the MFMAs of the OTHER wave of its SIMD -- 12 MFMAs 223 ns,
+// 96 VALU 334 ns, both 386 ns -- but two workgroups per CU running the same phases at the same time gain nothing from it.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 pk_splat(float x) { f2 r = {x, x}; return r; }
+
+// nn.Softplus(beta=100, threshold=20) on two elements: max(z,0) + log2(1 + 2^(-|100 z| / ln 2)) * ln 2 / 100 (see cnr_common.h)
+__device__ __forceinline__ f2 softplus100_pk(f2 z) {
+  const f2 m = z * pk_splat(144.26950408889634f);
+  f2 e;
+  e.x = __builtin_amdgcn_exp2f(-fabsf(m.x)); e.y = __builtin_amdgcn_exp2f(-fabsf(m.y));   // (the sign / abs modifiers are free)
+  const f2 s = e + pk_splat(1.0f);
+  f2 l, r;
+  l.x = __builtin_amdgcn_logf(s.x); l.y = __builtin_amdgcn_logf(s.y);
+  r.x = fmaxf(z.x, 0.0f); r.y = fmaxf(z.y, 0.0f);
+  return pk_fma(l, pk_splat(0.0069314718055994531f), r);
+}
+
+// 16 consecutive columns of one row -> hi / lo f16 planes (two 16-byte LDS stores per plane)
+__device__ __forceinline__ void chain_put16(const f32x16& a, float sc, unsigned char* dst, int aplane) {
+  h2 hi[8], lo[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    f2 x = {a[2 * q], a[2 * q + 1]};
+    x = x * pk_splat(sc);
+    hi[q] = __builtin_convertvector(x, h2);
+    const f2 back = __builtin_convertvector(hi[q], f2);
+    lo[q] = __builtin_convertvector(x - back, h2);
+  }
+  f16x8 h1a = {hi[0][0], hi[0][1], hi[1][0], hi[1][1], hi[2][0], hi[2][1], hi[3][0], hi[3][1]};
+  f16x8 h1b = {hi[4][0], hi[4][1], hi[5][0], hi[5][1], hi[6][0], hi[6][1], hi[7][0], hi[7][1]};
+  f16x8 h2a = {lo[0][0], lo[0][1], lo[1][0], lo[1][1], lo[2][0], lo[2][1], lo[3][0], lo[3][1]};
+  f16x8 h2b = {lo[4][0], lo[4][1], lo[5][0], lo[5][1], lo[6][0], lo[6][1], lo[7][0], lo[7][1]};
+  *reinterpret_cast<f16x8*>(dst) = h1a;
+  *reinterpret_cast<f16x8*>(dst + 16) = h1b;
+  *reinterpret_cast<f16x8*>(dst + aplane) = h2a;
+  *reinterpret_cast<f16x8*>(dst + aplane + 16) = h2b;
+}
+
+
+}  // namespace cnr
