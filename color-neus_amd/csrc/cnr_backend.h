@@ -188,6 +188,38 @@ struct SdfValueChain {   // sdf = SDFNetwork.sdf(x) from the embedding rows E (f
 };
 bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s);   // false: not handled (backend without fused kernels / unsupported shape)
 
+// The SAVING forward chains of the ReLU stacks (colour network fields.py:161-188, relight network fields.py:332-368) in ONE launch
+// (cnr_chain_fwd.hip): a 128-point tile goes through colour lin0..lin(NC-2) + the rgb head, then relight in_layer + rl_mlp[0..NR-2] + the
+// relight head, without the activations leaving the CU between layers; every hidden layer's ReLU output is stored once for the backward
+// pass (rows transposed through LDS into full 128-byte lines), the row scales of the layer inputs with it.
+constexpr int kChainSteps = 12;
+struct ChainFwdStep {
+  const unsigned short* Wf = nullptr;   // fragment-major f16 planes of the layer (FusedLayer::Wf layout, nkb_w k16 blocks per column block)
+  const float* wsc = nullptr;           // per output column: 1 / weight row scale (256 readable)
+  const float* bias = nullptr;          // per output column (256 readable)
+  int nkb_w = 0;                        // ldw / 16
+  int nkb_main = 0;                     // k16 blocks of the main input segment: 16 (a 256-wide row) or 1..3 (a narrow global input)
+  int nkb_x = 0;                        // k16 blocks of the extra segment (W columns from 16 * nkb_main on): 0..3
+  const float* in = nullptr; int ld_in = 0;   // main segment = columns [0, 16 nkb_main) of these global rows; null: the previous step's ReLU output (on chip)
+  int x_src = 0;                        // extra segment: 1 = columns [16 nkb_main, 16 (nkb_main + nkb_x)) of the same global row,
+                                        // 2 = the colour head's output kept on chip ([rgb | 0...], the relight y-layer's input tail)
+  float* save = nullptr; int ld_save = 0;     // [P][ld_save]: ReLU output of this step (256 columns)
+  float* rs_in = nullptr;               // optional [P]: power-of-two scale of this step's whole input row (LayerGemm::rs_out convention)
+  int head = 0;                         // 1 / 2: the colour / relight head follows this step (end of a chain)
+};
+struct ChainFwdHead { const float* W = nullptr; int ldw = 0; const float* bias = nullptr; int n = 0; };   // fp32 effective weights [n <= 4][ldw >= 256]
+struct ReluChainFwd {
+  long P = 0; int nsteps = 0; ChainFwdStep st[kChainSteps];
+  ChainFwdHead col_head; int col_squeeze = 1;           // rgb = sigmoid(.) (EK_SIGMOID) or plain (EK_LINEAR_SIG)
+  float* gcol = nullptr;                                // [P][4]
+  float* rgb_tail = nullptr; int ld_tail = 0;           // optional: rgb_tail[row * ld_tail + c] = rgb (c < n) or 0 (c < 16): the relight y-layer's input tail
+  ChainFwdHead rel_head; int inv_sigmoid = 1;
+  float* delta = nullptr;                               // [P][3] relight offsets (pre-activation)
+  float* relit = nullptr;                               // [P][4] relight_apply(rgb, delta)
+  int dbg = 0;                                          // ablation switches (CNR_CHAIN_FWD_DBG; wrong results): 1 no saves, 2 no MFMAs, 4 stores without the LDS pass, 8 no global stores
+};
+bool be_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s);   // false: not handled (per-layer launches instead)
+
 void be_layer_gemm(const LayerGemm& g, cnr_stream s);
 void be_dw_gemm(const DwGemm& g, cnr_stream s);
 // Layer launch g + the single-pair weight gradient d (X[0] = the launch's input view, Y[0] = the operand its epilogue derives from its side

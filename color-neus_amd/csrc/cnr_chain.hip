@@ -94,21 +94,8 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
   const long ntiles = (c.P + T - 1) / T;
 
   f16x8 wr1[4][CB], wr2[4][CB];                              // weight fragment ring: 4 k16 blocks in flight
-  auto wload = [&](int slot, const unsigned short* base, int nkb, int kb) {
-#pragma unroll
-    for (int j = 0; j < CB; ++j) {
-      const unsigned short* b = base + ((long)(j * nkb + kb) * 2 * 64 + lane) * 8;
-      wr1[slot][j] = *reinterpret_cast<const f16x8*>(b);
-      wr2[slot][j] = *reinterpret_cast<const f16x8*>(b + 512);
-    }
-  };
-  auto wprime = [&](const FusedLayer& L) {
-    const int nkb = L.K >> 4;
-    const unsigned short* base = L.Wf + (long)wave * CB * nkb * 1024;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) wload(q, base, nkb, q);      // (every layer has at least 3 blocks)
-    if (nkb > 3) wload(3, base, nkb, 3);
-  };
+  auto wlane_of = [&](const FusedLayer& L) { return L.Wf + (long)wave * CB * (L.K >> 4) * 1024 + lane * 8; };
+  auto wprime = [&](const FusedLayer& L) { chain_wprime<CB>(wr1, wr2, wlane_of(L), L.K >> 4, 0, L.K >> 4); };
   auto cw_fetch = [&](const FusedLayer& L) {                 // threads 0..127: one float4 of [column scales (256) | biases (256)]
     f4 v = {0.f, 0.f, 0.f, 0.f};
     if (tid < 64) v = *reinterpret_cast<const f4*>(L.wsc + tid * 4);
@@ -150,7 +137,7 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
       const FusedLayer& L = c.lay[l];
       const int nkb = L.K >> 4;
       const bool last = l + 1 == c.nl;
-      const unsigned short* wbase = L.Wf + (long)wave * CB * nkb * 1024;
+      const unsigned short* wlane = wlane_of(L);
       const f4 cw_next = cw_fetch(c.lay[last ? l : l + 1]);   // lands while the MFMAs run; parked in LDS behind the row-max barrier
       f32x16 acc[CB][RT];
 #pragma unroll
@@ -160,36 +147,10 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[j][rt][r] = 0.0f;
       const unsigned char* Ab = smem + pt * CH_ALD + half * 16;
-      // The k16 blocks of a layer are straight-line code (block count pinned at compile time): with a run-time guard around each
-      // block the compiler waits for ALL outstanding loads (vmcnt(0)) at every block and cannot hoist the LDS fragment reads of the
-      // next block over the MFMAs of the current one.
-      auto mfma_blocks = [&](auto nkb_c) {
-        constexpr int NKB = decltype(nkb_c)::value;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          f16x8 a1[RT], a2[RT];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            a1[rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + kb * 32);
-            a2[rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + APLANE + kb * 32);
-          }
-#pragma unroll
-          for (int j = 0; j < CB; ++j)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr2[kb & 3][j], a1[rt], acc[j][rt], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < CB; ++j)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[kb & 3][j], a2[rt], acc[j][rt], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < CB; ++j)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[kb & 3][j], a1[rt], acc[j][rt], 0, 0, 0);
-          if (kb + 4 < NKB) wload(kb & 3, wbase, NKB, kb + 4);   // refill the slot its MFMAs have just read (no register copy)
-        }
-      };
-      if (nkb == 16) mfma_blocks(std::integral_constant<int, 16>());
-      else mfma_blocks(std::integral_constant<int, 3>());
+      // The k16 blocks of a layer are straight-line code (block count pinned at compile time), weight ring four blocks deep, scheduling fence
+      // per block (chain_mfma_blocks in cnr_chain_util.h)
+      if (nkb == 16) chain_mfma_blocks<RT, CB, 16>(acc, wr1, wr2, Ab, APLANE, wlane, 16, 0);
+      else chain_mfma_blocks<RT, CB, 3>(acc, wr1, wr2, Ab, APLANE, wlane, 3, 0);
       // the next layer's (or the next tile's first layer's) leading weight blocks travel while the epilogue runs
       wprime(last ? c.lay[0] : c.lay[l + 1]);
 

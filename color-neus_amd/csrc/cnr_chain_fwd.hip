@@ -1,0 +1,371 @@
+// Chain-fused SAVING forward kernels for gfx950 (MI355X / CDNA4): the ReLU stacks of the render path (colour network, relight network)
+// in ONE launch.  A workgroup carries a tile of 32 * RT points through every layer of both stacks; between layers the activations stay on
+// the CU as two f16 planes in LDS (the chain-fused value kernel's scheme, cnr_chain.hip: error-free hi / lo split of the exactly
+// power-of-two scaled fp32 row, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation, weights streamed from L2 in MFMA-fragment
+// order four k16 blocks ahead, TRANSPOSED product so that a lane owns one point x 16 consecutive output columns).
+//
+// What the forward pass must leave behind for the backward pass -- every hidden layer's ReLU output (1 KB per point and layer) and the
+// row scales of the layer inputs -- is what sank the first saving variant of the chain kernel (commit eeb54d9): in the transposed layout a
+// lane holds a 64-byte piece of a row, a wave-wide 16-byte store touches 64 different 64-byte segments, and such stores drain at about
+// 8 B/clk/CU.  Here every wave passes its 32 x 32 output block through a private 2 KB LDS buffer, 16 rows at a time (XOR-swizzled 16-byte
+// chunks: conflict-free both ways), and stores it as 8 rows x 128 contiguous bytes per instruction -- full cache lines, the store pattern
+// of the per-layer kernel's epilogue.
+//
+// Against the per-layer launches this removes, per point: the read-back of every hidden activation (7 x 1 KB), the second read of the
+// 3-wide heads' input (2 x 1 KB), 9 launches, and for the narrow inputs (relight in_layer: 48 columns; colour layer 0: 256 + 16..48
+// columns; relight y-layer: 256 + 3) the special launches that re-read 1 KB/point tensors for a 48-column product.
+//
+// Layers whose input is wider than 256 columns (colour layer 0: [feat | p g PE(v)], relight y-layer: [h | rgb]) run as TWO input
+// segments through the same LDS planes: the 256 main columns, then -- one barrier later -- the 16..48 extra columns staged over them, the
+// accumulators carried across.  Both segments share ONE row scale (the power of two of the whole input row, as the per-layer kernel
+// forms it), so no accumulator rescaling is needed and the k16 blocks are summed in the per-layer kernel's order.
+// The 3-wide heads (rgb, relight offset) are fp32 dot products of the last hidden layer's ReLU output while it is still in registers;
+// rgb stays in LDS for the relight y-layer and the relight head's inverse-sigmoid combination.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "cnr_backend.h"
+#include "cnr_hip_util.h"
+#include "cnr_gemm_int.h"
+#include "cnr_chain_util.h"
+
+namespace cnr {
+
+// the scale a row's consumers get (LayerGemm::rs_out convention): 0 for an all-zero row, NaN for a non-finite one
+__device__ __forceinline__ float chain_rs_value(float mx, float sc) { return (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); }
+
+template <int RT>
+__global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainFwd c) {
+  constexpr int T = 32 * RT;
+  constexpr int APLANE = T * CH_ALD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* rs = reinterpret_cast<float*>(smem + 2 * APLANE);   // [T] 1 / row scale of the current step's input
+  float* rsf = rs + T;                                       // [T] the row scale itself (the extra segment is staged with it)
+  float* pm = rsf + T;                                       // [T][8] per-wave partial row maxima
+  float* cwb = pm + T * 8;                                   // [2][512] column scales | biases of the current / next step
+  float* rgbs = cwb + 1024;                                  // [T][4] output of the colour head (rgb, 0)
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // (scalar: the per-wave bases below stay in SGPRs)
+  unsigned char* tb = reinterpret_cast<unsigned char*>(rgbs + T * 4) + wave * 2048;   // this wave's [16 rows][128 B] transposition buffer
+  float* hp = reinterpret_cast<float*>(smem);                // [T][8][4] partial head dot products (in the planes: dead at the end of a chain)
+  const long ntiles = (c.P + T - 1) / T;
+
+  f16x8 wr1[4][1], wr2[4][1];                                // weight fragment ring: 4 k16 blocks in flight
+  auto wlane_of = [&](const ChainFwdStep& S, int lane_) __attribute__((always_inline)) { return S.Wf + (long)wave * S.nkb_w * 1024 + lane_ * 8; };
+  auto cw_fetch = [&](const ChainFwdStep& S, int tid) __attribute__((always_inline)) {      // threads 0..127: one float4 of [column scales (256) | biases (256)]
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) v = *reinterpret_cast<const f4*>(S.wsc + tid * 4);
+    else if (tid < 128) v = *reinterpret_cast<const f4*>(S.bias + (tid - 64) * 4);
+    return v;
+  };
+
+  chain_wprime<1>(wr1, wr2, wlane_of(c.st[0], tid0 & 63), c.st[0].nkb_w, 0, c.st[0].nkb_main);
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (tid0 < 128) *reinterpret_cast<f4*>(cwb + tid0 * 4) = cw_fetch(c.st[0], tid0);
+    for (int s = 0; s < c.nsteps; ++s) {
+      // The thread index is laundered once per step: every per-lane LDS / global offset below is derived from it, so the compiler recomputes
+      // them per step (a few integer operations) instead of hoisting dozens of loop-invariant addresses out of the loops and spilling them.
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, half = lane >> 5, pt = lane & 31;
+      const int cbase = wave * 32 + 16 * half;               // this lane's 16 consecutive output columns
+      const ChainFwdStep& S = c.st[s];
+      const bool last_step = s + 1 == c.nsteps;
+      const ChainFwdStep& Sn = c.st[last_step ? 0 : s + 1];
+      const unsigned short* wlane = wlane_of(S, lane);
+      const f4 cw_next = cw_fetch(Sn, tid);                       // lands while the MFMAs run; parked in LDS behind the row-max barrier
+      // ---- a chain starts: its input rows HBM -> registers -> exact row scale -> f16 planes (16 threads per row, 4 columns each)
+      if (S.in != nullptr) {
+        const int ncol = 16 * S.nkb_main, xcol = S.x_src == 1 ? 16 * S.nkb_x : 0;
+        const long tile0 = tile * T;
+        const int rows_left = (int)((c.P - tile0) < T ? (c.P - tile0) : T);          // rows of this tile that exist (>= 1)
+        const float* in_tile = S.in + tile0 * S.ld_in;                               // (uniform: scalar base + 32-bit lane offsets)
+        // all loads of the RT row groups first (one exposed memory round trip per chain start, not RT), then the conversion
+        const int sc4 = (tid & 15) * 4;
+        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f4 v0[RT], v1[RT], v2[RT], v3[RT], vx[RT];
+#pragma unroll
+        for (int pass = 0; pass < RT; ++pass) {
+          const int row_l = pass * 32 + (tid >> 4);
+          const int row_c = row_l < rows_left ? row_l : rows_left - 1;               // rows past the end read the last row (never stored)
+          const float* src = in_tile + row_c * S.ld_in;
+          v0[pass] = z4; v1[pass] = z4; v2[pass] = z4; v3[pass] = z4; vx[pass] = z4;
+          if (sc4 < ncol) v0[pass] = *reinterpret_cast<const f4*>(src + sc4);
+          if (64 + sc4 < ncol) v1[pass] = *reinterpret_cast<const f4*>(src + 64 + sc4);
+          if (128 + sc4 < ncol) v2[pass] = *reinterpret_cast<const f4*>(src + 128 + sc4);
+          if (192 + sc4 < ncol) v3[pass] = *reinterpret_cast<const f4*>(src + 192 + sc4);
+          if (sc4 < xcol) vx[pass] = *reinterpret_cast<const f4*>(src + ncol + sc4);   // (only its magnitude is used here: one scale for the whole row)
+        }
+#pragma unroll
+        for (int pass = 0; pass < RT; ++pass) {
+          const int row_l = pass * 32 + (tid >> 4);
+          float mx = fmaxf(fmaxf(fmaxf(ws_absmax4(v0[pass]), ws_absmax4(v1[pass])), fmaxf(ws_absmax4(v2[pass]), ws_absmax4(v3[pass]))), ws_absmax4(vx[pass]));
+#pragma unroll
+          for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+          const float sc = chain_row_scale(mx);
+          unsigned char* dst = smem + row_l * CH_ALD + sc4 * 2;
+          if (sc4 < ncol) chain_put4(v0[pass], sc, dst, APLANE);
+          if (64 + sc4 < ncol) chain_put4(v1[pass], sc, dst + 128, APLANE);
+          if (128 + sc4 < ncol) chain_put4(v2[pass], sc, dst + 256, APLANE);
+          if (192 + sc4 < ncol) chain_put4(v3[pass], sc, dst + 384, APLANE);
+          if ((tid & 15) == 0) {
+            rs[row_l] = 1.0f / sc; rsf[row_l] = sc;
+            if (S.rs_in != nullptr && row_l < rows_left) S.rs_in[tile0 + row_l] = chain_rs_value(mx, sc);
+          }
+        }
+        lds_barrier();
+      }
+
+      f32x16 acc1[1][RT];
+      f32x16 (&acc)[RT] = acc1[0];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
+      const unsigned char* Ab = smem + pt * CH_ALD + half * 16;
+      // k16 blocks as straight-line code, ring four blocks deep, one scheduling fence per block (chain_mfma_blocks); kb0: first block of the phase in W
+      auto mfma_phase = [&](int nkb, int kb0) __attribute__((always_inline)) {
+        if (nkb == 16) chain_mfma_blocks<RT, 1, 16>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, kb0);
+        else if (nkb == 3) chain_mfma_blocks<RT, 1, 3>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, kb0);
+        else if (nkb == 2) chain_mfma_blocks<RT, 1, 2>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, kb0);
+        else chain_mfma_blocks<RT, 1, 1>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, kb0);
+      };
+      if (!(c.dbg & 2)) mfma_phase(S.nkb_main, 0);
+      if (S.nkb_x > 0) {
+        // ---- the extra input columns, staged over the main ones with the SAME row scale
+        chain_wprime<1>(wr1, wr2, wlane, S.nkb_w, S.nkb_main, S.nkb_x);
+        lds_barrier();                                        // every wave is done reading the main segment
+#pragma unroll
+        for (int pass = 0; pass < RT; ++pass) {
+          const int row_l = pass * 32 + (tid >> 4), sc4 = (tid & 15) * 4;
+          if (sc4 < 16 * S.nkb_x) {
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (S.x_src == 1) {
+              const long tile0 = tile * T;
+              const int rows_left = (int)((c.P - tile0) < T ? (c.P - tile0) : T);
+              const int row_c = row_l < rows_left ? row_l : rows_left - 1;
+              v = *reinterpret_cast<const f4*>(S.in + tile0 * S.ld_in + row_c * S.ld_in + 16 * S.nkb_main + sc4);
+            } else if (sc4 == 0) {
+              v = *reinterpret_cast<const f4*>(rgbs + row_l * 4);
+            }
+            chain_put4(v, rsf[row_l], smem + row_l * CH_ALD + sc4 * 2, APLANE);
+          }
+        }
+        lds_barrier();
+        if (!(c.dbg & 2)) {
+          if (S.nkb_x == 3) chain_mfma_blocks<RT, 1, 3>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, S.nkb_main);
+          else if (S.nkb_x == 2) chain_mfma_blocks<RT, 1, 2>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, S.nkb_main);
+          else chain_mfma_blocks<RT, 1, 1>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, S.nkb_main);
+        }
+      }
+      // the next step's (or the next tile's first step's) leading weight blocks travel while the epilogue runs
+      chain_wprime<1>(wr1, wr2, wlane_of(Sn, lane), Sn.nkb_w, 0, Sn.nkb_main);
+
+      // ---- epilogue: a = relu(acc / (row scale * column scale) + bias) ; row max
+      const float* cw = cwb + (s & 1) * 512;
+      const bool chain_end = S.head != 0;                     // a head follows: the next step (if any) starts from global rows
+      {
+        f4 wsc4[4], b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          wsc4[q] = *reinterpret_cast<const f4*>(cw + cbase + 4 * q);
+          b4[q] = *reinterpret_cast<const f4*>(cw + 256 + cbase + 4 * q);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row_l = rt * 32 + pt;
+          const f2 rsc = pk_splat(rs[row_l]);
+          float mx = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const f2 w = {wsc4[q >> 1][(2 * q) & 3], wsc4[q >> 1][(2 * q + 1) & 3]};
+            const f2 b = {b4[q >> 1][(2 * q) & 3], b4[q >> 1][(2 * q + 1) & 3]};
+            f2 a = {acc[rt][2 * q], acc[rt][2 * q + 1]};
+            a = pk_fma(a, rsc * w, b);
+            a.x = fmaxf(a.x, 0.0f); a.y = fmaxf(a.y, 0.0f);
+            acc[rt][2 * q] = a.x; acc[rt][2 * q + 1] = a.y;
+            mx = fmaxf(fmaxf(a.x, a.y), mx);
+          }
+          if (!chain_end) {
+            const float other = __shfl_xor(mx, 32);
+            if (half == 0) pm[row_l * 8 + wave] = fmaxf(mx, other);
+          }
+        }
+      }
+      lds_barrier();   // partial maxima visible; every wave is done reading the planes of this step's input
+      if (tid < 128) *reinterpret_cast<f4*>(cwb + ((last_step ? 0 : s + 1) & 1) * 512 + tid * 4) = cw_next;
+      if (!chain_end) {
+        // ---- the next step's input planes (its extra segment, if it comes from the colour head, shares the row scale)
+        const bool with_rgb = Sn.x_src == 2;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row_l = rt * 32 + pt;
+          float mx = pm[row_l * 8];
+#pragma unroll
+          for (int w = 1; w < 8; ++w) mx = fmaxf(mx, pm[row_l * 8 + w]);
+          if (with_rgb) { const f4 g = *reinterpret_cast<const f4*>(rgbs + row_l * 4); mx = fmaxf(mx, ws_absmax4(g)); }
+          const float sc = chain_row_scale(mx);
+          chain_put16(acc[rt], sc, smem + row_l * CH_ALD + cbase * 2, APLANE);
+          if (wave == 0 && half == 0) {
+            rs[row_l] = 1.0f / sc; rsf[row_l] = sc;
+            const long grow = tile * T + row_l;
+            if (Sn.rs_in != nullptr && grow < c.P) Sn.rs_in[grow] = chain_rs_value(mx, sc);
+          }
+        }
+      }
+      // ---- the ReLU output rows for the backward pass: 32 x 32 block -> LDS (16 rows at a time) -> 8 rows x 128 contiguous bytes per store
+      if (S.save != nullptr && !(c.dbg & 1)) {
+        const long tile0 = tile * T;
+        const int rows_left = (int)((c.P - tile0) < T ? (c.P - tile0) : T);
+        float* save_tile = S.save + tile0 * S.ld_save + wave * 32;                   // (uniform)
+        const int sv_off = (lane >> 3) * S.ld_save + (lane & 7) * 4;                 // this lane's row / 16-byte chunk within an 8-row group
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+          for (int hpass = 0; hpass < 2; ++hpass) {
+            if ((pt >> 4) == hpass) {
+              const int r = pt & 15;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f4 v = {acc[rt][4 * q], acc[rt][4 * q + 1], acc[rt][4 * q + 2], acc[rt][4 * q + 3]};
+                *reinterpret_cast<f4*>(tb + r * 128 + (((4 * half + q) ^ (r & 7)) << 4)) = v;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int r = (lane >> 3) + 8 * i, ch = lane & 7;
+              const f4 v = *reinterpret_cast<const f4*>(tb + r * 128 + ((ch ^ (r & 7)) << 4));
+              const int row0 = rt * 32 + hpass * 16 + 8 * i;                         // first row of this 8-row group within the tile
+              if (row0 + (lane >> 3) < rows_left && !(c.dbg & 8)) *reinterpret_cast<f4*>(save_tile + row0 * S.ld_save + sv_off) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+      if (chain_end) {
+        // ---- the 3-wide head on the ReLU output still in registers: fp32 dot products, partial sums per (row, wave) in a fixed order
+        const ChainFwdHead& H = S.head == 1 ? c.col_head : c.rel_head;
+#pragma unroll 1
+        for (int j = 0; j < 3; ++j) {
+          f4 wj[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            wj[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (j < H.n) wj[q] = *reinterpret_cast<const f4*>(H.W + (long)j * H.ldw + cbase + 4 * q);
+          }
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            float dot = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot = fmaf(acc[rt][r], wj[r >> 2][r & 3], dot);
+            dot += __shfl_xor(dot, 32);
+            if (half == 0) hp[((rt * 32 + pt) * 8 + wave) * 4 + j] = dot;
+          }
+        }
+        lds_barrier();
+        if (tid < T) {
+          const int row_l = tid;
+          const long grow = tile * T + row_l;
+          float v[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            float sum = hp[(row_l * 8) * 4 + j];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) sum += hp[(row_l * 8 + w) * 4 + j];
+            v[j] = j < H.n ? sum + H.bias[j] : 0.0f;
+          }
+          if (S.head == 1) {
+            f4 y = {0.f, 0.f, 0.f, 0.f};
+            y.x = c.col_squeeze ? sigmoidf_(v[0]) : v[0];
+            if (H.n > 1) y.y = c.col_squeeze ? sigmoidf_(v[1]) : v[1];
+            if (H.n > 2) y.z = c.col_squeeze ? sigmoidf_(v[2]) : v[2];
+            *reinterpret_cast<f4*>(rgbs + row_l * 4) = y;
+            if (grow < c.P) {
+              float* g = c.gcol + grow * 4;
+              g[0] = y.x;
+              if (H.n > 1) g[1] = y.y;
+              if (H.n > 2) g[2] = y.z;
+              if (c.rgb_tail != nullptr) {
+                const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+                f4* t = reinterpret_cast<f4*>(c.rgb_tail + grow * c.ld_tail);
+                t[0] = y; t[1] = z4; t[2] = z4; t[3] = z4;
+              }
+            }
+          } else if (grow < c.P) {
+            const f4 rgb = *reinterpret_cast<const f4*>(rgbs + row_l * 4);
+            const float rv[3] = {rgb.x, rgb.y, rgb.z};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              if (j < H.n) {
+                c.delta[grow * 3 + j] = v[j];
+                c.relit[grow * 4 + j] = relight_apply(rv[j], v[j], c.inv_sigmoid);
+              }
+            }
+          }
+        }
+      }
+      lds_barrier();
+    }
+  }
+}
+
+template <int RT>
+static void launch_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
+  constexpr int T = 32 * RT;
+  const size_t lds = (size_t)2 * T * CH_ALD + (size_t)T * (2 + 8 + 4) * sizeof(float) + (size_t)1024 * sizeof(float) + (size_t)8 * 2048;
+  static DeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relu_chain_fwd_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const long ntiles = (c.P + T - 1) / T;
+  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
+  const long wgs = wgs_env > 0 ? wgs_env : 256;   // persistent, one workgroup per CU
+  const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
+  double macs = 0.0, bytes = 0.0;
+  for (int i = 0; i < c.nsteps; ++i) {
+    const ChainFwdStep& S = c.st[i];
+    macs += 16.0 * (S.nkb_main + S.nkb_x) * 256.0;
+    if (S.in) bytes += (double)c.P * 4.0 * 16.0 * (S.nkb_main + (S.x_src == 1 ? S.nkb_x : 0));
+    if (S.save) bytes += (double)c.P * 1024.0;
+    if (S.rs_in) bytes += (double)c.P * 4.0;
+    if (S.head) bytes += (double)c.P * (S.head == 1 ? (c.rgb_tail ? 80.0 : 16.0) : 28.0);
+  }
+  TimingScope ts_("chain_fwd", 3, RT * 10 + 1, c.P, (int)(macs / 256.0), 256, 1, s, bytes);
+  static const int dbg = getenv("CNR_CHAIN_FWD_DBG") ? atoi(getenv("CNR_CHAIN_FWD_DBG")) : 0;
+  ReluChainFwd cc = c;
+  cc.dbg = dbg;
+  hipLaunchKernelGGL((relu_chain_fwd_kernel<RT>), dim3(grid), dim3(512), lds, s, cc);
+}
+
+bool be_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
+  static const bool off = getenv("CNR_NO_FUSED") != nullptr || getenv("CNR_NO_CHAIN_FWD") != nullptr;   // debugging aids: per-layer launches
+  if (off || c.P <= 0 || c.nsteps < 1 || c.nsteps > kChainSteps) return false;
+  for (int i = 0; i < c.nsteps; ++i) {
+    const ChainFwdStep& S = c.st[i];
+    const bool main_ok = S.in != nullptr ? (S.nkb_main == 16 || (S.nkb_main >= 1 && S.nkb_main <= 3)) : S.nkb_main == 16;
+    if (!S.Wf || !S.wsc || !S.bias || !main_ok || S.nkb_x < 0 || S.nkb_x > 3 || S.nkb_main + S.nkb_x > S.nkb_w) return false;
+    if (S.nkb_x > 0 && S.x_src != 1 && S.x_src != 2) return false;
+    if (S.x_src == 1 && (S.in == nullptr || (S.ld_in & 3) != 0 || S.ld_in < 16 * (S.nkb_main + S.nkb_x))) return false;
+    if (S.in != nullptr && ((S.ld_in & 3) != 0 || S.ld_in < 16 * S.nkb_main)) return false;
+    if (S.x_src == 2 && S.nkb_x != 1) return false;
+    if (S.save != nullptr && (S.ld_save & 3) != 0) return false;
+    if (i == 0 && S.in == nullptr) return false;
+    if (i > 0 && c.st[i - 1].head != 0 && S.in == nullptr) return false;   // a chain starts from global rows
+    if (S.head == 1 && (!c.col_head.W || c.col_head.n < 1 || c.col_head.n > 3 || (c.col_head.ldw & 3) || !c.gcol || (c.rgb_tail && (c.ld_tail & 3)))) return false;
+    if (S.head == 2 && (!c.rel_head.W || c.rel_head.n < 1 || c.rel_head.n > 3 || (c.rel_head.ldw & 3) || !c.delta || !c.relit)) return false;
+  }
+  if (c.st[c.nsteps - 1].head == 0) return false;
+  static const int force = getenv("CNR_CHAIN_FWD_RT") ? atoi(getenv("CNR_CHAIN_FWD_RT")) : 0;   // tuning aid: 4, 2, 1
+  const int rt = force ? force : (c.P >= 256L * 128 ? 4 : (c.P >= 256L * 64 ? 2 : 1));
+  if (rt == 4) launch_relu_chain_fwd<4>(c, s);
+  else if (rt == 2) launch_relu_chain_fwd<2>(c, s);
+  else launch_relu_chain_fwd<1>(c, s);
+  CNR_LAUNCH_CHECK("chain_fwd");
+  return true;
+}
+
+}  // namespace cnr

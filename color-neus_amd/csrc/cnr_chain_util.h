@@ -53,6 +53,18 @@ __device__ __forceinline__ f2 softplus100_pk(f2 z) {
   return pk_fma(l, pk_splat(0.0069314718055994531f), r);
 }
 
+// 4 consecutive columns of one row -> hi / lo f16 planes (the per-layer kernel's ws_put4)
+__device__ __forceinline__ void chain_put4(const f4& v, float sc, unsigned char* dst, int aplane) {
+  f16x4 h1, h2;
+  float x;
+  x = v.x * sc; h1[0] = (_Float16)x; h2[0] = (_Float16)(x - (float)h1[0]);
+  x = v.y * sc; h1[1] = (_Float16)x; h2[1] = (_Float16)(x - (float)h1[1]);
+  x = v.z * sc; h1[2] = (_Float16)x; h2[2] = (_Float16)(x - (float)h1[2]);
+  x = v.w * sc; h1[3] = (_Float16)x; h2[3] = (_Float16)(x - (float)h1[3]);
+  *reinterpret_cast<f16x4*>(dst) = h1;
+  *reinterpret_cast<f16x4*>(dst + aplane) = h2;
+}
+
 // 16 consecutive columns of one row -> hi / lo f16 planes (two 16-byte LDS stores per plane)
 __device__ __forceinline__ void chain_put16(const f32x16& a, float sc, unsigned char* dst, int aplane) {
   h2 hi[8], lo[8];
@@ -74,5 +86,66 @@ __device__ __forceinline__ void chain_put16(const f32x16& a, float sc, unsigned 
   *reinterpret_cast<f16x8*>(dst + aplane + 16) = h2b;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One MFMA phase of a chain-fused kernel: NKB k16 blocks of the transposed product acc[j][rt] += W_frag(kb) x Act_frag(kb, rt) as straight-line
+// code (3 x v_mfma_f32_32x32x16_f16 per product: hi x lo, lo x hi, hi x hi).
+//   * the weight fragments come from a 4-deep register ring: blocks kb0 .. kb0 + 3 must already be in flight (chain_wprime); block kb + 4 is
+//     requested as soon as the MFMAs of block kb have read their slot;
+//   * the activation fragments of block kb + 1 are read from LDS into a second register set BEFORE the MFMAs of block kb;
+//   * a scheduling fence closes every block.  Without it the compiler sinks each weight load down to its first use (load, s_waitcnt vmcnt(0),
+//     MFMA -- checked in the ISA of both chain kernels), i.e. every k16 block waits for an L2 round trip and the "ring" is one block deep.
+// Wf layout: [column block cb][k16 block kb (nkb_w per column block)][plane][lane][8]; wbase = this wave's first column block + lane * 8.
+// ------------------------------------------------------------------------------------------------
+template <int CB>
+__device__ __forceinline__ void chain_wload(f16x8 (&wr1)[4][CB], f16x8 (&wr2)[4][CB], int slot, const unsigned short* wlane, int nkb_w, int kb) {
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const unsigned short* b = wlane + (long)(j * nkb_w + kb) * 1024;
+    wr1[slot][j] = *reinterpret_cast<const f16x8*>(b);
+    wr2[slot][j] = *reinterpret_cast<const f16x8*>(b + 512);
+  }
+}
+// the first four blocks of a phase of n >= 1 blocks (index clamped: a shorter phase loads its last block again -- no branch between the loads)
+template <int CB>
+__device__ __forceinline__ void chain_wprime(f16x8 (&wr1)[4][CB], f16x8 (&wr2)[4][CB], const unsigned short* wlane, int nkb_w, int kb0, int n) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) chain_wload<CB>(wr1, wr2, q, wlane, nkb_w, kb0 + (q < n ? q : n - 1));
+}
+template <int RT, int CB, int NKB>
+__device__ __forceinline__ void chain_mfma_blocks(f32x16 (&acc)[CB][RT], f16x8 (&wr1)[4][CB], f16x8 (&wr2)[4][CB], const unsigned char* Ab, int aplane,
+                                                  const unsigned short* wlane, int nkb_w, int kb0) {
+  f16x8 a1[2][RT], a2[2][RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    a1[0][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD);
+    a2[0][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + aplane);
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int cur = kb & 1;
+    if (kb + 1 < NKB) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        a1[cur ^ 1][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + (kb + 1) * 32);
+        a2[cur ^ 1][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + aplane + (kb + 1) * 32);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr2[kb & 3][j], a1[cur][rt], acc[j][rt], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[kb & 3][j], a2[cur][rt], acc[j][rt], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[kb & 3][j], a1[cur][rt], acc[j][rt], 0, 0, 0);
+    if (kb + 4 < NKB) chain_wload<CB>(wr1, wr2, kb & 3, wlane, nkb_w, kb0 + kb + 4);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 }  // namespace cnr

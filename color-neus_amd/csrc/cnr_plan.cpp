@@ -254,7 +254,7 @@ static void place_lin(Lin& q, Arena& a) {
   q.Wtp = reinterpret_cast<unsigned short*>(a.f((size_t)q.kpad * q.ldwt));
   q.Wps = a.f(q.wpad > 256 ? q.wpad : 256);   // (the fused kernels read 256 column scales; entries >= npad are never used)
   q.Wtps = a.f(q.kpad);
-  q.Wf = (q.ldw <= 256) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldw / 16) * 2 * 64 * 8 / 2)) : nullptr;
+  q.Wf = (q.ldw <= 304) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldw / 16) * 2 * 64 * 8 / 2)) : nullptr;   // (<= 19 k16 blocks: 256 + 48)
 }
 
 static void layout_weights(Model& m, Arena& a) {
@@ -411,6 +411,9 @@ static void prep_all(Model& m, const float* const* params, cnr_stream s) {
   be_split_planes_many(sj.data(), (int)sj.size(), s);       // their f16 planes (W and W^T): one launch
   std::vector<PackJob> pj;
   for (auto& q : m.sdf) if (q.Wf) pj.push_back(PackJob{q.Wp, (long)q.wpad * q.ldw, q.wpad, q.ldw, q.Wf});
+  // the hidden layers of the ReLU stacks (chain-fused forward, cnr_chain_fwd.hip); their 3-wide heads stay fp32
+  for (auto& q : m.col) if (q.Wf && q.n == 256) pj.push_back(PackJob{q.Wp, (long)q.wpad * q.ldw, q.wpad, q.ldw, q.Wf});
+  for (auto& q : m.rel) if (q.Wf && q.n == 256) pj.push_back(PackJob{q.Wp, (long)q.wpad * q.ldw, q.wpad, q.ldw, q.Wf});
   be_pack_frags_many(pj.data(), (int)pj.size(), s);         // fragment-major copies for the chain-fused kernels: one launch
 }
 
@@ -627,6 +630,75 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
   }
 }
 
+// Colour chain + relight chain as ONE chain-fused launch (cnr_chain_fwd.hip) where the shapes allow: 256-wide hidden layers, a 256-wide
+// feature vector, heads of <= 3 outputs.  Returns false (nothing launched) otherwise: the per-layer chains above then run.
+static bool relu_chains_fused(const Model& m, long P, const Ctx& x, float* delta_out, cnr_stream s) {
+  if (m.Hc != 256 || m.F != 256 || m.NC < 2 || m.NC - 1 + (m.has_relight ? m.NR : 0) > kChainSteps) return false;
+  ReluChainFwd c;
+  c.P = P;
+  auto hidden_ok = [](const Lin& q, int k_lo, int k_hi) { return q.n == 256 && q.Wf && q.wpad >= 256 && q.k_int >= k_lo && q.k_int <= k_hi; };
+  auto head_ok = [](const Lin& q) { return q.n >= 1 && q.n <= 3 && q.k_int == 256 && (q.ldw & 3) == 0; };
+  auto fill = [](ChainFwdStep& st, const Lin& q) { st.Wf = q.Wf; st.wsc = q.Wps; st.bias = q.bias; st.nkb_w = q.ldw / 16; };
+  int n = 0;
+  // ---- colour: lin0 takes [feat (256) | p g PE(view) (ldw - 256 columns of the aux part)], lin1.. the hidden vector
+  for (int l = 0; l + 1 < m.NC; ++l) {
+    const Lin& q = m.col[l];
+    ChainFwdStep& st = c.st[n++];
+    fill(st, q);
+    if (l == 0) {
+      if (!hidden_ok(q, 257, 304) || q.ldw > x.ldfx) return false;
+      st.in = x.featx; st.ld_in = x.ldfx; st.nkb_main = 16; st.nkb_x = q.ldw / 16 - 16; st.x_src = 1;
+    } else {
+      if (!hidden_ok(q, 256, 256) || q.ldw != 256) return false;
+      st.nkb_main = 16;
+    }
+    st.save = x.HC[l]; st.ld_save = m.Hc;
+    st.rs_in = (size_t)l < x.rsC.size() ? x.rsC[l] : nullptr;
+  }
+  c.st[n - 1].head = 1;
+  {
+    const Lin& q = m.col[m.NC - 1];
+    if (!head_ok(q)) return false;
+    c.col_head = ChainFwdHead{q.W, q.ldw, q.bias, q.n};
+    c.col_squeeze = m.c.col_squeeze_out ? 1 : 0;
+    c.gcol = x.gcol;
+    if (m.has_relight) { c.rgb_tail = x.hry + m.Hr; c.ld_tail = x.ldy; }
+  }
+  if (m.has_relight) {
+    if (m.Hr != 256 || m.NR < 2) return false;
+    const int y = m.c.rel_y_in_layer - 1;                    // rl_mlp[y] takes [h | rgb]
+    if (y < 1 || y > m.NR - 2) return false;                 // (y == 0 would put the tail on the in_layer's output; the head takes no tail)
+    {
+      const Lin& q = m.rel[0];
+      if (q.n != 256 || !q.Wf || q.ldw > kAux || q.ldw < 16) return false;
+      ChainFwdStep& st = c.st[n++];
+      fill(st, q);
+      st.in = x.AUX; st.ld_in = kAux; st.nkb_main = q.ldw / 16;
+      st.save = x.HR[0]; st.ld_save = hr_ld(m, x, 0);
+    }
+    for (int i = 0; i + 1 < m.NR; ++i) {
+      const Lin& q = m.rel[1 + i];
+      ChainFwdStep& st = c.st[n++];
+      fill(st, q);
+      st.nkb_main = 16;
+      if (i == y) {
+        if (!hidden_ok(q, 257, 259) || q.ldw != 272) return false;
+        st.nkb_x = 1; st.x_src = 2;
+      } else if (!hidden_ok(q, 256, 256) || q.ldw != 256) return false;
+      st.save = x.HR[i + 1]; st.ld_save = hr_ld(m, x, i + 1);
+      st.rs_in = (size_t)i < x.rsR.size() ? x.rsR[i] : nullptr;
+    }
+    c.st[n - 1].head = 2;
+    const Lin& q = m.rel[m.NR];
+    if (!head_ok(q) || q.n != m.col[m.NC - 1].n) return false;
+    c.rel_head = ChainFwdHead{q.W, q.ldw, q.bias, q.n};
+    c.inv_sigmoid = m.c.rel_inv_sigmoid;
+    c.delta = delta_out; c.relit = x.relit;
+  }
+  c.nsteps = n;
+  return be_relu_chain_fwd(c, s);
+}
+
 static int check_backend(const char* what) {
   char msg[256];
   if (be_check_last_error(msg, sizeof msg) != 0) return fail("%s: %s", what, msg);
@@ -711,8 +783,10 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
     be_prune_scatter(sc, s);
   } else {
     RangeScope r_("colour + relight chains");
-    color_chain(m, P, x, s);
-    if (m.has_relight) relight_chain(m, P, x, delta_out, s);
+    if (!relu_chains_fused(m, P, x, delta_out, s)) {
+      color_chain(m, P, x, s);
+      if (m.has_relight) relight_chain(m, P, x, delta_out, s);
+    }
   }
   RangeScope r_comp("compositor");
   be_composite_fwd(cf, s);
