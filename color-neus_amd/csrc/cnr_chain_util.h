@@ -112,38 +112,41 @@ __device__ __forceinline__ void chain_wprime(f16x8 (&wr1)[4][CB], f16x8 (&wr2)[4
 #pragma unroll
   for (int q = 0; q < 4; ++q) chain_wload<CB>(wr1, wr2, q, wlane, nkb_w, kb0 + (q < n ? q : n - 1));
 }
-template <int RT, int CB, int NKB>
+// KB0 / NTOT: this call covers the k16 blocks [KB0, KB0 + NKB) of a phase of NTOT blocks (a phase may be cut into several calls with a
+// workgroup barrier in between: the ring slots and the refill rule follow the block index within the phase; KB0 a multiple of 4).
+template <int RT, int CB, int NKB, int KB0 = 0, int NTOT = NKB>
 __device__ __forceinline__ void chain_mfma_blocks(f32x16 (&acc)[CB][RT], f16x8 (&wr1)[4][CB], f16x8 (&wr2)[4][CB], const unsigned char* Ab, int aplane,
                                                   const unsigned short* wlane, int nkb_w, int kb0) {
+  static_assert((KB0 & 3) == 0 && KB0 + NKB <= NTOT, "chain_mfma_blocks: block range");
   f16x8 a1[2][RT], a2[2][RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    a1[0][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD);
-    a2[0][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + aplane);
+    a1[0][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + KB0 * 32);
+    a2[0][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + aplane + KB0 * 32);
   }
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
-    const int cur = kb & 1;
+    const int cur = kb & 1, gk = KB0 + kb;
     if (kb + 1 < NKB) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        a1[cur ^ 1][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + (kb + 1) * 32);
-        a2[cur ^ 1][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + aplane + (kb + 1) * 32);
+        a1[cur ^ 1][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + (gk + 1) * 32);
+        a2[cur ^ 1][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + aplane + (gk + 1) * 32);
       }
     }
 #pragma unroll
     for (int j = 0; j < CB; ++j)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr2[kb & 3][j], a1[cur][rt], acc[j][rt], 0, 0, 0);
+      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr2[gk & 3][j], a1[cur][rt], acc[j][rt], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < CB; ++j)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[kb & 3][j], a2[cur][rt], acc[j][rt], 0, 0, 0);
+      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[gk & 3][j], a2[cur][rt], acc[j][rt], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < CB; ++j)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[kb & 3][j], a1[cur][rt], acc[j][rt], 0, 0, 0);
-    if (kb + 4 < NKB) chain_wload<CB>(wr1, wr2, kb & 3, wlane, nkb_w, kb0 + kb + 4);
+      for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[gk & 3][j], a1[cur][rt], acc[j][rt], 0, 0, 0);
+    if (gk + 4 < NTOT) chain_wload<CB>(wr1, wr2, gk & 3, wlane, nkb_w, kb0 + gk + 4);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
