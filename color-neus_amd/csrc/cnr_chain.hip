@@ -78,6 +78,11 @@ void be_pack_frags_many(const PackJob* jobs, int count, cnr_stream s) {
 //           Measured equal to <4, 1> (6.5 ms for 2 M points): the two workgroups start together, do identical work and stay in phase
 //           (both in the MFMA phase, then both in the epilogue), also when half of them are started a few microseconds late;
 //   <1, 2>  32-point tiles for small point counts (fills the chip from 8192 points).
+// Tried and dropped (round 4, commit 52bf6b3): two 4-wave groups per workgroup, each on its own 64-point half tile (<2, 2> per group), group 1
+// running two barriers behind group 0 so that on every SIMD one wave is in an MFMA phase while the other is in an epilogue phase -- enforced by
+// the barriers (4 per layer), with the weight ring pinned four blocks deep.  Bit-identical, and no faster: 1.57 ms against 1.55 ms per step for
+// the sampler's chains, the same for a delay of 0, 1, 2 or 3 barriers.  MFMA time and epilogue time add up whatever the phase relation; the
+// chip runs these kernels at 1.9-2.1 GHz of its 2.4 GHz (GRBM_GUI_ACTIVE / duration), i.e. it is at its power limit either way.
 // ------------------------------------------------------------------------------------------------
 template <int RT, int CB>
 __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_kernel(const SdfValueChain c) {
@@ -246,258 +251,14 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same chain with the MFMA phase of one half tile facing the epilogue of the other on every SIMD ("skewed" form).
-//
-// In the kernel above all 8 waves of a workgroup run the same phase at the same time: the matrix pipe idles during the epilogues (softplus,
-// split, LDS writes) and the VALU idles during the MFMA blocks -- 3.44 ms + 3.13 ms of a 6.57 ms call, and two workgroups per CU lock into
-// the same phases as well.  Here the workgroup's 128-point tile is cut into two 64-point halves, each owned by a GROUP of 4 waves (a wave =
-// 2 blocks of 32 columns x 2 blocks of 32 rows: the same 12 MFMAs per k16 block and wave); waves w and w + 4 share a SIMD, so every SIMD
-// hosts one wave of each group.  A layer is four phases -- M1 | M2 (k16 blocks 0..7 | 8..15), E1 (epilogue math, partial row maxima),
-// E2 (row maximum, next planes) -- every phase ends with the workgroup barrier, and group 1 runs two phases behind group 0: whenever one
-// group is in an MFMA phase the other one is in an epilogue phase, enforced by the barriers rather than hoped for.
-// The weights are streamed once per GROUP (4 KB of L2 reads per point and layer instead of 2).  Same arithmetic as the kernel above
-// (same scales, same MFMA order per output element): results are bit-identical to it.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void sdf_value_chain_skew_kernel(const SdfValueChain c, int delay) {
-  constexpr int RT = 2, CB = 2, HT = 64, T = 128;
-  constexpr int APLANE = HT * CH_ALD, GPL = 2 * APLANE;      // one group's two planes
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid0 = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), grp = wave >> 2, wg = wave & 3;
-  unsigned char* gp = smem + grp * GPL;                                        // this group's planes
-  float* rs = reinterpret_cast<float*>(smem + 2 * GPL) + grp * HT;             // [HT] 1 / row scale of the current layer input
-  float* pm = reinterpret_cast<float*>(smem + 2 * GPL) + 2 * HT + grp * HT * 4;   // [HT][4] per-wave partial row maxima / dot products
-  float* cwb = reinterpret_cast<float*>(smem + 2 * GPL) + 2 * HT + 2 * HT * 4 + grp * 512;   // [512] column scales | biases of the layer in flight
-  float* wtop = reinterpret_cast<float*>(smem + 2 * GPL) + 2 * HT + 2 * HT * 4 + 1024;       // [256] sdf row of the top layer (shared)
-  const long ntiles = (c.P + T - 1) / T;
-  const long my_tiles = blockIdx.x < ntiles ? (ntiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-
-  f16x8 wr1[4][CB], wr2[4][CB];
-  f32x16 acc[CB][RT];
-  auto wlane_of = [&](const FusedLayer& L, int lane_) __attribute__((always_inline)) { return L.Wf + (long)(wg * CB) * (L.K >> 4) * 1024 + lane_ * 8; };
-  chain_wprime<CB>(wr1, wr2, wlane_of(c.lay[0], tid0 & 63), c.lay[0].K >> 4, 0, c.lay[0].K >> 4);
-  for (int i = tid0; i < 256; i += 512) wtop[i] = c.wtop[i];
-  __syncthreads();
-  // Both groups run the SAME straight-line loop; group 1 simply enters it `delay` barriers late and group 0 leaves `delay` barriers late (the
-  // hardware barrier counts arrivals, not program locations).  Every phase ends with the workgroup barrier: 4 per layer.
-  if (grp) for (int d = 0; d < delay; ++d) lds_barrier();
-  // phases 3 and 4 of a layer (epilogue math | row maximum + next planes), each closed by the workgroup barrier
-  auto epilogue = [&](const int l, const long row0, const int tid) __attribute__((always_inline)) {
-    const int tg = tid & 255, lane = tid & 63, half = lane >> 5, pt = lane & 31;
-    const int cbase = wg * 64 + 16 * half;                   // this lane's 16 consecutive output columns of its j-th block: cbase + 32 j
-    const FusedLayer& L = c.lay[l];
-    const bool last = l + 1 == c.nl;
-      // ---- phase 3, epilogue math: z = acc * (1 / row scale) * (1 / column scale) + bias ; a = softplus(z) ; skip concat ; partial row max / dot
-    {
-      const bool next_skip = !last && ((c.skip_mask >> (l + 1)) & 1);
-      const float oscale = next_skip ? kInvSqrt2 : 1.0f;
-      const bool ragged = L.N < 256;
-      float red[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) red[rt] = 0.0f;
-      float rsc_[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) rsc_[rt] = rs[rt * 32 + pt];
-#pragma unroll
-      for (int j = 0; j < CB; ++j) {
-        const int c0 = cbase + 32 * j;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f4 wq = *reinterpret_cast<const f4*>(cwb + c0 + 4 * q);
-          const f4 bq = *reinterpret_cast<const f4*>(cwb + 256 + c0 + 4 * q);
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            const f2 rsc = pk_splat(rsc_[rt]);
-            f2 lo = {acc[j][rt][4 * q], acc[j][rt][4 * q + 1]}, hi = {acc[j][rt][4 * q + 2], acc[j][rt][4 * q + 3]};
-            lo = pk_fma(lo, rsc * f2{wq.x, wq.y}, f2{bq.x, bq.y});
-            hi = pk_fma(hi, rsc * f2{wq.z, wq.w}, f2{bq.z, bq.w});
-            lo = softplus100_pk(lo); hi = softplus100_pk(hi);
-            if (next_skip) { lo = lo * pk_splat(kInvSqrt2); hi = hi * pk_splat(kInvSqrt2); }
-            acc[j][rt][4 * q] = lo.x; acc[j][rt][4 * q + 1] = lo.y; acc[j][rt][4 * q + 2] = hi.x; acc[j][rt][4 * q + 3] = hi.y;
-          }
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const int row_l = rt * 32 + pt;
-          if (ragged && c0 + 16 > L.N) {
-            // columns >= N (only the lanes that own them enter): [softplus(z) | e] / sqrt(2) for a skip layer (fields.py:86-87), zero otherwise
-            long grow = row0 + row_l; if (grow >= c.P) grow = c.P - 1;
-            const float* erow = c.E + grow * kEmb;
-            float ev[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const int ei = c0 + r - L.N; ev[r] = erow[ei < 0 ? 0 : (ei < kEmb ? ei : kEmb - 1)]; }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int ei = c0 + r - L.N;
-              const float tail = (next_skip && ei < c.emb) ? ev[r] * oscale : 0.0f;
-              acc[j][rt][r] = ei < 0 ? acc[j][rt][r] : tail;
-            }
-          }
-          float mx = 0.0f, dot = 0.0f;
-          if (last) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f4 wt = *reinterpret_cast<const f4*>(wtop + c0 + 4 * q);
-              dot = fmaf(acc[j][rt][4 * q], wt.x, dot); dot = fmaf(acc[j][rt][4 * q + 1], wt.y, dot);
-              dot = fmaf(acc[j][rt][4 * q + 2], wt.z, dot); dot = fmaf(acc[j][rt][4 * q + 3], wt.w, dot);
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(fabsf(acc[j][rt][r]), fabsf(acc[j][rt][r + 1])), mx);
-          }
-          red[rt] = last ? red[rt] + dot : fmaxf(red[rt], mx);
-        }
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const float other = __shfl_xor(red[rt], 32);
-        if (half == 0) pm[(rt * 32 + pt) * 4 + wg] = last ? red[rt] + other : fmaxf(red[rt], other);
-      }
-    }
-    lds_barrier();
-    // ---- phase 4: row maximum -> scale -> the next layer's planes; after the last layer the sdf value
-    if (!last) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int row_l = rt * 32 + pt;
-        const f4 p4 = *reinterpret_cast<const f4*>(pm + row_l * 4);
-        const float mx = fmaxf(fmaxf(p4.x, p4.y), fmaxf(p4.z, p4.w));
-        const float sc = chain_row_scale(mx);
-#pragma unroll
-        for (int j = 0; j < CB; ++j) chain_put16(acc[j][rt], sc, gp + row_l * CH_ALD + (cbase + 32 * j) * 2, APLANE);
-        if (wg == 0 && half == 0) rs[row_l] = 1.0f / sc;
-      }
-    } else if (tg < HT) {
-      // sdf = (softplus(z_top-1) . w_sdf + b_sdf) * top_scale: the per-wave partial sums in a fixed order
-      const f4 p4 = *reinterpret_cast<const f4*>(pm + tg * 4);
-      const float sum = ((p4.x + p4.y) + p4.z) + p4.w;
-      const long grow = row0 + tg;
-      if (grow < c.P) c.sdf_out[grow] = (sum + c.btop[0]) * c.top_scale;
-    }
-    lds_barrier();
-  };
-  auto cw_fetch = [&](const FusedLayer& L, const int tg) __attribute__((always_inline)) {
-    f4 v = {0.f, 0.f, 0.f, 0.f};                              // column scales | biases of a layer: requested early, parked in LDS after the MFMAs
-    if (tg < 64) v = *reinterpret_cast<const f4*>(L.wsc + tg * 4);
-    else if (tg < 128) v = *reinterpret_cast<const f4*>(L.bias + (tg - 64) * 4);
-    return v;
-  };
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < CB; ++j)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][rt][r] = 0.0f;
-  };
-  for (long tile_i = 0; tile_i < my_tiles; ++tile_i) {
-    const long row0 = (blockIdx.x + tile_i * gridDim.x) * T + grp * HT;       // first point of this group's half tile
-    {
-      // ---- layer 0 (3 k16 blocks): phase 1 stages the input rows (E -> planes: 16 threads per row, 4 columns each, 16 rows per pass)
-      // (the thread index is laundered per layer: per-lane offsets are recomputed instead of being hoisted out of the loops and spilled)
-      int tid = tid0;
-      asm volatile("" : "+v"(tid));
-      const int tg = tid & 255, lane = tid & 63, half = lane >> 5, pt = lane & 31;
-      const FusedLayer& L = c.lay[0];
-      const f4 cw_next = cw_fetch(L, tg);
-      f4 v[4];
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int row_l = pass * 16 + (tg >> 4), sc4 = (tg & 15) * 4;
-        long grow = row0 + row_l; if (grow >= c.P) grow = c.P - 1;
-        v[pass] = f4{0.f, 0.f, 0.f, 0.f};
-        if (sc4 < kEmb) v[pass] = *reinterpret_cast<const f4*>(c.E + grow * kEmb + sc4);
-      }
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int row_l = pass * 16 + (tg >> 4), sc4 = (tg & 15) * 4;
-        float mx = ws_absmax4(v[pass]);
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
-        const float sc = chain_row_scale(mx);
-        if (sc4 < kEmb) chain_put4(v[pass], sc, gp + row_l * CH_ALD + sc4 * 2, APLANE);
-        if ((tg & 15) == 0) rs[row_l] = 1.0f / sc;
-      }
-      lds_barrier();
-      zero_acc();
-      chain_mfma_blocks<RT, CB, 3>(acc, wr1, wr2, gp + pt * CH_ALD + half * 16, APLANE, wlane_of(L, lane), 3, 0);
-      chain_wprime<CB>(wr1, wr2, wlane_of(c.lay[1], lane), c.lay[1].K >> 4, 0, c.lay[1].K >> 4);
-      if (tg < 128) *reinterpret_cast<f4*>(cwb + tg * 4) = cw_next;
-      lds_barrier();
-      epilogue(0, row0, tid);
-    }
-    for (int l = 1; l < c.nl; ++l) {
-      int tid = tid0;
-      asm volatile("" : "+v"(tid));
-      const int tg = tid & 255, lane = tid & 63, half = lane >> 5, pt = lane & 31;
-      const FusedLayer& L = c.lay[l];
-      const unsigned char* Ab = gp + pt * CH_ALD + half * 16;
-      const f4 cw_next = cw_fetch(L, tg);
-      zero_acc();
-      // ---- phase 1: k16 blocks 0..7 ; phase 2: blocks 8..15, then the next layer's (or the next tile's first layer's) leading weight blocks
-      // are requested: they travel while the epilogue phases run
-      chain_mfma_blocks<RT, CB, 8, 0, 16>(acc, wr1, wr2, Ab, APLANE, wlane_of(L, lane), 16, 0);
-      lds_barrier();
-      chain_mfma_blocks<RT, CB, 8, 8, 16>(acc, wr1, wr2, Ab, APLANE, wlane_of(L, lane), 16, 0);
-      {
-        const FusedLayer& Ln = c.lay[l + 1 == c.nl ? 0 : l + 1];
-        chain_wprime<CB>(wr1, wr2, wlane_of(Ln, lane), Ln.K >> 4, 0, Ln.K >> 4);
-      }
-      if (tg < 128) *reinterpret_cast<f4*>(cwb + tg * 4) = cw_next;
-      lds_barrier();
-      epilogue(l, row0, tid);
-    }
-  }
-  if (!grp) for (int d = 0; d < delay; ++d) lds_barrier();
-}
-
-static void launch_sdf_value_chain_skew(const SdfValueChain& c, cnr_stream s) {
-  constexpr int T = 128;
-  const size_t lds = (size_t)4 * 64 * CH_ALD + (size_t)(128 + 128 * 4 + 1024 + 256) * sizeof(float);
-  static DeviceOnce attr_once;
-  if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_value_chain_skew_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const long ntiles = (c.P + T - 1) / T;
-  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
-  const long wgs = wgs_env > 0 ? wgs_env : 256;
-  const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
-  static const int delay = getenv("CNR_CHAIN_SKEW_DELAY") ? atoi(getenv("CNR_CHAIN_SKEW_DELAY")) : 2;   // tuning aid: phases group 1 runs behind group 0
-  double macs = 0.0;
-  for (int l = 0; l < c.nl; ++l) macs += (double)c.lay[l].K * 256.0;
-  TimingScope ts_("chain_sdf_value", 3, 99, c.P, (int)(macs / 256.0), 256, 1, s, (double)c.P * (kEmb + 1) * 4.0);
-  hipLaunchKernelGGL(sdf_value_chain_skew_kernel, dim3(grid), dim3(512), lds, s, c, delay);
-}
-
-template <int RT, int CB>
-static void launch_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
-  constexpr int T = 32 * RT, THREADS = 512 / CB;
-  const size_t lds = (size_t)2 * T * CH_ALD + (size_t)T * 9 * sizeof(float) + (size_t)(1024 + 256) * sizeof(float);
-  static DeviceOnce attr_once;
-  if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_value_chain_kernel<RT, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const long ntiles = (c.P + T - 1) / T;
-  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
-  const long wgs = wgs_env > 0 ? wgs_env : (lds * 2 <= 160 * 1024 ? 512 : 256);   // persistent: as many workgroups as the chip holds at once
-  const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
-  double macs = 0.0;
-  for (int l = 0; l < c.nl; ++l) macs += (double)c.lay[l].K * 256.0;
-  TimingScope ts_("chain_sdf_value", 3, RT * 10 + CB, c.P, (int)(macs / 256.0), 256, 1, s, (double)c.P * (kEmb + 1) * 4.0);
-  hipLaunchKernelGGL((sdf_value_chain_kernel<RT, CB>), dim3(grid), dim3(THREADS), lds, s, c);
-}
-
 bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
   static const bool off = getenv("CNR_NO_FUSED") != nullptr;   // debugging aid: per-layer kernels everywhere
   if (off || c.P <= 0) return false;
   for (int l = 0; l < c.nl; ++l)
     if ((c.lay[l].K != 256 && c.lay[l].K != 48) || c.lay[l].N > 256 || c.lay[l].N < 1) return false;   // k16 block counts the kernel pins
-  static const int force = getenv("CNR_CHAIN_SHAPE") ? atoi(getenv("CNR_CHAIN_SHAPE")) : 0;   // tuning aid: 99 (skewed groups), 41, 22, 12
-  // the skewed form pins its phase table on a 48-wide first layer followed by 256-wide ones
-  bool skew_ok = c.nl >= 2 && c.lay[0].K == 48;
-  for (int l = 1; l < c.nl; ++l) skew_ok = skew_ok && c.lay[l].K == 256;
-  const int shape = force ? force : (c.P >= 256L * 128 ? (skew_ok ? 99 : 41) : (c.P >= 256L * 64 ? 22 : 12));
-  if (shape == 99 && skew_ok) launch_sdf_value_chain_skew(c, s);
-  else if (shape == 41 || shape == 99) launch_sdf_value_chain<4, 1>(c, s);
+  static const int force = getenv("CNR_CHAIN_SHAPE") ? atoi(getenv("CNR_CHAIN_SHAPE")) : 0;   // tuning aid: 41, 22, 12
+  const int shape = force ? force : (c.P >= 256L * 128 ? 41 : (c.P >= 256L * 64 ? 22 : 12));
+  if (shape == 41) launch_sdf_value_chain<4, 1>(c, s);
   else if (shape == 22) launch_sdf_value_chain<2, 2>(c, s);
   else launch_sdf_value_chain<1, 2>(c, s);
   CNR_LAUNCH_CHECK("chain_sdf_value");
