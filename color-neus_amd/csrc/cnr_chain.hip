@@ -251,6 +251,23 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
   }
 }
 
+template <int RT, int CB>
+static void launch_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
+  constexpr int T = 32 * RT, THREADS = 512 / CB;
+  const size_t lds = (size_t)2 * T * CH_ALD + (size_t)T * 9 * sizeof(float) + (size_t)(1024 + 256) * sizeof(float);
+  static DeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_value_chain_kernel<RT, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const long ntiles = (c.P + T - 1) / T;
+  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
+  const long wgs = wgs_env > 0 ? wgs_env : (lds * 2 <= 160 * 1024 ? 512 : 256);   // persistent: as many workgroups as the chip holds at once
+  const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
+  double macs = 0.0;
+  for (int l = 0; l < c.nl; ++l) macs += (double)c.lay[l].K * 256.0;
+  TimingScope ts_("chain_sdf_value", 3, RT * 10 + CB, c.P, (int)(macs / 256.0), 256, 1, s, (double)c.P * (kEmb + 1) * 4.0);
+  hipLaunchKernelGGL((sdf_value_chain_kernel<RT, CB>), dim3(grid), dim3(THREADS), lds, s, c);
+}
+
 bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
   static const bool off = getenv("CNR_NO_FUSED") != nullptr;   // debugging aid: per-layer kernels everywhere
   if (off || c.P <= 0) return false;
