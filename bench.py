@@ -85,13 +85,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the render path has no CPU fallback)"
-    # CNR_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than ranks (ranks then share
-    # devices, collectives go through the host); the measured configuration is always one rank per GPU over RCCL ("nccl")
-    backend = os.environ.get("CNR_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    # CNR_BENCH_EMU_LIB=<tests/_build/libcolorneus_emu.so>: TEST INFRASTRUCTURE ONLY (tests/test_bench_harness.py).  The harness -- rank set-up, ray
+    # sharding, collectives, the JSON line -- then runs on CPU tensors with the CPU emulation of the kernel layer and gloo, so that the code the
+    # driver launches on an 8-GPU node is exercised where no GPU exists.  The line says "emulation": true and is never a measurement.
+    emu = os.environ.get("CNR_BENCH_EMU_LIB")
+    if emu:
+        backend = "gloo"
+        dev = torch.device("cpu")
+        torch.set_num_threads(2)
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the render path has no CPU fallback)"
+        # CNR_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than ranks (ranks then share
+        # devices, collectives go through the host); the measured configuration is always one rank per GPU over RCCL ("nccl")
+        backend = os.environ.get("CNR_BENCH_BACKEND", "nccl")
+        dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -104,10 +113,12 @@ def main():
 
     cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)   # Color_NeuS_dtu.yml
     torch.manual_seed(0)
-    renderer = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(dev)
+    renderer = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg, library=emu) if emu else cn.ColorNeuSRenderer(cfg)).to(dev)
     params0 = params = list(renderer.parameters())
-    lib = cn.load_library()
-    assert lib.backend == "hip-gfx950"
+    lib = cn.load_library(emu) if emu else cn.load_library()
+    assert emu or lib.backend == "hip-gfx950"
+    if emu:   # every extra leg measures the GPU: off
+        args.no_roofline = args.no_small_batch = args.no_torch_gpu_baseline = args.no_inference = args.no_c5 = args.no_cpu_baseline = args.no_loss_only = True
     if args.torch_optim:
         opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.99), fused=True)
     else:   # config/Color_NeuS_dtu.yml: adam, LR 5e-4, GRAD_CLIP NORM 1.0 TYPE 2 per parameter tensor
@@ -121,12 +132,19 @@ def main():
     else:
         R = args.rays
     M = cfg.n_total
-    o_all, d_all, near_all, far_all, rgb_all, mask_all = synthetic.synthetic_view(seed=1 + rank, device=dev)
+    strong = args.scaling == "strong"
+    # weak scaling: every rank renders rays of its own view; strong scaling (BASELINE C4): ONE batch of --rays-total rays of one view, rank r
+    # takes rows [r R, (r + 1) R) of it and of its jitter draw -- the N-rank step is then the single-process step on the same batch
+    o_all, d_all, near_all, far_all, rgb_all, mask_all = synthetic.synthetic_view(seed=1 if strong else 1 + rank, device=dev)
     n_all = o_all.shape[0]
     perm = torch.randperm(n_all, generator=torch.Generator().manual_seed(7)).to(dev)
 
     def batch(i, r):
-        idx = perm[(i * r) % (n_all - r):(i * r) % (n_all - r) + r]
+        if strong:
+            rg = r * world
+            idx = perm[(i * rg) % (n_all - rg):(i * rg) % (n_all - rg) + rg][rank * r:(rank + 1) * r]
+        else:
+            idx = perm[(i * r) % (n_all - r):(i * r) % (n_all - r) + r]
         return o_all[idx], d_all[idx], near_all[idx], far_all[idx], rgb_all[idx], mask_all[idx]
 
     torch.manual_seed(2)   # jitter stream (CPU generator, like the reference)
@@ -137,7 +155,10 @@ def main():
         o, d, near, far, gt, mask = batch(i, r)
         rnd, params, opt = alt if alt is not None else (renderer, params0, opt0)
         M = rnd.rcfg.n_total
-        out = rnd(o, d, near, far, training_outputs=outputs)
+        if strong and world > 1:   # the whole batch's jitter draw, this rank's rows (every rank consumes the CPU generator like one process would)
+            out = rnd(o, d, near, far, training_outputs=outputs, t_rand=parallel.draw_jitter(rg, rank, world, "cpu"))
+        else:
+            out = rnd(o, d, near, far, training_outputs=outputs)
         if args.torch_loss:    # the torch restatement of compute_loss (and its sharded counterpart)
             if world == 1:
                 loss, _ = cn.compute_loss(out, gt, mask)
@@ -157,17 +178,19 @@ def main():
         return loss
 
     def sync():
-        torch.cuda.synchronize(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
 
     def timed(nsteps, warmup, r=None, alt=None, per_step=None, outputs="dict"):
         for i in range(warmup):
             step(i, r, alt, outputs)
         sync()
         # per-step HIP events on the stream every kernel of the step is launched on (torch's current stream): nsteps + 1 marks
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)] if per_step is not None else None
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)] if (per_step is not None and dev.type == "cuda") else None
         t0 = time.perf_counter()
         for i in range(nsteps):
             if marks:
@@ -197,7 +220,7 @@ def main():
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "dtype_note": "fp32 tensors and fp32 accumulation; matrix products through error-free f16 hi/lo splits of the fp32 operands "
                       "(3 MFMAs per product, exact power-of-two scaling), parity gate 1e-4 relative",
-        "data": "synthetic",
+        "data": "synthetic", **({"emulation": True} if emu else {}),
         "config": {"workload": "Color_NeuS_dtu.yml renderer block (SDF 8x256 + colour 4x256 + relight 4x256), synthetic 800x800 "
                                "view, %d rays/step/GPU x (64+64) samples, trained-like weights" % R,
                    "rays_per_step_per_gpu": R, "rays_per_step_total": Rg, "samples_per_ray": M, "parallelism": "ray-sharded dp%d" % world,

@@ -372,10 +372,16 @@ class NeuSRenderer(nn.Module):
         if perturb_overwrite >= 0:
             perturb = perturb_overwrite
         t_rand = None
-        if perturb > 0 and (z_vals is None or self.n_outside > 0):
-            t_cpu = torch.rand([n_rays, 1])   # CPU generator, exactly like NeuS.py:325 (drawn even under a z override when the
-            if z_vals is None:                # background draw follows, so that the stream stays the reference's)
-                t_rand = self._jitter_to_device(t_cpu, dev)
+        t_given = kwargs.get("t_rand")        # extra kwarg (not in the reference): the jitter draw of THESE rays, e.g. a rank's rows of the
+        if perturb > 0 and (z_vals is None or self.n_outside > 0):   # whole batch's draw in ray-sharded training (parallel.draw_jitter)
+            if t_given is not None:
+                if t_given.numel() != n_rays:
+                    raise ValueError(f"t_rand must hold one draw per ray ({n_rays}), got {tuple(t_given.shape)}")
+                t_cpu = t_given.detach().reshape(n_rays, 1).float()
+            else:
+                t_cpu = torch.rand([n_rays, 1])   # CPU generator, exactly like NeuS.py:325 (drawn even under a z override when the
+            if z_vals is None:                    # background draw follows, so that the stream stays the reference's)
+                t_rand = self._jitter_to_device(t_cpu, dev) if t_cpu.device.type == "cpu" else t_cpu.to(dev).contiguous()
         bg = None
         if background_rgb is not None:
             bg = torch.as_tensor(background_rgb, dtype=torch.float32, device=dev).reshape(-1)[:3].contiguous()

@@ -1,0 +1,55 @@
+"""CPU, world_size 2, gloo: bench.py's OWN multi-rank code path -- what the driver launches on an 8-GPU node as
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` -- run as two processes on the CPU emulation of the kernel layer
+(CNR_BENCH_EMU_LIB, test infrastructure) in its BASELINE C4 form (--scaling strong: a fixed batch split over the ranks), against the
+single-process run of the same batch: same rays_per_step_total, the parallelism the line reports, and the same loss after the same steps
+(the ray-sharded objective equals the single-process objective; parallel.py and tests/test_sharded_gloo.py cover the pieces, this covers the
+harness that assembles them)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import _native as N
+
+pytestmark = pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, rays_total, extra=()):
+    env = dict(os.environ, CNR_BENCH_EMU_LIB=N.EMU_LIB, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--rays-total", str(rays_total), *extra]
+    if world == 1:
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_strong_scaling_line_matches_single_process():
+    one = _run(1, 16)
+    two = _run(2, 16)
+    for d, w in ((one, 1), (two, 2)):
+        assert d["emulation"] is True and d["n_gpus"] == w and d["scaling"] == "strong" and d["steps"] == 2 and d["warmup"] == 1
+        assert d["metric"].startswith("rays/sec") and d["unit"] == "rays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+        assert d["config"]["rays_per_step_total"] == 16 and d["config"]["rays_per_step_per_gpu"] == 16 // w
+        assert d["config"]["parallelism"] == "ray-sharded dp%d" % w
+        assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-3 * d["value"] + 0.1     # value = all ranks' rays / max-over-ranks time
+    assert "allreduce" in two["config"]["step"] and "allreduce" not in one["config"]["step"]
+    # strong scaling: the two ranks split the single-process batch and its jitter draw, the loss terms are reduced over the ranks before
+    # backward and the gradients after it -- so after the same 3 optimiser steps (1 warm-up + 2 timed) the reported loss of the last step
+    # equals the single-process one up to the summation order of the reductions
+    assert abs(one["config"]["final_loss"] - two["config"]["final_loss"]) <= 2e-5 * abs(one["config"]["final_loss"]), (one["config"]["final_loss"], two["config"]["final_loss"])
