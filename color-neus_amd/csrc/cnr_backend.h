@@ -187,6 +187,18 @@ struct SdfValueChain {   // sdf = SDFNetwork.sdf(x) from the embedding rows E (f
   float* sdf_out;                  // [P]
 };
 bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s);   // false: not handled (backend without fused kernels / unsupported shape)
+// The SAVING SDF forward (Color_NeuS.py:52-54 on the fine samples): the value chain above that also leaves behind what the backward pass
+// reads -- every hidden layer's PRE-activation row z_l (the tail columns of the layer in front of a skip connection receive e: the tail fill
+// of the per-layer launches), the row scales of the layer inputs, the feature rows of the top layer -- in one launch (cnr_chain_fwd.hip).
+struct SdfSaveChain {
+  SdfValueChain v;                 // E, P, hidden layers, skip mask, sdf row of the top layer, sdf_out
+  float* Z[kMaxLayers] = {};       // [P][ldz] per hidden layer
+  int ldz = 0;
+  float* rs[kMaxLayers + 1] = {};  // optional [P]: power-of-two scale of the input row of layer l (l >= 1; LayerGemm::rs_out convention)
+  FusedLayer top;                  // the feature rows of the top layer (K == 256, N == 256): feat = h W^T + b, no activation
+  float* feat = nullptr; int ld_feat = 0;   // [P][ld_feat]
+};
+bool be_sdf_save_chain(const SdfSaveChain& c, cnr_stream s);      // false: not handled
 
 // The SAVING forward chains of the ReLU stacks (colour network fields.py:161-188, relight network fields.py:332-368) in ONE launch
 // (cnr_chain_fwd.hip): a 128-point tile goes through colour lin0..lin(NC-2) + the rgb head, then relight in_layer + rl_mlp[0..NR-2] + the

@@ -314,6 +314,266 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// A wave's 32 x 32 output block (lane = row pt, 16 consecutive columns per half) -> global rows: through the wave's private 2 KB LDS buffer,
+// 16 rows at a time (XOR-swizzled 16-byte chunks: conflict-free both ways), stored as 8 rows x 128 contiguous bytes per instruction.
+// dst_tile: first row of the tile (uniform) + the wave's first column; row_base: the block's first row within the tile.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chain_save_block(const f32x16& a, unsigned char* tb, float* dst_tile, int ld, int row_base, int rows_left, int lane) {
+  const int half = lane >> 5, pt = lane & 31;
+  const int sv_off = (lane >> 3) * ld + (lane & 7) * 4;
+#pragma unroll
+  for (int hpass = 0; hpass < 2; ++hpass) {
+    if ((pt >> 4) == hpass) {
+      const int r = pt & 15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        *reinterpret_cast<f4*>(tb + r * 128 + (((4 * half + q) ^ (r & 7)) << 4)) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (lane >> 3) + 8 * i, ch = lane & 7;
+      const f4 v = *reinterpret_cast<const f4*>(tb + r * 128 + ((ch ^ (r & 7)) << 4));
+      const int row0 = row_base + hpass * 16 + 8 * i;
+      if (row0 + (lane >> 3) < rows_left) *reinterpret_cast<f4*>(dst_tile + row0 * ld + sv_off) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The SAVING SDF value chain (SdfSaveChain): sdf_value_chain_kernel<RT, 1> of cnr_chain.hip plus the stores the backward pass needs.
+// Per hidden layer: z = acc / (row scale x column scale) + bias is stored (through chain_save_block) BEFORE the activation; the layer in front
+// of a skip connection stores [z | e] (what the per-layer launches' tail fill writes) and hands [softplus(z) | e] / sqrt(2) to the next layer.
+// The top layer's 256 feature rows are one more MFMA step whose output goes straight to the colour network's input buffer.
+// ------------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(512, 1) void sdf_save_chain_kernel(const SdfSaveChain c) {
+  constexpr int T = 32 * RT;
+  constexpr int APLANE = T * CH_ALD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* rs = reinterpret_cast<float*>(smem + 2 * APLANE);   // [T] 1 / row scale of the current layer input
+  float* pm = rs + T;                                        // [T][8] per-wave partial row maxima
+  float* pd = pm + T * 8;                                    // [T][8] per-wave partial dot products of the sdf row
+  float* cwb = pd + T * 8;                                   // [512] column scales | biases of the step in flight (rewritten behind the row-max barrier: every wave has read its values by then)
+  float* wtop = cwb + 512;                                   // [256] sdf row of the top layer
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  unsigned char* tb = reinterpret_cast<unsigned char*>(wtop + 256) + wave * 2048;
+  const SdfValueChain& v = c.v;
+  const long ntiles = (v.P + T - 1) / T;
+  const int nsteps = v.nl + 1;                               // hidden layers + the feature rows of the top layer
+  // (the host puts the top layer's feature rows behind the hidden layers, v.lay[v.nl]: one array index for every step -- a choice between
+  // two kernel-argument references would make the compiler copy the argument block to scratch)
+
+  f16x8 wr1[4][1], wr2[4][1];
+  auto wlane_of = [&](const FusedLayer& L, int lane_) __attribute__((always_inline)) { return L.Wf + (long)wave * (L.K >> 4) * 1024 + lane_ * 8; };
+  auto cw_fetch = [&](const FusedLayer& L, int tid) __attribute__((always_inline)) {
+    f4 x = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) x = *reinterpret_cast<const f4*>(L.wsc + tid * 4);
+    else if (tid < 128) x = *reinterpret_cast<const f4*>(L.bias + (tid - 64) * 4);
+    return x;
+  };
+  chain_wprime<1>(wr1, wr2, wlane_of(v.lay[0], tid0 & 63), v.lay[0].K >> 4, 0, v.lay[0].K >> 4);
+  for (int i = tid0; i < 256; i += 512) wtop[i] = v.wtop[i];
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long tile0 = tile * T;
+    const int rows_left = (int)((v.P - tile0) < T ? (v.P - tile0) : T);
+    {
+      // ---- layer-0 input: E rows -> planes (16 threads per row, 4 columns each)
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      if (tid < 128) *reinterpret_cast<f4*>(cwb + tid * 4) = cw_fetch(v.lay[0], tid);
+      const int sc4 = (tid & 15) * 4;
+      f4 x[RT];
+#pragma unroll
+      for (int pass = 0; pass < RT; ++pass) {
+        const int row_l = pass * 32 + (tid >> 4);
+        const int row_c = row_l < rows_left ? row_l : rows_left - 1;
+        x[pass] = f4{0.f, 0.f, 0.f, 0.f};
+        if (sc4 < kEmb) x[pass] = *reinterpret_cast<const f4*>(v.E + (tile0 + row_c) * kEmb + sc4);
+      }
+#pragma unroll
+      for (int pass = 0; pass < RT; ++pass) {
+        const int row_l = pass * 32 + (tid >> 4);
+        float mx = ws_absmax4(x[pass]);
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+        const float sc = chain_row_scale(mx);
+        if (sc4 < kEmb) chain_put4(x[pass], sc, smem + row_l * CH_ALD + sc4 * 2, APLANE);
+        if ((tid & 15) == 0) rs[row_l] = 1.0f / sc;
+      }
+      lds_barrier();
+    }
+    for (int l = 0; l < nsteps; ++l) {
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, half = lane >> 5, pt = lane & 31;
+      const int cbase = wave * 32 + 16 * half;
+      const bool is_top = l == v.nl, last_hidden = l + 1 == v.nl;
+      const FusedLayer& L = v.lay[l];
+      const FusedLayer& Ln = v.lay[is_top ? 0 : l + 1];
+      const int nkb = L.K >> 4;
+      const f4 cw_next = cw_fetch(Ln, tid);
+      f32x16 acc1[1][RT];
+      f32x16 (&acc)[RT] = acc1[0];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
+      const unsigned char* Ab = smem + pt * CH_ALD + half * 16;
+      if (nkb == 16) chain_mfma_blocks<RT, 1, 16>(acc1, wr1, wr2, Ab, APLANE, wlane_of(L, lane), 16, 0);
+      else chain_mfma_blocks<RT, 1, 3>(acc1, wr1, wr2, Ab, APLANE, wlane_of(L, lane), 3, 0);
+      chain_wprime<1>(wr1, wr2, wlane_of(Ln, lane), Ln.K >> 4, 0, Ln.K >> 4);
+
+      const float* cw = cwb;
+      const bool next_skip = !is_top && !last_hidden && ((v.skip_mask >> (l + 1)) & 1);
+      const bool ragged = !is_top && L.N < 256;             // wave-uniform: only the layer in front of a skip connection
+      float* out_tile = (is_top ? c.feat + tile0 * c.ld_feat : c.Z[l] + tile0 * c.ldz) + wave * 32;
+      const int out_ld = is_top ? c.ld_feat : c.ldz;
+      float rmax[RT], rdot[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) { rmax[rt] = 0.0f; rdot[rt] = 0.0f; }
+      {
+        f4 wsc4[4], b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          wsc4[q] = *reinterpret_cast<const f4*>(cw + cbase + 4 * q);
+          b4[q] = *reinterpret_cast<const f4*>(cw + 256 + cbase + 4 * q);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row_l = rt * 32 + pt;
+          const f2 rsc = pk_splat(rs[row_l]);
+          // z (or, for the top layer, the feature row): acc / (row scale * column scale) + bias
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const f2 w = {wsc4[q >> 1][(2 * q) & 3], wsc4[q >> 1][(2 * q + 1) & 3]};
+            const f2 b = {b4[q >> 1][(2 * q) & 3], b4[q >> 1][(2 * q + 1) & 3]};
+            f2 a = {acc[rt][2 * q], acc[rt][2 * q + 1]};
+            a = pk_fma(a, rsc * w, b);
+            acc[rt][2 * q] = a.x; acc[rt][2 * q + 1] = a.y;
+          }
+          const bool tail_lane = ragged && cbase + 16 > L.N;  // owns columns >= N: they carry e (fields.py:86-87)
+          if (tail_lane) {
+            const int row_c = row_l < rows_left ? row_l : rows_left - 1;
+            const float* erow = v.E + (tile0 + row_c) * kEmb;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ei = cbase + r - L.N;
+              const float e = erow[ei < 0 ? 0 : (ei < kEmb ? ei : kEmb - 1)];
+              acc[rt][r] = ei < 0 ? acc[rt][r] : ((next_skip && ei < v.emb) ? e : 0.0f);
+            }
+          }
+          chain_save_block(acc[rt], tb, out_tile, out_ld, rt * 32, rows_left, lane);
+          if (!is_top) {
+            // a = softplus(z) (the tail columns keep e), / sqrt(2) in front of a skip layer ; row max ; partial dot with the sdf row
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              f2 z = {acc[rt][2 * q], acc[rt][2 * q + 1]};
+              f2 a = softplus100_pk(z);
+              if (tail_lane) { a.x = cbase + 2 * q >= L.N ? z.x : a.x; a.y = cbase + 2 * q + 1 >= L.N ? z.y : a.y; }
+              if (next_skip) a = a * pk_splat(kInvSqrt2);
+              acc[rt][2 * q] = a.x; acc[rt][2 * q + 1] = a.y;
+            }
+            float mx = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(fabsf(acc[rt][r]), fabsf(acc[rt][r + 1])), mx);
+            rmax[rt] = mx;
+            if (last_hidden) {
+              float dot = 0.0f;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f4 wt = *reinterpret_cast<const f4*>(wtop + cbase + 4 * q);
+                dot = fmaf(acc[rt][4 * q], wt.x, dot); dot = fmaf(acc[rt][4 * q + 1], wt.y, dot);
+                dot = fmaf(acc[rt][4 * q + 2], wt.z, dot); dot = fmaf(acc[rt][4 * q + 3], wt.w, dot);
+              }
+              rdot[rt] = dot;
+            }
+          }
+        }
+      }
+      if (!is_top) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const float o = __shfl_xor(rmax[rt], 32);
+          if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = fmaxf(rmax[rt], o);
+          if (last_hidden) { const float od = __shfl_xor(rdot[rt], 32); if (half == 0) pd[(rt * 32 + pt) * 8 + wave] = rdot[rt] + od; }
+        }
+      }
+      lds_barrier();   // partial maxima / dots visible; every wave is done reading the planes of this step's input
+      if (tid < 128) *reinterpret_cast<f4*>(cwb + tid * 4) = cw_next;
+      if (!is_top) {
+        float* rso = c.rs[l + 1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row_l = rt * 32 + pt;
+          float mx = pm[row_l * 8];
+#pragma unroll
+          for (int w = 1; w < 8; ++w) mx = fmaxf(mx, pm[row_l * 8 + w]);
+          const float sc = chain_row_scale(mx);
+          chain_put16(acc[rt], sc, smem + row_l * CH_ALD + cbase * 2, APLANE);
+          if (wave == 0 && half == 0) {
+            rs[row_l] = 1.0f / sc;
+            if (rso != nullptr && row_l < rows_left) rso[tile0 + row_l] = chain_rs_value(mx, sc);
+          }
+        }
+        if (last_hidden && tid < T) {
+          // sdf = (softplus(z_top-1) . w_sdf + b_sdf) * top_scale: the per-wave partial sums in a fixed order
+          float sum = pd[tid * 8];
+#pragma unroll
+          for (int w = 1; w < 8; ++w) sum += pd[tid * 8 + w];
+          if (tid < rows_left) v.sdf_out[tile0 + tid] = (sum + v.btop[0]) * v.top_scale;
+        }
+      }
+      lds_barrier();
+    }
+  }
+}
+
+template <int RT>
+static void launch_sdf_save_chain(const SdfSaveChain& c, cnr_stream s) {
+  constexpr int T = 32 * RT;
+  const size_t lds = (size_t)2 * T * CH_ALD + (size_t)T * 17 * sizeof(float) + (size_t)(512 + 256) * sizeof(float) + (size_t)8 * 2048;
+  static_assert((size_t)2 * T * CH_ALD + (size_t)T * 17 * sizeof(float) + (size_t)(512 + 256) * sizeof(float) + (size_t)8 * 2048 <= 160 * 1024, "LDS budget");
+  static DeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_save_chain_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const long ntiles = (c.v.P + T - 1) / T;
+  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
+  const long wgs = wgs_env > 0 ? wgs_env : 256;
+  const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
+  double macs = 256.0 * 256.0, bytes = (double)c.v.P * ((kEmb + 1) * 4.0 + 1024.0);
+  for (int l = 0; l < c.v.nl; ++l) { macs += (double)c.v.lay[l].K * 256.0; bytes += (double)c.v.P * (1024.0 + (c.rs[l + 1] ? 4.0 : 0.0)); }
+  TimingScope ts_("chain_sdf_fwd", 3, RT * 10 + 1, c.v.P, (int)(macs / 256.0), 256, 1, s, bytes);
+  SdfSaveChain cc = c;
+  cc.v.lay[c.v.nl] = c.top;
+  hipLaunchKernelGGL((sdf_save_chain_kernel<RT>), dim3(grid), dim3(512), lds, s, cc);
+}
+
+bool be_sdf_save_chain(const SdfSaveChain& c, cnr_stream s) {
+  static const bool off = getenv("CNR_NO_FUSED") != nullptr || getenv("CNR_NO_CHAIN_SDF") != nullptr;   // debugging aids: per-layer launches
+  const SdfValueChain& v = c.v;
+  if (off || v.P <= 0 || v.nl < 1 || v.nl >= kMaxLayers) return false;
+  for (int l = 0; l < v.nl; ++l) {
+    if ((v.lay[l].K != 256 && !(l == 0 && v.lay[l].K == 48)) || v.lay[l].N > 256 || v.lay[l].N < 1 || !v.lay[l].Wf || !c.Z[l]) return false;
+    if (l + 1 < v.nl && v.lay[l].N < 256 && !((v.skip_mask >> (l + 1)) & 1)) return false;   // a narrow layer only in front of a skip connection
+  }
+  if (v.lay[v.nl - 1].N != 256 || c.top.K != 256 || c.top.N != 256 || !c.top.Wf || !c.feat || (c.ld_feat & 3) || (c.ldz & 3) || c.ldz < 256) return false;
+  static const int force = getenv("CNR_CHAIN_FWD_RT") ? atoi(getenv("CNR_CHAIN_FWD_RT")) : 0;
+  const int rt = force ? force : (v.P >= 256L * 128 ? 4 : (v.P >= 256L * 64 ? 2 : 1));
+  if (rt == 4) launch_sdf_save_chain<4>(c, s);
+  else if (rt == 2) launch_sdf_save_chain<2>(c, s);
+  else launch_sdf_save_chain<1>(c, s);
+  CNR_LAUNCH_CHECK("chain_sdf_fwd");
+  return true;
+}
+
 template <int RT>
 static void launch_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
   constexpr int T = 32 * RT;

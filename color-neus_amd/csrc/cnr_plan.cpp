@@ -448,9 +448,37 @@ static bool sdf_value_chain_fused(const Model& m, long n, const float* E, float*
   return be_sdf_value_chain(c, s);
 }
 
+// the SAVING forward (pre-activations, row scales, feature rows for the backward pass) as one chain-fused launch (cnr_chain_fwd.hip)
+static bool sdf_save_chain_fused(const Model& m, long n, const float* E, float* const* Z, float* sdf_out, float* feat_out, int ld_feat,
+                                 float top_scale, float* const* rs, cnr_stream s) {
+  if (m.Hs != 256 || m.L < 1 || m.F != 256 || m.L + 1 > kMaxLayers) return false;
+  if (m.skip(m.L) || m.sdf[m.L - 1].n != 256 || m.sdf[m.L].ldw != 256 || !m.sdf[m.L].Wf) return false;
+  // Where the chain pays: it loads the layer weights once per 128-point tile from L2 instead of once per launch and workgroup, and saves
+  // 17 launches' fixed costs -- decisive for small batches; at large batches its stores do not overlap its MFMA phases and the per-layer
+  // launches are faster (measured: DESIGN.md section 4.5).  CNR_CHAIN_SDF_MAXP moves the switch-over (points).
+  static const long maxp = getenv("CNR_CHAIN_SDF_MAXP") ? atol(getenv("CNR_CHAIN_SDF_MAXP")) : (1L << 62);
+  if (n > maxp) return false;
+  SdfSaveChain c;
+  c.v.E = E; c.v.P = n; c.v.nl = m.L; c.v.skip_mask = m.c.sdf_skip_mask; c.v.emb = m.emb;
+  for (int l = 0; l < m.L; ++l) {
+    const Lin& q = m.sdf[l];
+    if (!q.Wf || !Z[l]) return false;
+    c.v.lay[l] = FusedLayer{q.Wf, q.Wps, q.bias, q.ldw, q.n};
+    c.Z[l] = Z[l];
+  }
+  c.ldz = m.Hs;
+  for (int l = 1; l <= m.L; ++l) c.rs[l] = rs ? rs[l] : nullptr;
+  const Lin& t = m.sdf[m.L];
+  c.top = FusedLayer{t.Wf, t.Wps, t.bias, t.ldw, m.F};
+  c.feat = feat_out; c.ld_feat = ld_feat;
+  c.v.wtop = t.W + (long)m.F * t.ldw; c.v.btop = t.bias + m.F; c.v.top_scale = top_scale; c.v.sdf_out = sdf_out;
+  return be_sdf_save_chain(c, s);
+}
+
 static void sdf_chain(const Model& m, long n, const float* E, float* const* Z, float* sdf_out, float* feat_out, int ld_feat,
                       float top_scale, cnr_stream s, float* const* rs = nullptr /* [L+1] row scales of the layer inputs, see Ctx::rsY */) {
   if (!feat_out && !rs && sdf_value_chain_fused(m, n, E, sdf_out, top_scale, s)) return;   // value only: one chain-fused launch
+  if (feat_out && sdf_save_chain_fused(m, n, E, Z, sdf_out, feat_out, ld_feat, top_scale, rs, s)) return;
   for (int l = 0; l <= m.L; ++l) {
     const Lin& q = m.sdf[l];
     LayerGemm g;
