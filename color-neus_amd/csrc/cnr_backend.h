@@ -199,6 +199,24 @@ struct SdfSaveChain {
   float* feat = nullptr; int ld_feat = 0;   // [P][ld_feat]
 };
 bool be_sdf_save_chain(const SdfSaveChain& c, cnr_stream s);      // false: not handled
+// The analytic gradient chain of the SDF network (the reverse sweep that replaces SDFNetwork.gradient, fields.py:105-115) in one launch:
+//   u_l = softplus'(z_l) * v_l ;  v_{l-1} = W_l^T u_l  (/ sqrt(2) and split into [hidden | embedding] parts below a skip connection), l = L-1 .. 0,
+// v_{L-1} the broadcast sdf row of the top layer.  Every v_l is stored for the backward pass (second-order sweep), the row scales of u_l with it;
+// the embedding cotangents go to ce0 (layer 0) and ces (skip layer).
+struct SdfGradChain {
+  long P = 0; int nl = 0;
+  FusedLayer lay[kMaxLayers];             // per layer l: fragment-major planes of W_l^T (a row per INPUT column of layer l), wsc = per-row inverse scales,
+                                          // K = round_up(layer width n_l, 16) (contraction), N = k_int(l) (outputs = the layer's input columns)
+  const float* Z[kMaxLayers] = {}; int ldz = 0;   // pre-activations of the hidden layers
+  const float* vrow = nullptr; float vscale = 1.0f;   // v_{L-1}[col] = vrow[col] * vscale
+  float* V[kMaxLayers] = {};              // V[l - 1] <- step l (l >= 1), row stride ldz; columns >= the width of layer l - 1 are written as zeros
+  int skip_mask = 0; int n_out[kMaxLayers] = {};      // n_out[l]: hidden width n_{l-1} of the layer below (output columns that go to V[l-1]); the rest of a skip layer's output is embedding
+  float* ces = nullptr; int ces_off = 0;  // [P][kEmb]: embedding cotangent of the skip layer at column offset ces_off
+  float* ce0 = nullptr;                   // [P][kEmb]: output of step 0 (emb live columns, the rest zero)
+  int emb = 0;
+  float* rs[kMaxLayers] = {};             // optional [P]: row scale of u_l (LayerGemm::rs_out convention)
+};
+bool be_sdf_grad_chain(const SdfGradChain& c, cnr_stream s);      // false: not handled
 
 // The SAVING forward chains of the ReLU stacks (colour network fields.py:161-188, relight network fields.py:332-368) in ONE launch
 // (cnr_chain_fwd.hip): a 128-point tile goes through colour lin0..lin(NC-2) + the rgb head, then relight in_layer + rl_mlp[0..NR-2] + the

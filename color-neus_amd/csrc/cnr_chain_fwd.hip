@@ -574,6 +574,290 @@ bool be_sdf_save_chain(const SdfSaveChain& c, cnr_stream s) {
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Global rows -> a wave's 32 x 32 block in the chain layout (lane = row pt, 16 consecutive columns per half): the reverse of chain_save_block.
+// The 16-byte pieces are requested first (chain_load_issue: 8 rows x 128 contiguous bytes per instruction) and pass through the wave's
+// LDS buffer later (chain_load_finish), so that the memory latency hides behind whatever the caller does in between.
+// ------------------------------------------------------------------------------------------------
+struct ChainRaw { f4 v[2][2]; };   // [16-row pass][8-row group]
+__device__ __forceinline__ ChainRaw chain_load_issue(const float* src_tile, int ld, int row_base, int rows_left, int lane) {
+  ChainRaw r;
+#pragma unroll
+  for (int hpass = 0; hpass < 2; ++hpass)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int row = row_base + hpass * 16 + 8 * i + (lane >> 3);
+      if (row >= rows_left) row = rows_left - 1;             // rows past the end read the last row (their results are never stored)
+      r.v[hpass][i] = *reinterpret_cast<const f4*>(src_tile + row * ld + (lane & 7) * 4);
+    }
+  return r;
+}
+__device__ __forceinline__ void chain_load_finish(const ChainRaw& raw, unsigned char* tb, float (&z)[16], int lane) {
+  const int half = lane >> 5, pt = lane & 31;
+#pragma unroll
+  for (int hpass = 0; hpass < 2; ++hpass) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (lane >> 3) + 8 * i, ch = lane & 7;
+      *reinterpret_cast<f4*>(tb + r * 128 + ((ch ^ (r & 7)) << 4)) = raw.v[hpass][i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if ((pt >> 4) == hpass) {
+      const int r = pt & 15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f4 v = *reinterpret_cast<const f4*>(tb + r * 128 + (((4 * half + q) ^ (r & 7)) << 4));
+        z[4 * q] = v.x; z[4 * q + 1] = v.y; z[4 * q + 2] = v.z; z[4 * q + 3] = v.w;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The analytic gradient chain (SdfGradChain) on a 32 * RT point tile.  Step l: planes = u_l (hi / lo of the exactly scaled row);
+// v_{l-1} = W_l^T u_l by the transposed MFMA product; the epilogue undoes the scales, stores v_{l-1} (chain_save_block), fetches z_{l-1} in the
+// lane layout (chain_load_*), forms u_{l-1} = softplus'(z_{l-1}) * v_{l-1}, its row scale, and the next planes.
+// ------------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(512, 1) void sdf_grad_chain_kernel(const SdfGradChain c) {
+  constexpr int T = 32 * RT;
+  constexpr int APLANE = T * CH_ALD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* rs = reinterpret_cast<float*>(smem + 2 * APLANE);   // [T] 1 / row scale of the current step's input
+  float* pm = rs + T;                                        // [T][8] per-wave partial row maxima
+  float* cwb = pm + T * 8;                                   // [256] column scales of the step in flight
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  unsigned char* tb = reinterpret_cast<unsigned char*>(cwb + 256) + wave * 2048;
+  const long ntiles = (c.P + T - 1) / T;
+  const int L = c.nl;
+
+  f16x8 wr1[4][1], wr2[4][1];
+  auto wlane_of = [&](const FusedLayer& Q, int lane_) __attribute__((always_inline)) { return Q.Wf + (long)wave * (Q.K >> 4) * 1024 + lane_ * 8; };
+  chain_wprime<1>(wr1, wr2, wlane_of(c.lay[L - 1], tid0 & 63), c.lay[L - 1].K >> 4, 0, c.lay[L - 1].K >> 4);
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long tile0 = tile * T;
+    const int rows_left = (int)((c.P - tile0) < T ? (c.P - tile0) : T);
+    {
+      // ---- the chain starts: u_{L-1} = softplus'(z_{L-1}) * (vrow * vscale), rows from HBM (16 threads per row, 4 columns each per 64)
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      if (tid < 64) *reinterpret_cast<f4*>(cwb + tid * 4) = *reinterpret_cast<const f4*>(c.lay[L - 1].wsc + tid * 4);
+      const int sc4 = (tid & 15) * 4;
+      const float* zt = c.Z[L - 1] + tile0 * c.ldz;
+      f4 w4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w4[j] = *reinterpret_cast<const f4*>(c.vrow + 64 * j + sc4);
+      f4 zv[RT][4];
+#pragma unroll
+      for (int pass = 0; pass < RT; ++pass) {
+        const int row_l = pass * 32 + (tid >> 4);
+        const int row_c = row_l < rows_left ? row_l : rows_left - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zv[pass][j] = *reinterpret_cast<const f4*>(zt + row_c * c.ldz + 64 * j + sc4);
+      }
+#pragma unroll
+      for (int pass = 0; pass < RT; ++pass) {
+        const int row_l = pass * 32 + (tid >> 4);
+        float mx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f4& u = zv[pass][j];
+          u.x = softplus100_d1(u.x) * w4[j].x * c.vscale; u.y = softplus100_d1(u.y) * w4[j].y * c.vscale;
+          u.z = softplus100_d1(u.z) * w4[j].z * c.vscale; u.w = softplus100_d1(u.w) * w4[j].w * c.vscale;
+          mx = fmaxf(mx, ws_absmax4(u));
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+        const float sc = chain_row_scale(mx);
+        unsigned char* dst = smem + row_l * CH_ALD + sc4 * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) chain_put4(zv[pass][j], sc, dst + 128 * j, APLANE);
+        if ((tid & 15) == 0) {
+          rs[row_l] = 1.0f / sc;
+          if (c.rs[L - 1] != nullptr && row_l < rows_left) c.rs[L - 1][tile0 + row_l] = chain_rs_value(mx, sc);
+        }
+      }
+      lds_barrier();
+    }
+    for (int l = L - 1; l >= 0; --l) {
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, half = lane >> 5, pt = lane & 31;
+      const int cbase = wave * 32 + 16 * half;
+      const FusedLayer& Q = c.lay[l];
+      const FusedLayer& Qn = c.lay[l == 0 ? L - 1 : l - 1];
+      const int nkb = Q.K >> 4;
+      f4 cw_next = {0.f, 0.f, 0.f, 0.f};
+      if (tid < 64) cw_next = *reinterpret_cast<const f4*>(Qn.wsc + tid * 4);
+      f32x16 acc1[1][RT];
+      f32x16 (&acc)[RT] = acc1[0];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
+      const unsigned char* Ab = smem + pt * CH_ALD + half * 16;
+      // z_{l-1} of this wave's first row blocks is requested BEFORE the MFMA phase (its latency hides behind the matrix work), the rest at the
+      // start of the epilogue (hidden behind the first blocks' stores and sigmoid math): 32 + 32 registers in flight instead of 64
+      constexpr int RG = RT < 2 ? RT : 2;
+      ChainRaw zraw0[RG];
+      if (l > 0) {
+        const float* zt = c.Z[l - 1] + tile0 * c.ldz + wave * 32;
+#pragma unroll
+        for (int k = 0; k < RG; ++k) zraw0[k] = chain_load_issue(zt, c.ldz, k * 32, rows_left, lane);
+      }
+      if (nkb == 16) chain_mfma_blocks<RT, 1, 16>(acc1, wr1, wr2, Ab, APLANE, wlane_of(Q, lane), 16, 0);
+      else chain_mfma_blocks<RT, 1, 14>(acc1, wr1, wr2, Ab, APLANE, wlane_of(Q, lane), 14, 0);
+      chain_wprime<1>(wr1, wr2, wlane_of(Qn, lane), Qn.K >> 4, 0, Qn.K >> 4);
+
+      // ---- epilogue
+      const bool skip = (c.skip_mask >> l) & 1;
+      const float oscale = skip ? kInvSqrt2 : 1.0f;
+      const int nv = l > 0 ? c.n_out[l] : 0;                 // output columns that are v_{l-1} (the hidden width of the layer below)
+      const int nlive = Q.N;                                 // live output columns (v part + embedding part)
+      float rmax[RT];
+      {
+        f4 wsc4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wsc4[q] = *reinterpret_cast<const f4*>(cwb + cbase + 4 * q);
+        ChainRaw zraw1[RG];
+        if (l > 0 && RT > RG) {
+          const float* zt = c.Z[l - 1] + tile0 * c.ldz + wave * 32;
+#pragma unroll
+          for (int k = 0; k < RG; ++k) zraw1[k] = chain_load_issue(zt, c.ldz, (RG + k) * 32, rows_left, lane);
+        }
+#pragma unroll
+        for (int g0 = 0; g0 < RT; g0 += RG) {
+          ChainRaw (&zraw)[RG] = g0 == 0 ? zraw0 : zraw1;
+#pragma unroll
+          for (int k = 0; k < RG; ++k) {
+            const int rt = g0 + k;
+            const int row_l = rt * 32 + pt;
+            const float rsc = rs[row_l];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float o = (acc[rt][r] * (rsc * wsc4[r >> 2][r & 3])) * oscale;
+              acc[rt][r] = cbase + r < nlive ? o : 0.0f;     // (columns without weights: their scales are not even defined)
+            }
+            if (l == 0) {
+              // embedding cotangent of layer 0: [P][kEmb], kEmb = 48 columns (waves 0 and 1 hold them)
+              if (wave == 0) chain_save_block(acc[rt], tb, c.ce0 + tile0 * kEmb, kEmb, rt * 32, rows_left, lane);
+              else if (wave == 1) {
+                // columns 32..47: the left half of this wave's block (lanes of half 0), 64 bytes per row
+                if (half == 0 && row_l < rows_left) {
+                  float* d = c.ce0 + (tile0 + row_l) * kEmb + 32;
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(d + 4 * q) = f4{acc[rt][4 * q], acc[rt][4 * q + 1], acc[rt][4 * q + 2], acc[rt][4 * q + 3]};
+                }
+              }
+            } else {
+              if (skip && cbase + 16 > nv) {
+                // embedding part of a skip layer's output -> ces (scalar stores: 39 floats per row), then zero in the row that becomes v_{l-1}
+                if (row_l < rows_left) {
+                  float* d = c.ces + (tile0 + row_l) * kEmb + c.ces_off - nv;
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) if (cbase + r >= nv && cbase + r < nlive) d[cbase + r] = acc[rt][r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][r] = cbase + r < nv ? acc[rt][r] : 0.0f;
+              }
+              chain_save_block(acc[rt], tb, c.V[l - 1] + tile0 * c.ldz + wave * 32, c.ldz, rt * 32, rows_left, lane);
+            }
+          }
+          if (l > 0) {
+            // u_{l-1} = softplus'(z_{l-1}) * v_{l-1} ; row max
+#pragma unroll
+            for (int k = 0; k < RG; ++k) {
+              const int rt = g0 + k;
+              float z[16];
+              chain_load_finish(zraw[k], tb, z, lane);
+              float mx = 0.0f;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float u = softplus100_d1(z[r]) * acc[rt][r];
+                acc[rt][r] = cbase + r < nv ? u : 0.0f;      // (the tail columns of z below a skip connection hold e, not a pre-activation)
+                mx = fmaxf(mx, fabsf(acc[rt][r]));
+              }
+              rmax[rt] = mx;
+            }
+          }
+        }
+        if (l > 0) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const float o = __shfl_xor(rmax[rt], 32);
+            if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = fmaxf(rmax[rt], o);
+          }
+        }
+      }
+      lds_barrier();   // partial maxima visible; every wave is done reading the planes of this step's input and its column scales
+      if (tid < 64) *reinterpret_cast<f4*>(cwb + tid * 4) = cw_next;
+      if (l > 0) {
+        float* rso = c.rs[l - 1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row_l = rt * 32 + pt;
+          float mx = pm[row_l * 8];
+#pragma unroll
+          for (int w = 1; w < 8; ++w) mx = fmaxf(mx, pm[row_l * 8 + w]);
+          const float sc = chain_row_scale(mx);
+          chain_put16(acc[rt], sc, smem + row_l * CH_ALD + cbase * 2, APLANE);
+          if (wave == 0 && half == 0) {
+            rs[row_l] = 1.0f / sc;
+            if (rso != nullptr && row_l < rows_left) rso[tile0 + row_l] = chain_rs_value(mx, sc);
+          }
+        }
+      }
+      lds_barrier();
+    }
+  }
+}
+
+template <int RT>
+static void launch_sdf_grad_chain(const SdfGradChain& c, cnr_stream s) {
+  constexpr int T = 32 * RT;
+  const size_t lds = (size_t)2 * T * CH_ALD + (size_t)T * 9 * sizeof(float) + (size_t)256 * sizeof(float) + (size_t)8 * 2048;
+  static DeviceOnce attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_grad_chain_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const long ntiles = (c.P + T - 1) / T;
+  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
+  const long wgs = wgs_env > 0 ? wgs_env : 256;
+  const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
+  double macs = 0.0, bytes = (double)c.P * (2.0 * kEmb * 4.0);
+  for (int l = 0; l < c.nl; ++l) { macs += (double)c.lay[l].K * 256.0; bytes += (double)c.P * (1024.0 + (l > 0 ? 1024.0 : 0.0) + (c.rs[l] ? 4.0 : 0.0)); }
+  TimingScope ts_("chain_sdf_grad", 3, RT * 10 + 1, c.P, (int)(macs / 256.0), 256, 1, s, bytes);
+  hipLaunchKernelGGL((sdf_grad_chain_kernel<RT>), dim3(grid), dim3(512), lds, s, c);
+}
+
+bool be_sdf_grad_chain(const SdfGradChain& c, cnr_stream s) {
+  // OFF by default: measured slower than the 8 per-layer launches at every batch size (4096 rays: 3.6 ms against 2.3 ms; 512 rays: 0.50 against
+  // 0.35 ms) -- each step's epilogue has to fetch z_{l-1} (1 KB per point, through the LDS transposition in the other direction) and run a
+  // sigmoid per element before the next MFMA phase can start, and none of that overlaps the matrix work.  Kept as a
+  // tested alternative (CNR_CHAIN_GRAD=1; tests/test_hip_parity.py runs the strict gate on it).
+  static const bool on = getenv("CNR_CHAIN_GRAD") != nullptr && getenv("CNR_NO_FUSED") == nullptr;
+  if (!on || c.P <= 0 || c.nl < 2 || c.nl > kMaxLayers || !c.vrow || !c.ce0 || (c.ldz & 3) || c.ldz < 256) return false;
+  for (int l = 0; l < c.nl; ++l) {
+    const FusedLayer& Q = c.lay[l];
+    if (!Q.Wf || !Q.wsc || (Q.K != 256 && Q.K != 224) || Q.N < 1 || Q.N > 256 || !c.Z[l]) return false;
+    if (l > 0 && (!c.V[l - 1] || c.n_out[l] < 1 || c.n_out[l] > Q.N)) return false;
+    if (((c.skip_mask >> l) & 1) && (!c.ces || l == 0)) return false;
+    if (l > 0 && !((c.skip_mask >> l) & 1) && c.n_out[l] != Q.N) return false;
+    if (l > 0 && c.lay[l - 1].K < c.n_out[l]) return false;   // the planes of step l - 1 hold the v part
+  }
+  if (c.lay[0].N > kEmb) return false;
+  static const int force = getenv("CNR_CHAIN_FWD_RT") ? atoi(getenv("CNR_CHAIN_FWD_RT")) : 0;
+  const int rt = force ? force : (c.P >= 256L * 128 ? 4 : (c.P >= 256L * 64 ? 2 : 1));
+  if (rt == 4) launch_sdf_grad_chain<4>(c, s);
+  else if (rt == 2) launch_sdf_grad_chain<2>(c, s);
+  else launch_sdf_grad_chain<1>(c, s);
+  CNR_LAUNCH_CHECK("chain_sdf_grad");
+  return true;
+}
+
 template <int RT>
 static void launch_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
   constexpr int T = 32 * RT;

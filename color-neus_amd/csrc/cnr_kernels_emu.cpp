@@ -387,6 +387,7 @@ void be_pack_frags_many(const PackJob*, int, cnr_stream) {}
 bool be_sdf_value_chain(const SdfValueChain&, cnr_stream) { return false; }
 bool be_relu_chain_fwd(const ReluChainFwd&, cnr_stream) { return false; }
 bool be_sdf_save_chain(const SdfSaveChain&, cnr_stream) { return false; }
+bool be_sdf_grad_chain(const SdfGradChain&, cnr_stream) { return false; }
 
 void be_upsample(const UpSample& p, cnr_stream) {
 #pragma omp parallel for

@@ -45,6 +45,7 @@ struct Lin {
   float *W = nullptr, *Wt = nullptr, *bias = nullptr;
   unsigned short *Wp = nullptr, *Wtp = nullptr;   // two f16 planes (hi, lo) of the row-scaled W / Wt
   unsigned short* Wf = nullptr;                   // the planes of W in the fragment-major order of the chain-fused kernels
+  unsigned short* Wtf = nullptr;                  // ... and of W^T (gradient chain): SDF layers only
   float *Wps = nullptr, *Wtps = nullptr;          // per-row inverse scales
   std::string name;
   void finish_dims() {
@@ -246,20 +247,21 @@ struct Ctx {   // forward-saved state
 
 static int hr_ld(const Model& m, const Ctx& x, int i) { return i == m.c.rel_y_in_layer - 1 ? x.ldy : m.Hr; }
 
-static void place_lin(Lin& q, Arena& a) {
+static void place_lin(Lin& q, Arena& a, bool want_wtf = false) {
   q.W = a.f((size_t)q.wpad * q.ldw);
   q.Wt = a.f((size_t)q.kpad * q.ldwt);
   q.bias = a.f(q.wpad);
   q.Wp = reinterpret_cast<unsigned short*>(a.f((size_t)q.wpad * q.ldw));
   q.Wtp = reinterpret_cast<unsigned short*>(a.f((size_t)q.kpad * q.ldwt));
   q.Wps = a.f(q.wpad > 256 ? q.wpad : 256);   // (the fused kernels read 256 column scales; entries >= npad are never used)
-  q.Wtps = a.f(q.kpad);
+  q.Wtps = a.f(q.kpad > 256 ? q.kpad : 256);  // (likewise)
   q.Wf = (q.ldw <= 304) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldw / 16) * 2 * 64 * 8 / 2)) : nullptr;   // (<= 19 k16 blocks: 256 + 48)
+  q.Wtf = (want_wtf && q.ldwt <= 256 && q.kpad <= 256) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldwt / 16) * 2 * 64 * 8 / 2)) : nullptr;
 }
 
 static void layout_weights(Model& m, Arena& a) {
   auto place = [&](Lin& q) { place_lin(q, a); };
-  for (auto& q : m.sdf) place(q);
+  for (size_t l = 0; l < m.sdf.size(); ++l) place_lin(m.sdf[l], a, l + 1 < m.sdf.size());   // (hidden SDF layers: W^T fragments for the gradient chain)
   for (auto& q : m.col) place(q);
   for (auto& q : m.rel) place(q);
 }
@@ -411,6 +413,7 @@ static void prep_all(Model& m, const float* const* params, cnr_stream s) {
   be_split_planes_many(sj.data(), (int)sj.size(), s);       // their f16 planes (W and W^T): one launch
   std::vector<PackJob> pj;
   for (auto& q : m.sdf) if (q.Wf) pj.push_back(PackJob{q.Wp, (long)q.wpad * q.ldw, q.wpad, q.ldw, q.Wf});
+  for (auto& q : m.sdf) if (q.Wtf) pj.push_back(PackJob{q.Wtp, (long)q.kpad * q.ldwt, q.kpad, q.ldwt, q.Wtf});
   // the hidden layers of the ReLU stacks (chain-fused forward, cnr_chain_fwd.hip); their 3-wide heads stay fp32
   for (auto& q : m.col) if (q.Wf && q.n == 256) pj.push_back(PackJob{q.Wp, (long)q.wpad * q.ldw, q.wpad, q.ldw, q.Wf});
   for (auto& q : m.rel) if (q.Wf && q.n == 256) pj.push_back(PackJob{q.Wp, (long)q.wpad * q.ldw, q.wpad, q.ldw, q.Wf});
@@ -554,8 +557,29 @@ static int skip_off(const Model& m) {
   return 0;
 }
 
+// the whole gradient chain as one chain-fused launch (cnr_chain_fwd.hip); false: not handled
+static bool sdf_grad_chain_fused(const Model& m, long P, const float* const* Z, float* const* V, float* CE0, float* CES, cnr_stream s, float* const* rs) {
+  if (m.Hs != 256 || m.L < 2 || m.F != 256 || m.skip(m.L) || m.sdf[m.L].ldw < 256) return false;
+  SdfGradChain c;
+  c.P = P; c.nl = m.L; c.ldz = m.Hs; c.skip_mask = m.c.sdf_skip_mask; c.emb = m.emb;
+  c.vrow = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; c.vscale = 1.0f / m.c.sdf_scale;
+  c.ce0 = CE0; c.ces = CES; c.ces_off = skip_off(m);
+  for (int l = 0; l < m.L; ++l) {
+    const Lin& q = m.sdf[l];
+    if (!q.Wtf || !Z[l] || (l > 0 && !V[l - 1])) return false;
+    c.lay[l] = FusedLayer{q.Wtf, q.Wtps, nullptr, q.ldwt, q.k_int};
+    c.Z[l] = Z[l];
+    if (l > 0) { c.V[l - 1] = V[l - 1]; c.n_out[l] = m.sdf[l - 1].n; }
+    c.rs[l] = rs ? rs[l] : nullptr;
+    if (m.skip(l) && (l == 0 || q.k_int != m.sdf[l - 1].n + m.emb)) return false;
+    if (l > 0 && !m.skip(l) && q.k_int != m.sdf[l - 1].n) return false;
+  }
+  return be_sdf_grad_chain(c, s);
+}
+
 static void sdf_grad_chain(const Model& m, long P, const float* E, const float* const* Z, float* const* V, float* CE0, float* CES,
                            cnr_stream s, float* const* rs = nullptr /* [L] row scales of sigma'(z_l) v_l, see Ctx::rsX1 */) {
+  if (sdf_grad_chain_fused(m, P, Z, V, CE0, CES, s, rs)) return;
   const float inv_scale = 1.0f / m.c.sdf_scale;
   // V[l-1] of a skip layer is written over n < round_up(n,16) columns only (EK_SPLIT) but read back over the padded width by the
   // next GEMM of this chain: its pad columns must hold finite values whatever the caller's scratch contained (every user of the

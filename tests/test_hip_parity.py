@@ -199,10 +199,13 @@ def test_results_do_not_depend_on_scratch_contents():
         assert torch.equal(ref[4][k], got[4][k]), k
 
 
-@pytest.mark.parametrize("switch", ["CNR_DISABLE_WS", "CNR_WS_GENERIC", "CNR_DW_BF16", "CNR_DW_FP32", "CNR_WS_SERP=0", "CNR_WS_NOSTREAM"])
+@pytest.mark.parametrize("switch", ["CNR_DISABLE_WS", "CNR_WS_GENERIC", "CNR_DW_BF16", "CNR_DW_FP32", "CNR_WS_SERP=0", "CNR_WS_NOSTREAM",
+                                    "CNR_NO_FUSED", "CNR_NO_CHAIN_FWD", "CNR_NO_CHAIN_SDF", "CNR_CHAIN_GRAD"])
 def test_fallback_kernels_keep_parity(switch):
     """The debugging switches select the fallback kernels (FP32-MFMA layer GEMM, interpreted weight-stationary kernel, split-bf16 and
-    FP32-MFMA weight-gradient tiles, one walk direction for every layer launch, the general layer kernel instead of its stream form).  They are read once per process, so the G2 gate runs in a child process."""
+    FP32-MFMA weight-gradient tiles, one walk direction for every layer launch, the general layer kernel instead of its stream form, the
+    per-layer launches instead of the chain-fused forward kernels) or, for CNR_CHAIN_GRAD, the opt-in chain-fused gradient chain.  They are
+    read once per process, so the G2 gate runs in a child process."""
     name, _, val = switch.partition("=")
     env = dict(os.environ, **{name: val or "1"})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
