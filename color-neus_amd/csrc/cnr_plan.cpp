@@ -256,7 +256,8 @@ static void place_lin(Lin& q, Arena& a, bool want_wtf = false) {
   q.Wps = a.f(q.wpad > 256 ? q.wpad : 256);   // (the fused kernels read 256 column scales; entries >= npad are never used)
   q.Wtps = a.f(q.kpad > 256 ? q.kpad : 256);  // (likewise)
   q.Wf = (q.ldw <= 304) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldw / 16) * 2 * 64 * 8 / 2)) : nullptr;   // (<= 19 k16 blocks: 256 + 48)
-  q.Wtf = (want_wtf && q.ldwt <= 256 && q.kpad <= 256) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldwt / 16) * 2 * 64 * 8 / 2)) : nullptr;
+  static const bool grad_chain = getenv("CNR_CHAIN_GRAD") != nullptr;   // (the opt-in chain-fused gradient chain: its W^T fragments are only laid out and packed for it)
+  q.Wtf = (want_wtf && grad_chain && q.ldwt <= 256 && q.kpad <= 256) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldwt / 16) * 2 * 64 * 8 / 2)) : nullptr;
 }
 
 static void layout_weights(Model& m, Arena& a) {
