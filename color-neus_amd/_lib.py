@@ -41,6 +41,21 @@ class CnrOutGrads(C.Structure):
     _fields_ = [(n, _FP) for n in OUT_GRAD_FIELDS]
 
 
+class CnrNerfConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("D", "W", "multires", "multires_view", "skip_mask")]
+
+
+class CnrBgCompositeIn(C.Structure):
+    _fields_ = [("rays_o", _FP), ("rays_d", _FP), ("z_vals", _FP), ("z_feed", _FP), ("n_rays", C.c_int64), ("n_z", C.c_int32), ("n_feed", C.c_int32),
+                ("sample_dist", C.c_float), ("sdf_samples", _FP), ("gradients", _FP), ("color_samples", _FP), ("global_color_samples", _FP),
+                ("bg_alpha", _FP), ("bg_color", _FP), ("variance", _FP), ("cos_anneal_ratio", C.c_float), ("background_rgb", _FP)]
+
+
+class CnrBgCompositeGrads(C.Structure):
+    _fields_ = [(n, _FP) for n in ("d_sdf_samples", "d_gradients", "d_color_samples", "d_global_color_samples", "d_bg_alpha", "d_bg_color",
+                                   "d_variance", "d_rays_d", "d_z_vals", "d_z_feed")]
+
+
 class CnrKernelTiming(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("kind", C.c_int32), ("nt", C.c_int32), ("P", C.c_int64), ("N", C.c_int32),
                 ("K", C.c_int32), ("pairs", C.c_int32), ("ms", C.c_float), ("bytes", C.c_double)]
@@ -83,7 +98,10 @@ EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_c
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_sdf_grid_slab_scratch_bytes", "cnr_sdf_grid_slab", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
            "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_sums_ray", "cnr_loss_grads", "cnr_loss_combine", "cnr_loss_coef",
            "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward", "cnr_sample_z", "cnr_mc_scratch_bytes", "cnr_mc_count", "cnr_mc_emit",
-           "cnr_linear_scratch_bytes", "cnr_linear_forward", "cnr_linear_backward"]
+           "cnr_linear_scratch_bytes", "cnr_linear_forward", "cnr_linear_backward",
+           "cnr_nerf_param_count", "cnr_nerf_param_info", "cnr_outside_z", "cnr_outside_z_backward", "cnr_background_ctx_bytes",
+           "cnr_background_bwd_scratch_bytes", "cnr_background_forward", "cnr_background_backward", "cnr_composite_background_scratch_bytes",
+           "cnr_composite_background_forward", "cnr_composite_background_backward"]
 
 
 class RenderLibrary:
@@ -146,7 +164,23 @@ class RenderLibrary:
         L.cnr_timing_enable.argtypes = [C.c_int]
         L.cnr_timing_enable.restype = None
         L.cnr_timing_collect.argtypes = [C.POINTER(CnrKernelTiming), C.c_int]
-        if L.cnr_abi_version() != 4:
+        L.cnr_nerf_param_count.argtypes = [C.POINTER(CnrNerfConfig)]
+        L.cnr_nerf_param_info.argtypes = [C.POINTER(CnrNerfConfig), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.cnr_outside_z.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP]
+        L.cnr_outside_z_backward.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP]
+        for f in ("cnr_background_ctx_bytes", "cnr_background_bwd_scratch_bytes"):
+            getattr(L, f).restype = C.c_size_t
+            getattr(L, f).argtypes = [C.POINTER(CnrNerfConfig), C.c_int64, C.c_int32]
+        L.cnr_background_forward.argtypes = [C.POINTER(CnrNerfConfig), C.POINTER(_FP), _FP, _FP, _FP, C.c_int64, C.c_int32, C.c_float, _FP, _FP, _FP,
+                                             C.c_size_t, _FP]
+        L.cnr_background_backward.argtypes = [C.POINTER(CnrNerfConfig), C.POINTER(_FP), _FP, _FP, _FP, C.c_int64, C.c_int32, C.c_float, _FP, C.c_size_t,
+                                              _FP, _FP, _FP, C.POINTER(_FP), _FP, _FP, _FP, _FP, C.c_size_t, _FP]
+        L.cnr_composite_background_scratch_bytes.restype = C.c_size_t
+        L.cnr_composite_background_scratch_bytes.argtypes = [C.c_int64]
+        L.cnr_composite_background_forward.argtypes = [C.POINTER(CnrBgCompositeIn), C.POINTER(CnrOutputs), _FP, C.c_size_t, _FP]
+        L.cnr_composite_background_backward.argtypes = [C.POINTER(CnrBgCompositeIn), C.POINTER(CnrOutputs), C.POINTER(CnrOutGrads),
+                                                        C.POINTER(CnrBgCompositeGrads), _FP, C.c_size_t, _FP]
+        if L.cnr_abi_version() != 5:
             raise RuntimeError("colorneus library ABI mismatch")
 
     @property

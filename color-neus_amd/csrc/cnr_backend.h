@@ -7,6 +7,7 @@
 namespace cnr {
 
 constexpr int kMaxRaySamples = 256;   // per-ray kernels stage one ray in LDS: M <= 256
+constexpr int kMaxOutside = 128;      // background samples per ray (N_OUTSIDE)
 
 struct Segment { int dst, src, len; };   // internal column [dst, dst+len) <- reference column [src, src+len)
 
@@ -417,6 +418,72 @@ CNR_HD int mc_cell(const float* u, int res, float thr, int x, int y, int z, unsi
   return idx;
 }
 CNR_HD int mc_popcount3(unsigned x) { return (int)((x & 1) + ((x >> 1) & 1) + ((x >> 2) & 1)); }
+
+// ---- N_OUTSIDE > 0: the NeRF++ background of NeuS (NeuS.py:95-134, 313-369; NeRF, fields.py:192-274) -----------------------------------
+// No shipped configuration enables it; these kernels favour plain code over speed (one thread per ray / per point).
+struct OutsideZ {       // background sample positions (NeuS.py:315-338) merged with the sorted foreground samples (NeuS.py:353-355)
+  long R; int M, n_out, n_samples;
+  const float* far_; const float* t_rand /* [R][n_out] uniform draws (NeuS.py:335) or null: no perturbation */; const float* z /* [R][M], ascending */;
+  float* z_feed;        // [R][M + n_out] ascending
+  int* src;             // [R][M + n_out]: j >= 0: z[j];  -1 - k: background sample k
+};
+struct OutsideZBwd {    // d far (z_out[k] = far / zz[n_out - 1 - k] + 1 / n_samples) and, for the copies of z in z_feed, d z
+  long R; int M, n_out, n_samples; const float* t_rand; const int* src; const float* d_z_feed;
+  float* d_far;         // [R]
+  float* d_z;           // [R][M] or null
+};
+struct BgEmbed {        // render_core_outside's inputs (NeuS.py:102-115): section length, mid point, [p / r, 1 / r], PE-multires of it, PE-multires_view of the direction
+  const float* o; const float* d; const float* z_feed; long R; int MF; float sample_dist; int multires, multires_view;
+  float* E; int lde;               // [n][lde]: PE row (4 + 8 multires live columns, zero padded)
+  float* XH; int ldxh, xh_off;     // optional second copy of the PE row: XH[pt][xh_off + c] (the skip layer's input tail, zero padded up to ldxh)
+  float* FV; int ldfv, fv_off;     // PE of the view direction: FV[pt][fv_off + c] (the view layer's input tail, zero padded up to ldfv)
+  float* dist;                     // [n] section lengths
+};
+struct BgAlpha {        // alpha = 1 - exp(-softplus(density) dist) (NeuS.py:119-120)
+  long n; const float* density; const float* dist; float* alpha;
+};
+struct BgHeadsBwd {     // cotangents of the two heads' pre-activations: d density (through alpha) and d rgb_pre (through the sigmoid), d dist
+  long n; const float* density; const float* dist; const float* rgb /* [n][3] post-sigmoid */; const float* d_alpha; const float* d_rgb /* [n][3] */;
+  float* d_density /* [n][ldd], column 0 live, the rest zero */; int ldd; float* d_rgb_pre /* [n][ldr], 3 live */; int ldr; float* d_dist /* [n] */;
+};
+struct BgJoin {         // dZ[pt][c] = H[pt][c] > 0 ? T[pt][c] + d_density[pt] * w_alpha[c] : 0: the last hidden layer feeds the feature layer AND the density head
+  long n; int W; const float* T; const float* H; const float* d_density; int ldd; const float* w_alpha; float* dZ;
+};
+struct BgEmbedBwd {     // per point: cotangent of the sample point p and of the view direction from the PE cotangents
+  const float* o; const float* d; const float* z_feed; long R; int MF; float sample_dist; int multires, multires_view;
+  const float* dE0; int lde0; const float* dE1; int lde1 /* second PE cotangent (skip layer) or null */; const float* dVE; int ldve;
+  float* dp;            // [n][8]: {dp.x, dp.y, dp.z, dview.x, dview.y, dview.z, 0, 0}
+};
+struct BgRaysBwd {      // per ray: d rays_o, d rays_d, d z_feed from the per-point cotangents
+  const float* d; const float* z_feed; long R; int MF; float sample_dist; const float* dp; const float* d_dist;
+  float* d_o; float* d_d; float* d_z_feed;   // [R][3], [R][3], [R][MF] (d_z_feed is ADDED to: the compositor's depth term lands there first)
+};
+struct CompositeBg {    // render_core with a background (NeuS.py:236-292, Color_NeuS.py:66-138): S-density alpha, inside / outside mixing, compositing over M + n_out samples
+  const float* o; const float* d; const float* z; const float* z_feed; long R; int M, MF; float sample_dist;
+  const float* sdf; const float* g /* [R][M][3] */; const float* color /* [R][M][3] */; const float* gcolor /* [R][M][3] or null */;
+  const float* bg_alpha /* [R][MF] */; const float* bg_color /* [R][MF][3] */;
+  const float* variance; float cos_anneal; const float* background_rgb;
+  float* color_fine; float* s_val; float* cdf_fine; float* weight_sum; float* weight_max; float* weights /* [R][MF] */; float* inside_sphere;
+  float* depth; float* global_color; float* eik_partial /* [R][2] */;
+};
+struct CompositeBgBwd {
+  CompositeBg f;        // the forward arguments (outputs unused except weights)
+  const float* d_color_fine; const float* d_s_val; const float* d_cdf; const float* d_weight_sum; const float* d_weight_max; const float* d_weights;
+  const float* d_gradient_error; const float* d_depth; const float* d_global_color; const float* d_gradients /* [R][M][3] or null */;
+  const float* eik_sums;   // [2] of the forward pass
+  float* d_sdf; float* d_g; float* d_color; float* d_gcolor; float* d_bg_alpha; float* d_bg_color;
+  float* d_inv_s_partial /* [R] */; float* d_rays_d /* [R][3] */; float* d_z /* [R][M] */; float* d_z_feed /* [R][MF] */;
+};
+void be_outside_z(const OutsideZ& p, cnr_stream s);
+void be_outside_z_bwd(const OutsideZBwd& p, cnr_stream s);
+void be_bg_embed(const BgEmbed& p, cnr_stream s);
+void be_bg_alpha(const BgAlpha& p, cnr_stream s);
+void be_bg_heads_bwd(const BgHeadsBwd& p, cnr_stream s);
+void be_bg_join(const BgJoin& p, cnr_stream s);
+void be_bg_embed_bwd(const BgEmbedBwd& p, cnr_stream s);
+void be_bg_rays_bwd(const BgRaysBwd& p, cnr_stream s);
+void be_composite_bg(const CompositeBg& p, cnr_stream s);
+void be_composite_bg_bwd(const CompositeBgBwd& p, cnr_stream s);
 
 // p[row][c] = 0 for c in [c0, c1), row < rows: zero the pad columns a GEMM reads without touching the rest of a wide buffer
 void be_zero_cols(float* p, int ld, int c0, int c1, long rows, cnr_stream s);

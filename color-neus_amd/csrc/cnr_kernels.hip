@@ -385,6 +385,27 @@ static void embed_z_launch(const EmbedZ& p, long n, cnr_stream s) { staged_rows_
 static void embed_pts_launch(const EmbedPts& p, long n, cnr_stream s) { staged_rows_launch<EmbedPts, body_embed_pts_rows>("embed_pts", p, n, p.E, p.AUX, s); CNR_LAUNCH_CHECK("embed_pts"); }
 static void fine_setup_launch(const FineSetup& p, long n, cnr_stream s) { staged_rows_launch<FineSetup, body_fine_setup_rows>("fine_setup", p, n, p.E, p.AUX, s); CNR_LAUNCH_CHECK("fine_setup"); }
 CNR_PW_KERNEL(coltop_bwd, ColTopBwd, body_coltop_bwd)
+// N_OUTSIDE > 0 (NeRF++ background): plain per-ray / per-point kernels
+CNR_PW_KERNEL(outside_z, OutsideZ, body_outside_z)
+CNR_PW_KERNEL(outside_z_bwd, OutsideZBwd, body_outside_z_bwd)
+CNR_PW_KERNEL(bg_embed, BgEmbed, body_bg_embed)
+CNR_PW_KERNEL(bg_alpha, BgAlpha, body_bg_alpha)
+CNR_PW_KERNEL(bg_heads_bwd, BgHeadsBwd, body_bg_heads_bwd)
+CNR_PW_KERNEL(bg_join, BgJoin, body_bg_join)
+CNR_PW_KERNEL(bg_embed_bwd, BgEmbedBwd, body_bg_embed_bwd)
+CNR_PW_KERNEL(bg_rays_bwd, BgRaysBwd, body_bg_rays_bwd)
+CNR_PW_KERNEL(composite_bg, CompositeBg, body_composite_bg)
+CNR_PW_KERNEL(composite_bg_bwd, CompositeBgBwd, body_composite_bg_bwd)
+void be_outside_z(const OutsideZ& p, cnr_stream s) { outside_z_launch(p, p.R, s); }
+void be_outside_z_bwd(const OutsideZBwd& p, cnr_stream s) { outside_z_bwd_launch(p, p.R, s); }
+void be_bg_embed(const BgEmbed& p, cnr_stream s) { bg_embed_launch(p, p.R * p.MF, s); }
+void be_bg_alpha(const BgAlpha& p, cnr_stream s) { bg_alpha_launch(p, p.n, s); }
+void be_bg_heads_bwd(const BgHeadsBwd& p, cnr_stream s) { bg_heads_bwd_launch(p, p.n, s); }
+void be_bg_join(const BgJoin& p, cnr_stream s) { bg_join_launch(p, p.n * p.W, s); }
+void be_bg_embed_bwd(const BgEmbedBwd& p, cnr_stream s) { bg_embed_bwd_launch(p, p.R * p.MF, s); }
+void be_bg_rays_bwd(const BgRaysBwd& p, cnr_stream s) { bg_rays_bwd_launch(p, p.R, s); }
+void be_composite_bg(const CompositeBg& p, cnr_stream s) { composite_bg_launch(p, p.R, s); }
+void be_composite_bg_bwd(const CompositeBgBwd& p, cnr_stream s) { composite_bg_bwd_launch(p, p.f.R, s); }
 CNR_PW_KERNEL(pbar_finish, PbarFinish, body_pbar_finish)
 CNR_PW_KERNEL(gen_rays, GenRays, body_gen_rays)
 

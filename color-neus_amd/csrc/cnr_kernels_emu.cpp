@@ -124,6 +124,16 @@ CNR_PW(be_grad_finish, GradFinish, body_grad_finish, p.P)
 CNR_PW(be_coltop_bwd, ColTopBwd, body_coltop_bwd, p.P)
 CNR_PW(be_gbar_finish, GbarFinish, body_gbar_finish, p.P)
 CNR_PW(be_pbar_finish, PbarFinish, body_pbar_finish, p.P)
+CNR_PW(be_outside_z, OutsideZ, body_outside_z, p.R)
+CNR_PW(be_outside_z_bwd, OutsideZBwd, body_outside_z_bwd, p.R)
+CNR_PW(be_bg_embed, BgEmbed, body_bg_embed, p.R* p.MF)
+CNR_PW(be_bg_alpha, BgAlpha, body_bg_alpha, p.n)
+CNR_PW(be_bg_heads_bwd, BgHeadsBwd, body_bg_heads_bwd, p.n)
+CNR_PW(be_bg_join, BgJoin, body_bg_join, p.n* p.W)
+CNR_PW(be_bg_embed_bwd, BgEmbedBwd, body_bg_embed_bwd, p.R* p.MF)
+CNR_PW(be_bg_rays_bwd, BgRaysBwd, body_bg_rays_bwd, p.R)
+CNR_PW(be_composite_bg, CompositeBg, body_composite_bg, p.R)
+CNR_PW(be_composite_bg_bwd, CompositeBgBwd, body_composite_bg_bwd, p.f.R)
 
 void be_head_bwd(const HeadBwd& p, cnr_stream) {
   const long per = round_up((int)((p.P + p.nslots - 1) / p.nslots), 64);

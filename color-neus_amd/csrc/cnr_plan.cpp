@@ -1390,6 +1390,259 @@ static void pad_in(float* dst, int ld, const float* src, int c, long n, cnr_stre
   be_zero_cols(dst, ld, c, ld, n, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// N_OUTSIDE > 0: the NeRF++ background network (NeRF, fields.py:192-274) evaluated by render_core_outside (NeuS.py:95-134) as ONE library
+// call each way: positional encodings, the D x W ReLU stack with its skip concat, density and feature heads, the view branch, density ->
+// alpha and sigmoid(rgb); backward through all of it down to the rays and the sample positions.  Layer launches: the render path's layer /
+// weight-gradient kernels (whatever shape fits: the 340- and 283-wide layers take the FP32-MFMA forms).
+// Internal input order of the skip layer is [h | e] (the reference concatenates [e | h], fields.py:252-253: a column permutation of its
+// weights, like colour layer 0), so that the layer in front of it writes h into an aligned position and the backward launch's split
+// epilogue separates the two cotangents.
+// ------------------------------------------------------------------------------------------------
+struct NerfModel {
+  cnr_nerf_config c;
+  int D, W, ne, nv;                   // depth, width, PE widths (4 + 8 multires, 3 + 6 multires_view)
+  std::vector<Lin> pts;               // D layers
+  Lin alpha, feat, view, rgb;
+  std::vector<ParamInfo> params;
+  int skip_at = -1;                   // the layer AFTER which [e | h] is concatenated (input of layer skip_at + 1), -1: none
+};
+static int nerf_add(NerfModel& m, Lin& q, const std::string& name) {
+  q.name = name; q.wn = false;
+  q.p_v = (int)m.params.size(); m.params.push_back({name + ".weight", q.n, q.k_ref});
+  q.p_b = (int)m.params.size(); m.params.push_back({name + ".bias", q.n, 1});
+  return 0;
+}
+static int build_nerf(const cnr_nerf_config* cfg, NerfModel& m) {
+  if (!cfg) return fail("null nerf config");
+  m.c = *cfg;
+  m.D = cfg->D; m.W = cfg->W;
+  if (m.D < 2 || m.D > kMaxLayers - 1 || m.W < 32 || m.W > 256 || m.W % 32) return fail("nerf: D in [2, %d], W a multiple of 32 in [32, 256]", kMaxLayers - 1);
+  if (cfg->multires < 0 || cfg->multires > 10 || cfg->multires_view < 0 || cfg->multires_view > 4) return fail("nerf: multires <= 10, multires_view <= 4");
+  m.ne = 4 + 8 * cfg->multires; m.nv = 3 + 6 * cfg->multires_view;
+  int nskip = 0;
+  for (int i = 0; i < m.D - 1; ++i) if ((cfg->skip_mask >> i) & 1) { m.skip_at = i; ++nskip; }
+  if (nskip > 1 || (cfg->skip_mask >> (m.D - 1)) != 0) return fail("nerf: at most one skip connection, below the last layer");
+  m.pts.resize(m.D);
+  for (int i = 0; i < m.D; ++i) {
+    Lin& q = m.pts[i];
+    q.n = m.W;
+    if (i == 0) { q.k_ref = m.ne; identity_seg(q); }
+    else if (i - 1 == m.skip_at) {      // reference input [e | h] -> internal [h | e]
+      q.k_ref = m.W + m.ne; q.k_int = q.k_ref; q.nseg = 2;
+      q.seg[0] = {0, m.ne, m.W}; q.seg[1] = {m.W, 0, m.ne};
+    } else { q.k_ref = m.W; identity_seg(q); }
+    q.finish_dims();
+    nerf_add(m, q, "pts_linears." + std::to_string(i));
+  }
+  // nn.Module registration order of NeRF.__init__ (fields.py:215-231): pts_linears, views_linears, feature_linear, alpha_linear, rgb_linear
+  m.view.n = m.W / 2; m.view.k_ref = m.W + m.nv; identity_seg(m.view); m.view.finish_dims(); nerf_add(m, m.view, "views_linears.0");
+  m.feat.n = m.W; m.feat.k_ref = m.W; identity_seg(m.feat); m.feat.finish_dims(); nerf_add(m, m.feat, "feature_linear");
+  m.alpha.n = 1; m.alpha.k_ref = m.W; identity_seg(m.alpha); m.alpha.finish_dims(); nerf_add(m, m.alpha, "alpha_linear");
+  m.rgb.n = 3; m.rgb.k_ref = m.W / 2; identity_seg(m.rgb); m.rgb.finish_dims(); nerf_add(m, m.rgb, "rgb_linear");
+  return 0;
+}
+struct NerfCtx {       // forward-saved state of one background call
+  int lde, ldxh, ldfv;
+  float *E, *XH, *FV, *HV, *dens, *dist;
+  std::vector<float*> H;             // output of pts layer i ([n][W]); H[skip_at] aliases XH (row stride ldxh)
+};
+static void nerf_layers(NerfModel& m, std::vector<Lin*>& all) {
+  for (auto& q : m.pts) all.push_back(&q);
+  all.push_back(&m.view); all.push_back(&m.feat); all.push_back(&m.alpha); all.push_back(&m.rgb);
+}
+static void layout_nerf(NerfModel& m, long n, Arena& a, NerfCtx& x) {
+  std::vector<Lin*> all;
+  nerf_layers(m, all);
+  for (Lin* q : all) place_lin(*q, a);
+  x.lde = round_up(m.ne, 16);
+  x.ldxh = round_up(m.W + m.ne, 16);
+  x.ldfv = round_up(m.W + m.nv, 16);
+  x.E = a.f((size_t)n * x.lde);
+  x.XH = m.skip_at >= 0 ? a.f((size_t)n * x.ldxh) : nullptr;
+  x.FV = a.f((size_t)n * x.ldfv);
+  x.HV = a.f((size_t)n * (m.W / 2));
+  x.dens = a.f(n);
+  x.dist = a.f(n);
+  x.H.resize(m.D);
+  for (int i = 0; i < m.D; ++i) x.H[i] = (i == m.skip_at) ? x.XH : a.f((size_t)n * m.W);
+  a.f(1024);
+}
+static int nerf_h_ld(const NerfModel& m, const NerfCtx& x, int i) { return i == m.skip_at ? x.ldxh : m.W; }
+static void nerf_prep(NerfModel& m, const float* const* params, cnr_stream s) {
+  std::vector<Lin*> all;
+  nerf_layers(m, all);
+  std::vector<PrepWeight> pw;
+  std::vector<SplitJob> sj;
+  for (Lin* qp : all) {
+    Lin& q = *qp;
+    PrepWeight p;
+    p.g = nullptr; p.v = params[q.p_v]; p.b = params[q.p_b]; p.n = q.n; p.k_ref = q.k_ref; p.nseg = q.nseg;
+    for (int i = 0; i < q.nseg; ++i) p.seg[i] = q.seg[i];
+    p.W = q.W; p.ldw = q.ldw; p.npad = q.wpad; p.Wt = q.Wt; p.ldwt = q.ldwt; p.kpad = q.kpad; p.bias = q.bias; p.row_rot = 0;
+    pw.push_back(p);
+    sj.push_back(SplitJob{q.W, q.wpad, q.ldw, q.Wp, q.Wps});
+    sj.push_back(SplitJob{q.Wt, q.kpad, q.ldwt, q.Wtp, q.Wtps});
+  }
+  be_prep_weights(pw.data(), (int)pw.size(), s);
+  be_split_planes_many(sj.data(), (int)sj.size(), s);
+}
+static LayerGemm nerf_fwd_gemm(const Lin& q, const float* in, int ld_in, long n) {
+  LayerGemm g;
+  g.A.kind = VK_DIRECT; g.A.a = in; g.A.lda = ld_in;
+  g.W = q.W; g.ldw = q.ldw; g.Wp = q.Wp; g.wp_stride = (long)q.wpad * q.ldw; g.w_rows = q.wpad; g.wscale = q.Wps; g.N = q.n; g.K = q.k_int; g.P = n;
+  g.E.bias = q.bias; g.E.n_out = q.n;
+  return g;
+}
+static int background_forward(const cnr_nerf_config* cfg, const float* const* params, const float* rays_o, const float* rays_d, const float* z_feed,
+                              long R, int MF, float sample_dist, float* alpha, float* color, void* ctx, size_t ctx_bytes, cnr_stream s) {
+  NerfModel m;
+  if (build_nerf(cfg, m)) return -1;
+  if (!params || !rays_o || !rays_d || !z_feed || !alpha || !color || !ctx) return fail("null argument");
+  if (R <= 0 || MF < 1 || MF > kMaxRaySamples) return fail("background: n_rays > 0, 1 <= samples per ray <= %d", kMaxRaySamples);
+  const long n = R * MF;
+  Arena a(ctx);
+  NerfCtx x;
+  layout_nerf(m, n, a, x);
+  if (a.off > ctx_bytes) return fail("background context too small: need %zu bytes, got %zu", a.off, ctx_bytes);
+  nerf_prep(m, params, s);
+  BgEmbed e;
+  e.o = rays_o; e.d = rays_d; e.z_feed = z_feed; e.R = R; e.MF = MF; e.sample_dist = sample_dist; e.multires = cfg->multires; e.multires_view = cfg->multires_view;
+  e.E = x.E; e.lde = x.lde; e.XH = x.XH; e.ldxh = x.ldxh; e.xh_off = m.W; e.FV = x.FV; e.ldfv = x.ldfv; e.fv_off = m.W; e.dist = x.dist;
+  be_bg_embed(e, s);
+  for (int i = 0; i < m.D; ++i) {
+    const Lin& q = m.pts[i];
+    LayerGemm g = nerf_fwd_gemm(q, i == 0 ? x.E : x.H[i - 1], i == 0 ? x.lde : nerf_h_ld(m, x, i - 1), n);
+    g.E.kind = EK_RELU; g.E.o1 = x.H[i]; g.E.ld1 = nerf_h_ld(m, x, i);
+    be_layer_gemm(g, s);
+  }
+  const float* hl = x.H[m.D - 1];
+  const int ldh = nerf_h_ld(m, x, m.D - 1);
+  {
+    LayerGemm g = nerf_fwd_gemm(m.alpha, hl, ldh, n);
+    g.Wp = nullptr; g.E.kind = EK_STORE; g.E.o1 = x.dens; g.E.ld1 = 1;
+    be_layer_gemm(g, s);
+    LayerGemm f = nerf_fwd_gemm(m.feat, hl, ldh, n);
+    f.E.kind = EK_STORE; f.E.o1 = x.FV; f.E.ld1 = x.ldfv;
+    be_layer_gemm(f, s);
+    LayerGemm v = nerf_fwd_gemm(m.view, x.FV, x.ldfv, n);
+    v.E.kind = EK_RELU; v.E.o1 = x.HV; v.E.ld1 = m.W / 2;
+    be_layer_gemm(v, s);
+    LayerGemm c = nerf_fwd_gemm(m.rgb, x.HV, m.W / 2, n);
+    c.Wp = nullptr; c.E.kind = EK_SIGMOID; c.E.o1 = color; c.E.ld1 = 3;
+    be_layer_gemm(c, s);
+  }
+  BgAlpha ba;
+  ba.n = n; ba.density = x.dens; ba.dist = x.dist; ba.alpha = alpha;
+  be_bg_alpha(ba, s);
+  return check_backend("background_forward");
+}
+struct NerfBwd { float *dRGB, *dDens, *dDist, *DHV, *dF, *dVE, *T, *dEs, *dE0, *dp; std::vector<float*> DZ; float* part; size_t part_floats; int nchunk; };
+static void layout_nerf_bwd(NerfModel& m, const NerfCtx& x, long n, Arena& a, NerfBwd& b) {
+  b.dRGB = a.f((size_t)n * 16); b.dDens = a.f((size_t)n * 16); b.dDist = a.f(n);
+  b.DHV = a.f((size_t)n * (m.W / 2)); b.dF = a.f((size_t)n * m.W); b.dVE = a.f((size_t)n * 32);
+  b.T = a.f((size_t)n * m.W); b.dEs = m.skip_at >= 0 ? a.f((size_t)n * x.lde) : nullptr; b.dE0 = a.f((size_t)n * x.lde); b.dp = a.f((size_t)n * 8);
+  b.DZ.resize(m.D);
+  for (int i = 0; i < m.D; ++i) b.DZ[i] = a.f((size_t)n * m.W);
+  long nch = n / 128; if (nch < 1) nch = 1; if (nch > 256) nch = 256;
+  b.nchunk = (int)nch;
+  std::vector<Lin*> all;
+  nerf_layers(m, all);
+  size_t tot = 0;
+  for (Lin* q : all) tot += round_up_sz((size_t)b.nchunk * q->npad * q->ldw, 64) + round_up_sz((size_t)b.nchunk * q->npad, 64);
+  b.part_floats = tot; b.part = a.f(tot);
+  a.f(1024);
+}
+// weight + bias gradient of one background layer: dW = sum_pt X (x) Y, db = column sums of X; queued for one batched finish
+static void nerf_dw(const Lin& q, const float* X, int ldx, const float* Y, int ldy, long n, NerfBwd& b, size_t& off, const float* const* params,
+                    float* const* dP, std::vector<FinishWeight>& pend, cnr_stream s) {
+  float* part = b.part + off; off += round_up_sz((size_t)b.nchunk * q.npad * q.ldw, 64);
+  float* csum = b.part + off; off += round_up_sz((size_t)b.nchunk * q.npad, 64);
+  DwGemm d;
+  d.npairs = 1; d.P = n; d.X[0].kind = VK_DIRECT; d.X[0].a = X; d.X[0].lda = ldx; d.Y[0].kind = VK_DIRECT; d.Y[0].a = Y; d.Y[0].lda = ldy;
+  d.N = q.n; d.K = q.k_int; d.nchunk = b.nchunk; d.chunk_pts = round_up((int)((n + b.nchunk - 1) / b.nchunk), 16);
+  d.partial = part; d.Npad = q.npad; d.ldk = q.ldw; d.colsum = csum; d.split_f16 = false;
+  be_dw_gemm(d, s);
+  FinishWeight f;
+  f.partial = part; f.nchunk = b.nchunk; f.npad = q.npad; f.ldk = q.ldw; f.colsum = csum; f.ncolsum = b.nchunk;
+  f.g = nullptr; f.v = params[q.p_v]; f.n = q.n; f.k_ref = q.k_ref; f.nseg = q.nseg;
+  for (int i = 0; i < q.nseg; ++i) f.seg[i] = q.seg[i];
+  f.dg = nullptr; f.dv = dP[q.p_v]; f.db = dP[q.p_b]; f.row_rot = 0;
+  pend.push_back(f);
+}
+static LayerGemm nerf_bwd_gemm(const Lin& q, const float* dout, int ldo, long n) {
+  LayerGemm g;
+  g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo;
+  g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = n;
+  g.E.n_out = q.k_int;
+  return g;
+}
+static int background_backward(const cnr_nerf_config* cfg, const float* const* params, const float* rays_o, const float* rays_d, const float* z_feed,
+                               long R, int MF, float sample_dist, const void* ctx, size_t ctx_bytes, const float* color, const float* d_alpha,
+                               const float* d_color, float* const* dP, float* d_rays_o, float* d_rays_d, float* d_z_feed, void* scratch,
+                               size_t scratch_bytes, cnr_stream s) {
+  NerfModel m;
+  if (build_nerf(cfg, m)) return -1;
+  if (!params || !rays_o || !rays_d || !z_feed || !ctx || !color || !dP || !d_rays_o || !d_rays_d || !d_z_feed || !scratch) return fail("null argument");
+  const long n = R * MF;
+  Arena a(const_cast<void*>(ctx));
+  NerfCtx x;
+  layout_nerf(m, n, a, x);
+  if (a.off > ctx_bytes) return fail("background context too small");
+  Arena sa(scratch);
+  NerfBwd b;
+  layout_nerf_bwd(m, x, n, sa, b);
+  if (sa.off > scratch_bytes) return fail("background scratch too small: need %zu bytes, got %zu", sa.off, scratch_bytes);
+  std::vector<FinishWeight> pend;
+  size_t off = 0;
+  BgHeadsBwd hb;
+  hb.n = n; hb.density = x.dens; hb.dist = x.dist; hb.rgb = color; hb.d_alpha = d_alpha; hb.d_rgb = d_color;
+  hb.d_density = b.dDens; hb.ldd = 16; hb.d_rgb_pre = b.dRGB; hb.ldr = 16; hb.d_dist = b.dDist;
+  be_bg_heads_bwd(hb, s);
+  const float* hl = x.H[m.D - 1];
+  const int ldh = nerf_h_ld(m, x, m.D - 1);
+  // rgb head: dW, cotangent of the view layer's pre-activation (ReLU mask)
+  nerf_dw(m.rgb, b.dRGB, 16, x.HV, m.W / 2, n, b, off, params, dP, pend, s);
+  { LayerGemm g = nerf_bwd_gemm(m.rgb, b.dRGB, 16, n); g.Wp = nullptr; g.E.kind = EK_RELU_MASK; g.E.o1 = b.DHV; g.E.ld1 = m.W / 2; g.E.aux = x.HV; g.E.ldaux = m.W / 2; be_layer_gemm(g, s); }
+  // view layer: dW, cotangent of [feature | PE(view)]
+  nerf_dw(m.view, b.DHV, m.W / 2, x.FV, x.ldfv, n, b, off, params, dP, pend, s);
+  { LayerGemm g = nerf_bwd_gemm(m.view, b.DHV, m.W / 2, n); g.E.kind = EK_SPLIT; g.E.split = m.W; g.E.o1 = b.dF; g.E.ld1 = m.W; g.E.o2 = b.dVE; g.E.ld2 = 32; be_layer_gemm(g, s); }
+  be_zero_cols(b.dVE, 32, m.nv, 32, n, s);
+  // feature layer and density head: both read the last hidden activation
+  nerf_dw(m.feat, b.dF, m.W, hl, ldh, n, b, off, params, dP, pend, s);
+  nerf_dw(m.alpha, b.dDens, 16, hl, ldh, n, b, off, params, dP, pend, s);
+  { LayerGemm g = nerf_bwd_gemm(m.feat, b.dF, m.W, n); g.E.kind = EK_STORE; g.E.o1 = b.T; g.E.ld1 = m.W; be_layer_gemm(g, s); }
+  if (ldh != m.W) return fail("background: the last layer cannot carry the skip concat");
+  BgJoin bj;
+  bj.n = n; bj.W = m.W; bj.T = b.T; bj.H = hl; bj.d_density = b.dDens; bj.ldd = 16; bj.w_alpha = m.alpha.W; bj.dZ = b.DZ[m.D - 1];
+  be_bg_join(bj, s);
+  for (int i = m.D - 1; i >= 0; --i) {
+    const Lin& q = m.pts[i];
+    const float* in = i == 0 ? x.E : x.H[i - 1];
+    const int ld_in = i == 0 ? x.lde : nerf_h_ld(m, x, i - 1);
+    nerf_dw(q, b.DZ[i], m.W, in, ld_in, n, b, off, params, dP, pend, s);
+    LayerGemm g = nerf_bwd_gemm(q, b.DZ[i], m.W, n);
+    if (i == 0) { g.E.kind = EK_STORE; g.E.o1 = b.dE0; g.E.ld1 = x.lde; }
+    else if (i - 1 == m.skip_at) {    // input [h | e]: h part through the ReLU mask of the layer below, e part to its own buffer
+      g.E.kind = EK_RELU_MASK; g.E.split = m.W; g.E.o1 = b.DZ[i - 1]; g.E.ld1 = m.W; g.E.aux = x.H[i - 1]; g.E.ldaux = ld_in; g.E.o2 = b.dEs; g.E.ld2 = x.lde;
+    } else { g.E.kind = EK_RELU_MASK; g.E.split = 1 << 30; g.E.o1 = b.DZ[i - 1]; g.E.ld1 = m.W; g.E.aux = x.H[i - 1]; g.E.ldaux = ld_in; }
+    be_layer_gemm(g, s);
+  }
+  be_zero_cols(b.dE0, x.lde, m.ne, x.lde, n, s);
+  if (b.dEs) be_zero_cols(b.dEs, x.lde, m.ne, x.lde, n, s);
+  be_finish_weights(pend.data(), (int)pend.size(), s);
+  BgEmbedBwd eb;
+  eb.o = rays_o; eb.d = rays_d; eb.z_feed = z_feed; eb.R = R; eb.MF = MF; eb.sample_dist = sample_dist; eb.multires = cfg->multires; eb.multires_view = cfg->multires_view;
+  eb.dE0 = b.dE0; eb.lde0 = x.lde; eb.dE1 = b.dEs; eb.lde1 = x.lde; eb.dVE = b.dVE; eb.ldve = 32; eb.dp = b.dp;
+  be_bg_embed_bwd(eb, s);
+  BgRaysBwd rb;
+  rb.d = rays_d; rb.z_feed = z_feed; rb.R = R; rb.MF = MF; rb.sample_dist = sample_dist; rb.dp = b.dp; rb.d_dist = b.dDist;
+  rb.d_o = d_rays_o; rb.d_d = d_rays_d; rb.d_z_feed = d_z_feed;
+  be_memset_zero(d_z_feed, (size_t)n * sizeof(float), s);
+  be_bg_rays_bwd(rb, s);
+  return check_backend("background_backward");
+}
+
 constexpr long kVcChunk = 1 << 16;
 
 __attribute__((unused)) static void copy_rgb_stub() {}
@@ -1748,6 +2001,123 @@ int cnr_linear_forward(const float* x, int64_t n, int32_t k, const float* W, con
   be_layer_gemm(g, s);
   be_copy_cols(y, n_out, op.yp, op.ldy, n_out, n, s);
   return check_backend("linear_forward");
+}
+
+// ---- N_OUTSIDE > 0 ------------------------------------------------------------------------------------------------------------------
+int cnr_nerf_param_count(const cnr_nerf_config* cfg) {
+  NerfModel m;
+  if (build_nerf(cfg, m)) return -1;
+  return (int)m.params.size();
+}
+int cnr_nerf_param_info(const cnr_nerf_config* cfg, int index, char* name, int name_len, int* rows, int* cols) {
+  NerfModel m;
+  if (build_nerf(cfg, m)) return -1;
+  if (index < 0 || index >= (int)m.params.size()) return fail("parameter index out of range");
+  if (name && name_len > 0) snprintf(name, name_len, "%s", m.params[index].name.c_str());
+  if (rows) *rows = m.params[index].rows;
+  if (cols) *cols = m.params[index].cols;
+  return 0;
+}
+int cnr_outside_z(const float* far_, const float* t_rand, const float* z_vals, int64_t n_rays, int32_t n_z, int32_t n_outside, int32_t n_samples,
+                  float* z_feed, int32_t* src, void* stream) {
+  if (!far_ || !z_vals || !z_feed || !src) return fail("null argument");
+  if (n_rays <= 0 || n_z < 1 || n_outside < 1 || n_outside > kMaxOutside || n_z + n_outside > kMaxRaySamples || n_samples < 1)
+    return fail("outside_z: need n_rays > 0, 1 <= n_outside <= %d, n_z + n_outside <= %d", kMaxOutside, kMaxRaySamples);
+  OutsideZ p;
+  p.R = n_rays; p.M = n_z; p.n_out = n_outside; p.n_samples = n_samples; p.far_ = far_; p.t_rand = t_rand; p.z = z_vals; p.z_feed = z_feed; p.src = src;
+  be_outside_z(p, (cnr_stream)stream);
+  return check_backend("outside_z");
+}
+int cnr_outside_z_backward(const float* t_rand, const int32_t* src, const float* d_z_feed, int64_t n_rays, int32_t n_z, int32_t n_outside,
+                           int32_t n_samples, float* d_far, float* d_z, void* stream) {
+  if (!src || !d_z_feed || !d_far) return fail("null argument");
+  if (n_rays <= 0 || n_z < 1 || n_outside < 1 || n_outside > kMaxOutside || n_z + n_outside > kMaxRaySamples) return fail("outside_z_backward: bad sizes");
+  OutsideZBwd p;
+  p.R = n_rays; p.M = n_z; p.n_out = n_outside; p.n_samples = n_samples; p.t_rand = t_rand; p.src = src; p.d_z_feed = d_z_feed; p.d_far = d_far; p.d_z = d_z;
+  be_outside_z_bwd(p, (cnr_stream)stream);
+  return check_backend("outside_z_backward");
+}
+size_t cnr_background_ctx_bytes(const cnr_nerf_config* cfg, int64_t n_rays, int32_t n_feed) {
+  NerfModel m;
+  if (build_nerf(cfg, m) || n_rays <= 0 || n_feed < 1) return 0;
+  Arena a(nullptr);
+  NerfCtx x;
+  layout_nerf(m, n_rays * n_feed, a, x);
+  return a.off;
+}
+size_t cnr_background_bwd_scratch_bytes(const cnr_nerf_config* cfg, int64_t n_rays, int32_t n_feed) {
+  NerfModel m;
+  if (build_nerf(cfg, m) || n_rays <= 0 || n_feed < 1) return 0;
+  Arena a(nullptr);
+  NerfCtx x;
+  layout_nerf(m, n_rays * n_feed, a, x);
+  Arena sa(nullptr);
+  NerfBwd b;
+  layout_nerf_bwd(m, x, n_rays * n_feed, sa, b);
+  return sa.off;
+}
+int cnr_background_forward(const cnr_nerf_config* cfg, const float* const* params, const float* rays_o, const float* rays_d, const float* z_feed,
+                           int64_t n_rays, int32_t n_feed, float sample_dist, float* alpha, float* color, void* ctx, size_t ctx_bytes, void* stream) {
+  return background_forward(cfg, params, rays_o, rays_d, z_feed, n_rays, n_feed, sample_dist, alpha, color, ctx, ctx_bytes, (cnr_stream)stream);
+}
+int cnr_background_backward(const cnr_nerf_config* cfg, const float* const* params, const float* rays_o, const float* rays_d, const float* z_feed,
+                            int64_t n_rays, int32_t n_feed, float sample_dist, const void* ctx, size_t ctx_bytes, const float* color,
+                            const float* d_alpha, const float* d_color, float* const* d_params, float* d_rays_o, float* d_rays_d, float* d_z_feed,
+                            void* scratch, size_t scratch_bytes, void* stream) {
+  return background_backward(cfg, params, rays_o, rays_d, z_feed, n_rays, n_feed, sample_dist, ctx, ctx_bytes, color, d_alpha, d_color, d_params,
+                             d_rays_o, d_rays_d, d_z_feed, scratch, scratch_bytes, (cnr_stream)stream);
+}
+static int composite_bg_args(const cnr_bg_composite_in* in, const cnr_render_outputs* out, CompositeBg& p) {
+  if (!in || !out) return fail("null argument");
+  if (in->n_rays <= 0 || in->n_z < 1 || in->n_feed < in->n_z || in->n_feed > kMaxRaySamples) return fail("composite_background: bad sample counts");
+  if (!in->rays_o || !in->rays_d || !in->z_vals || !in->z_feed || !in->sdf_samples || !in->gradients || !in->color_samples || !in->bg_alpha ||
+      !in->bg_color || !in->variance) return fail("composite_background: missing input");
+  if (!out->color_fine || !out->s_val || !out->cdf_fine || !out->weight_sum || !out->weight_max || !out->weights || !out->inside_sphere ||
+      !out->depth || !out->gradient_error || !out->eik_sums) return fail("composite_background: missing output buffer");
+  if (in->global_color_samples && !out->global_color) return fail("composite_background: global_color buffer missing");
+  p.o = in->rays_o; p.d = in->rays_d; p.z = in->z_vals; p.z_feed = in->z_feed; p.R = in->n_rays; p.M = in->n_z; p.MF = in->n_feed; p.sample_dist = in->sample_dist;
+  p.sdf = in->sdf_samples; p.g = in->gradients; p.color = in->color_samples; p.gcolor = in->global_color_samples; p.bg_alpha = in->bg_alpha; p.bg_color = in->bg_color;
+  p.variance = in->variance; p.cos_anneal = in->cos_anneal_ratio; p.background_rgb = in->background_rgb;
+  p.color_fine = out->color_fine; p.s_val = out->s_val; p.cdf_fine = out->cdf_fine; p.weight_sum = out->weight_sum; p.weight_max = out->weight_max;
+  p.weights = out->weights; p.inside_sphere = out->inside_sphere; p.depth = out->depth; p.global_color = in->global_color_samples ? out->global_color : nullptr;
+  p.eik_partial = nullptr;
+  return 0;
+}
+size_t cnr_composite_background_scratch_bytes(int64_t n_rays) { return n_rays > 0 ? round_up_sz((size_t)n_rays * 2 * sizeof(float), 256) + 256 : 0; }
+int cnr_composite_background_forward(const cnr_bg_composite_in* in, const cnr_render_outputs* out, void* scratch, size_t scratch_bytes, void* stream) {
+  CompositeBg p;
+  if (composite_bg_args(in, out, p)) return -1;
+  if (!scratch || scratch_bytes < cnr_composite_background_scratch_bytes(in->n_rays)) return fail("composite_background: scratch too small");
+  cnr_stream s = (cnr_stream)stream;
+  Arena a(scratch);
+  p.eik_partial = a.f((size_t)in->n_rays * 2);
+  float* sums = a.f(64);
+  be_composite_bg(p, s);
+  ReduceEik re;
+  re.partial = p.eik_partial; re.R = in->n_rays; re.sums = sums; re.sums_out = out->eik_sums; re.gradient_error = out->gradient_error;
+  be_reduce_eik(re, s);
+  return check_backend("composite_background_forward");
+}
+int cnr_composite_background_backward(const cnr_bg_composite_in* in, const cnr_render_outputs* out, const cnr_render_out_grads* go,
+                                      const cnr_bg_composite_grads* gi, void* scratch, size_t scratch_bytes, void* stream) {
+  CompositeBgBwd b;
+  if (composite_bg_args(in, out, b.f)) return -1;
+  if (!go || !gi || !scratch || scratch_bytes < cnr_composite_background_scratch_bytes(in->n_rays)) return fail("composite_background_backward: null argument / scratch too small");
+  if (!gi->d_sdf_samples || !gi->d_gradients || !gi->d_color_samples || !gi->d_bg_alpha || !gi->d_bg_color || !gi->d_variance || !gi->d_rays_d || !gi->d_z_vals ||
+      !gi->d_z_feed || (in->global_color_samples && !gi->d_global_color_samples)) return fail("composite_background_backward: missing gradient buffer");
+  cnr_stream s = (cnr_stream)stream;
+  Arena a(scratch);
+  float* dinvs = a.f((size_t)in->n_rays * 2);
+  b.d_color_fine = go->color_fine; b.d_s_val = go->s_val; b.d_cdf = go->cdf_fine; b.d_weight_sum = go->weight_sum; b.d_weight_max = go->weight_max;
+  b.d_weights = go->weights; b.d_gradient_error = go->gradient_error; b.d_depth = go->depth; b.d_global_color = go->global_color; b.d_gradients = go->gradients;
+  b.eik_sums = out->eik_sums;
+  b.d_sdf = gi->d_sdf_samples; b.d_g = gi->d_gradients; b.d_color = gi->d_color_samples; b.d_gcolor = gi->d_global_color_samples; b.d_bg_alpha = gi->d_bg_alpha;
+  b.d_bg_color = gi->d_bg_color; b.d_inv_s_partial = dinvs; b.d_rays_d = gi->d_rays_d; b.d_z = gi->d_z_vals; b.d_z_feed = gi->d_z_feed;
+  be_composite_bg_bwd(b, s);
+  VarianceFinish vf;
+  vf.partial = dinvs; vf.R = in->n_rays; vf.variance = in->variance; vf.d_variance = gi->d_variance;
+  be_variance_finish(vf, s);
+  return check_backend("composite_background_backward");
 }
 
 int cnr_linear_backward(const float* x, const float* y, const float* dy, int64_t n, int32_t k, const float* W, int32_t n_out, int32_t relu,

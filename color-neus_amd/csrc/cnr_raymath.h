@@ -69,6 +69,38 @@ CNR_HD AlphaGrad alpha_backward(const AlphaOut& o, float dist, float inv_s, floa
   return gr;
 }
 
+// The same pair in double, for the per-ray background compositor (N_OUTSIDE > 0: one thread per ray, speed is no concern there): the
+// d inv_s terms of one ray cancel to a few percent of their size, so their float32 round-off would show in d variance.
+struct AlphaOutD { double tc, ic, pe, ne, pc, nc, a_raw; };
+CNR_HD AlphaOutD alpha_forward_d(double sdf, const float g[3], const float d[3], double dist, double inv_s, double r) {
+  AlphaOutD o;
+  o.tc = (double)d[0] * g[0] + (double)d[1] * g[1] + (double)d[2] * g[2];
+  const double A = fmax(-o.tc * 0.5 + 0.5, 0.0), B = fmax(-o.tc, 0.0);
+  o.ic = -(A * (1.0 - r) + B * r);
+  o.ne = sdf + o.ic * dist * 0.5;
+  o.pe = sdf - o.ic * dist * 0.5;
+  o.pc = 1.0 / (1.0 + exp(-o.pe * inv_s));
+  o.nc = 1.0 / (1.0 + exp(-o.ne * inv_s));
+  o.a_raw = (o.pc - o.nc + 1e-5) / (o.pc + 1e-5);
+  return o;
+}
+CNR_HD AlphaGrad alpha_backward_d(const AlphaOutD& o, double dist, double inv_s, double r, double d_alpha, double d_pc_extra, double* d_inv_s) {
+  AlphaGrad gr;
+  const double da = (o.a_raw >= 0.0 && o.a_raw <= 1.0) ? d_alpha : 0.0;
+  const double den = o.pc + 1e-5;
+  const double d_pc = da * (o.nc / (den * den)) + d_pc_extra, d_nc = -da / den;
+  const double spc = o.pc * (1.0 - o.pc), snc = o.nc * (1.0 - o.nc);
+  const double d_pe = d_pc * spc * inv_s, d_ne = d_nc * snc * inv_s;
+  *d_inv_s = d_pc * spc * o.pe + d_nc * snc * o.ne;
+  gr.d_inv_s = (float)*d_inv_s;
+  gr.d_sdf = (float)(d_pe + d_ne);
+  const double d_ic = (d_ne - d_pe) * dist * 0.5;
+  gr.d_dist = (float)((d_ne - d_pe) * o.ic * 0.5);
+  const double dic_dtc = (o.tc < 1.0 ? 0.5 * (1.0 - r) : 0.0) + (o.tc < 0.0 ? r : 0.0);
+  gr.d_tc = (float)(d_ic * dic_dtc);
+  return gr;
+}
+
 // up-sampling section alpha (no clip)                                              (NeuS.py:144-177)
 CNR_HD float upsample_alpha(float s0, float s1, float z0, float z1, float cos_val, float inv_s) {
   float mid = (s0 + s1) * 0.5f;

@@ -293,12 +293,11 @@ class NeuSRenderer(nn.Module):
         self.color_network = _ColorNet(rcfg)
         self.n_samples, self.n_importance = rcfg.n_samples, rcfg.n_importance
         self.n_outside, self.up_sample_steps, self.perturb, self.N = rcfg.n_outside, rcfg.up_sample_steps, rcfg.perturb, rcfg.N
-        if self.n_outside > 0:   # NeRF++ background (NeuS.py:87-91): torch fallback, see background.py
+        if self.n_outside > 0:   # NeRF++ background (NeuS.py:87-91): parameters here, arithmetic in the library (background.py)
             from .background import NeRF
             self.nerf = NeRF()
         self._library_arg = library
         self._lib_obj = None
-        self.torch_background = False   # True: evaluate the NeRF++ background network with torch ops instead of the library's layer kernels
         self._ccfg = _lib.c_config(rcfg)
         self._order = None
 
@@ -322,7 +321,7 @@ class NeuSRenderer(nn.Module):
                 if named[name].numel() != rows * cols:
                     raise RuntimeError(f"parameter {name}: expected {rows}x{cols}, have {tuple(named[name].shape)}")
                 order.append(name)
-            extra = [k for k in named if k not in order and not k.startswith("nerf.")]   # nerf.*: background network, torch side only
+            extra = [k for k in named if k not in order and not k.startswith("nerf.")]   # nerf.*: the background network has its own inventory (cnr_nerf_param_info)
             if extra:
                 raise RuntimeError(f"parameter inventory mismatch between module and library: {extra[:3]}")
             self._order = order
@@ -428,31 +427,38 @@ class NeuSRenderer(nn.Module):
         self._lib.check(rc, "cnr_up_sample")
         return out
 
-    # -- N_OUTSIDE > 0 (NeuS.py:313-369): foreground fields from the library, background + mixing in torch (background.py) ----------
+    # -- N_OUTSIDE > 0 (NeuS.py:313-369): four library calls chained by autograd (background.py); no tensor arithmetic here ------------
     def _forward_with_background(self, rays_o, rays_d, near, far, perturb, t_rand, bg, cos_anneal_ratio, params, z_override):
         from . import background as B
-        rc = self.rcfg
+        rc, lib = self.rcfg, self._lib
         R = len(rays_o)
-        z_out = B.outside_samples(far.reshape(-1), self.n_outside, self.n_samples, perturb)   # second draw of the CPU generator, like NeuS.py:335
+        dev = rays_o.device
+        # second draw of the CPU generator, like NeuS.py:335
+        t_out = torch.rand([R, self.n_outside]).to(dev) if perturb > 0 else None
         if z_override is None:
-            z_vals = self._sample_z(rays_o, rays_d, near, far, t_rand)
+            z_vals = self._sample_z(rays_o, rays_d, near, far, t_rand)      # (built under no_grad in the reference when N_IMPORTANCE > 0, NeuS.py:343)
         else:
             z_vals = z_override.detach().reshape(R, rc.n_total).float()
-        z_feed, _ = torch.sort(torch.cat([z_vals, z_out], dim=-1), dim=-1)
         sample_dist = 2.0 / self.n_samples
-        if self.nerf.library is None and not self.torch_background:
-            self.nerf.library = self._lib     # the background network's layers run on the render library's kernels (background.HipLinear)
-        bg_alpha, bg_color = B.render_outside(self.nerf, rays_o, rays_d, z_feed, sample_dist)
+        z_feed, _src = B.OutsideZ.apply(lib, far, t_out, z_vals, int(self.n_samples), int(self.n_outside))
+        nparams = self.nerf.ordered_params(lib)
+        bg_alpha, bg_color = B.Background.apply(lib, self.nerf.config(), sample_dist, rays_o, rays_d, z_feed, *nparams)
         res = _RenderFunction.apply(self, rays_o, rays_d, near, far, None, z_vals, None, 0.0, 0.0, True, *params)
         color = rc.type == "Color_NeuS"
         names = [k for k in _OUT_DIFF if color or k not in ("global_color", "delta_relight")] + \
                 [k for k in _SAMPLE_OUT if color or k != "global_color_samples"] + ["inside_sphere", "z_vals", "eik_sums"]
         f = dict(zip(names, res))
-        inv_s = torch.exp(self.deviation_network.variance * 10.0).clip(1e-6, 1e6)
-        out = B.composite_with_background(rc.type, rays_o, rays_d, z_vals, sample_dist, inv_s, f["sdf_samples"], f["gradients"],
-                                          f["color_samples"], f.get("global_color_samples"), f.get("delta_relight"), bg_alpha, bg_color,
-                                          z_feed, cos_anneal_ratio, bg)
+        cres = B.CompositeBg.apply(lib, sample_dist, float(cos_anneal_ratio), bg, rays_o, rays_d, z_vals, z_feed, f["sdf_samples"], f["gradients"],
+                                   f["color_samples"], f.get("global_color_samples"), bg_alpha, bg_color, self.deviation_network.variance)
+        cnames = [k for k in B._COMP_OUT if color or k != "global_color"] + ["inside_sphere", "eik_sums"]
+        c = dict(zip(cnames, cres))
+        out = {k: c[k] for k in ("color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max")}
+        out.update(gradients=f["gradients"], weights=c["weights"], gradient_error=c["gradient_error"], inside_sphere=c["inside_sphere"], depth=c["depth"])
+        if color:
+            out["global_color"] = c["global_color"]
+            out["delta_relight"] = f["delta_relight"]
         out["z_vals"] = z_vals
+        out["eik_sums"] = c["eik_sums"]
         return out
 
     def _sample_z(self, rays_o, rays_d, near, far, t_rand):

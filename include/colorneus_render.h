@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CNR_ABI_VERSION 4
+#define CNR_ABI_VERSION 5
 
 typedef struct cnr_config {
   int32_t type;              /* 0 = NeuS (NeuS.py:68), 1 = Color_NeuS (Color_NeuS.py:10) */
@@ -269,6 +269,66 @@ int cnr_linear_forward(const float* x, int64_t n, int32_t k, const float* W, con
 int cnr_linear_backward(const float* x, const float* y /* the forward output (ReLU gate); may be NULL without ReLU */, const float* dy, int64_t n,
                         int32_t k, const float* W, int32_t n_out, int32_t relu, float* dx, float* dW, float* db, void* scratch,
                         size_t scratch_bytes, void* stream);
+
+/* ---- N_OUTSIDE > 0: the NeRF++ background of NeuS.forward (lib/models/renderers/NeuS.py:313-369) -----------------------------------------
+ * The reference evaluates a second network (NeRF, fields.py:192-274, built with its defaults: NeuS.py:87-91) on the foreground samples
+ * merged with n_outside inverse-depth samples beyond `far`, and mixes its alpha / colour into render_core by the inside-sphere mask
+ * (NeuS.py:262-268, Color_NeuS.py:97-102).  No shipped configuration sets N_OUTSIDE.  Four steps, each a forward / backward pair; the
+ * foreground fields come from cnr_render_forward's per-sample outputs (sdf_samples, gradients, color_samples, global_color_samples) and
+ * their gradients go back through cnr_render_out_grads:
+ *   cnr_outside_z                  z_vals_outside (NeuS.py:315-338) merged into the sorted z_vals_feed (NeuS.py:353-355)
+ *   cnr_background_forward         render_core_outside (NeuS.py:95-134) up to its per-sample outputs: alpha and sigmoid(rgb)
+ *   cnr_composite_background_*     the tail of render_core with background_alpha / background_sampled_color given
+ * Parameters of the background network: cnr_nerf_param_info order = nn.Module order of NeRF (pts_linears.i.weight / .bias, views_linears.0.*,
+ * feature_linear.*, alpha_linear.*, rgb_linear.*), plain nn.Linear tensors. */
+typedef struct cnr_nerf_config {
+  int32_t D, W;              /* depth / width of the pts stack (NeRF defaults 8 / 256) */
+  int32_t multires;          /* PE of the 4-vector (x / r, 1 / r): default 10 */
+  int32_t multires_view;     /* PE of the view direction: default 4 */
+  int32_t skip_mask;         /* bit i: [PE | h] is concatenated after pts layer i (default 1 << 4) */
+} cnr_nerf_config;
+int cnr_nerf_param_count(const cnr_nerf_config* cfg);
+int cnr_nerf_param_info(const cnr_nerf_config* cfg, int index, char* name, int name_len, int* rows, int* cols);
+
+/* z_feed [R][n_z + n_outside] = sort(cat(z_vals [R][n_z] (ascending), far / flip(zz) + 1 / n_samples)); t_rand [R][n_outside] = the
+ * torch.rand draw of NeuS.py:335 or NULL (no perturbation); src [R][n_z + n_outside] (int32, for the backward call): where each entry came from.
+ * Backward: d_far [R] through the background samples, d_z [R][n_z] (or NULL) for the copies of z_vals. */
+int cnr_outside_z(const float* far_, const float* t_rand, const float* z_vals, int64_t n_rays, int32_t n_z, int32_t n_outside, int32_t n_samples,
+                  float* z_feed, int32_t* src, void* stream);
+int cnr_outside_z_backward(const float* t_rand, const int32_t* src, const float* d_z_feed, int64_t n_rays, int32_t n_z, int32_t n_outside,
+                           int32_t n_samples, float* d_far, float* d_z, void* stream);
+
+/* alpha [R][n_feed], color [R][n_feed][3] of the background network at the n_feed samples of every ray; ctx keeps the activations for
+ * cnr_background_backward, which overwrites d_params (host array of device pointers, cnr_nerf_param_info order), d_rays_o / d_rays_d [R][3]
+ * and d_z_feed [R][n_feed]. */
+size_t cnr_background_ctx_bytes(const cnr_nerf_config* cfg, int64_t n_rays, int32_t n_feed);
+size_t cnr_background_bwd_scratch_bytes(const cnr_nerf_config* cfg, int64_t n_rays, int32_t n_feed);
+int cnr_background_forward(const cnr_nerf_config* cfg, const float* const* params, const float* rays_o, const float* rays_d, const float* z_feed,
+                           int64_t n_rays, int32_t n_feed, float sample_dist, float* alpha, float* color, void* ctx, size_t ctx_bytes, void* stream);
+int cnr_background_backward(const cnr_nerf_config* cfg, const float* const* params, const float* rays_o, const float* rays_d, const float* z_feed,
+                            int64_t n_rays, int32_t n_feed, float sample_dist, const void* ctx, size_t ctx_bytes, const float* color,
+                            const float* d_alpha, const float* d_color, float* const* d_params, float* d_rays_o, float* d_rays_d, float* d_z_feed,
+                            void* scratch, size_t scratch_bytes, void* stream);
+
+/* render_core's alpha / mixing / compositing over n_feed = n_z + n_outside samples.  Outputs: the members of cnr_render_outputs that render_core
+ * returns (weights is [R][n_feed] here; gradients / delta_relight / z_vals / the per-sample members are not written); eik_sums must be given.
+ * Backward: upstream gradients in cnr_render_out_grads (color_fine, s_val, cdf_fine, weight_sum, weight_max, weights [R][n_feed],
+ * gradient_error, depth, global_color, gradients), results in cnr_bg_composite_grads (all overwritten; d_variance is [1]). */
+typedef struct cnr_bg_composite_in {
+  const float* rays_o; const float* rays_d; const float* z_vals /* [R][n_z] */; const float* z_feed /* [R][n_feed] */;
+  int64_t n_rays; int32_t n_z, n_feed; float sample_dist;
+  const float* sdf_samples; const float* gradients /* [R][n_z][3] */; const float* color_samples; const float* global_color_samples /* or NULL (NeuS) */;
+  const float* bg_alpha /* [R][n_feed] */; const float* bg_color /* [R][n_feed][3] */;
+  const float* variance /* deviation_network.variance, device [1] */; float cos_anneal_ratio; const float* background_rgb /* [3] or NULL */;
+} cnr_bg_composite_in;
+typedef struct cnr_bg_composite_grads {
+  float* d_sdf_samples; float* d_gradients; float* d_color_samples; float* d_global_color_samples; float* d_bg_alpha; float* d_bg_color;
+  float* d_variance; float* d_rays_d /* [R][3] */; float* d_z_vals /* [R][n_z] */; float* d_z_feed /* [R][n_feed] */;
+} cnr_bg_composite_grads;
+size_t cnr_composite_background_scratch_bytes(int64_t n_rays);
+int cnr_composite_background_forward(const cnr_bg_composite_in* in, const cnr_render_outputs* out, void* scratch, size_t scratch_bytes, void* stream);
+int cnr_composite_background_backward(const cnr_bg_composite_in* in, const cnr_render_outputs* out, const cnr_render_out_grads* gout,
+                                      const cnr_bg_composite_grads* gin, void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -71,3 +71,4 @@ def run_native(name, tag, library, device, fixed_z=True, rays_grad=True, nearfar
     if nearfar_grad:
         return fx, r, out, loss, grads, o, d, near, far
     return fx, r, out, loss, grads, o, d
+

@@ -77,18 +77,20 @@ def test_g2_every_gradient_entry_against_live_float64_oracle(name, tag):
 
 @pytest.mark.parametrize("name", ["tiny_outside", "tiny_neus_outside"])
 @pytest.mark.parametrize("tag", ["det", "jit"])
-def test_nerfpp_background_fallback(name, tag):
-    """N_OUTSIDE = 8 (a19 / f4): foreground on the HIP library; the NeRF++ background network's 12 linear layers on the library's layer and
-    weight-gradient kernels (cnr_linear_forward / cnr_linear_backward, background.HipLinear); encodings, concatenations and the inside /
-    outside alpha mixing in torch (background.py)."""
+def test_nerfpp_background(name, tag):
+    """N_OUTSIDE = 8 on the HIP library end to end: background samples, the NeRF++ network (encodings, skip concat, heads),
+    density -> alpha, inside / outside mixing and the compositing over M + N_OUTSIDE samples behind the C ABI (cnr_outside_z, cnr_background_*,
+    cnr_composite_background_*); strict gate on every parameter gradient, nerf.* included."""
     fx, r, out, loss, grads, o, d = N.run_native(name, tag, None, DEV, fixed_z=True)
     for k in G.OUTPUT_KEYS:
         if f"{tag}:out_{k}" in fx:
             ref = fx[f"{tag}:out_{k}"]
             assert G.relerr(out[k].detach().cpu().reshape(ref.shape), ref) < TOL, k
     assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
-    bad = G.check_param_grads(fx, tag, grads, strict=True)   # every tensor, nerf.* included: the HIP gate (1 % outliers, 5e-4 cap)
+    bad = G.check_param_grads(fx, tag, grads, strict=True)
     assert not bad, bad
+    for key, got in (("grad_rays_o", o.grad), ("grad_rays_d", d.grad)):
+        assert G.check_input_grad(fx, tag, key, got, strict=True) is None, G.check_input_grad(fx, tag, key, got, strict=True)
 
 
 def test_param_grad_error_table():

@@ -51,10 +51,11 @@ def test_g3_end_to_end_init():
 
 @pytest.mark.parametrize("name", ["tiny_outside", "tiny_neus_outside"])
 @pytest.mark.parametrize("tag", ["det", "jit"])
-def test_nerfpp_background_fallback(name, tag):
-    """N_OUTSIDE = 8 (a19): foreground fields from the library, the NeRF++ background network's layers through cnr_linear_* (emulation
-    build here), encodings / concatenations / inside-outside mixing in torch (color-neus_amd/background.py); outputs, loss and every
-    parameter gradient -- nerf.* included -- against the reference."""
+def test_nerfpp_background(name, tag):
+    """N_OUTSIDE = 8 through the product route: background samples, the NeRF++ network (encodings, skip concat, heads),
+    density -> alpha, inside / outside mixing and the compositing over M + N_OUTSIDE samples all behind the C ABI (cnr_outside_z,
+    cnr_background_*, cnr_composite_background_*; emulation build here); outputs, loss and every parameter gradient -- nerf.* included --
+    against the reference."""
     fx, r, out, loss, grads, o, d = N.run_native(name, tag, N.EMU_LIB, "cpu", fixed_z=True)
     assert out["weights"].shape[1] == r.rcfg.n_total + 8
     for k in G.OUTPUT_KEYS:

@@ -160,3 +160,34 @@ def test_reference_ops_mode_matches_golden():
     assert abs(float(loss.detach()) - float(fx["jit:loss"])) < 1e-6 * abs(float(fx["jit:loss"]))
     bad = G.check_param_grads(fx, "jit", {k: v.grad for k, v in P.items()})
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["tiny_outside", "tiny_neus_outside"])
+@pytest.mark.parametrize("tag", ["det", "jit"])
+def test_outside_oracle_against_reference_goldens(name, tag):
+    """N_OUTSIDE = 8: oracle/background_oracle.py (background samples, NeRF network, render_core_outside, mixing in
+    render_core) against the vectors captured from the imported reference (tools/gen_golden.py): outputs, loss, every parameter gradient
+    incl. nerf.*, d rays.  This pins the restatement that the N_OUTSIDE tests of the native path use as their float64 reference."""
+    from oracle import background_oracle as BO
+    fx = G.load(name)
+    cfg, P = G.weights_of(name, fx)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    t = lambda k: torch.from_numpy(fx[k])
+    o, d = t("rays_o").requires_grad_(True), t("rays_d").requires_grad_(True)
+    R = o.shape[0]
+    t_out = None
+    if tag == "jit":   # the fixture's run seeds the CPU generator with 2 and draws the foreground jitter first (tools/gen_golden.py)
+        torch.manual_seed(2)
+        torch.rand([R, 1])
+        t_out = torch.rand([R, cfg.n_outside])
+    out = BO.render(P, cfg, o, d, t(f"{tag}:near"), t(f"{tag}:far"), t(f"{tag}:z_vals"), t_out=t_out)
+    for k in G.OUTPUT_KEYS:
+        if f"{tag}:out_{k}" in fx:
+            assert G.relerr(out[k].detach().reshape(fx[f"{tag}:out_{k}"].shape), fx[f"{tag}:out_{k}"]) < TOL, k
+    loss, _ = O.compute_loss(out, t("rgb_gt"), t("mask"))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
+    bad = G.check_param_grads(fx, tag, {k: p.grad for k, p in P.items()}, TOL)
+    assert not bad, bad
+    assert G.relerr(o.grad, fx[f"{tag}:grad_rays_o"]) < TOL
+    assert G.relerr(d.grad, fx[f"{tag}:grad_rays_d"]) < TOL

@@ -32,7 +32,7 @@ if "layer_gemm_ws" in out and "layer_gemm_ws_stream" in out:   # one family for 
     out["layer_gemm_ws_general"] = g
     out["layer_gemm_ws"] = {"launches": n, **{f: round((g[f] * g["launches"] + st[f] * st["launches"]) / n)
                                                for f in ("fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch")}}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-small-batch --no-torch-gpu-baseline --no-inference --no-c5` "
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-small-batch --no-torch-gpu-baseline --no-inference --no-c5 --no-loss-only` "
                    "(4096 rays/step); FETCH_SIZE doubled per the gfx950 correction", "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
     print(k, v)

@@ -6,7 +6,7 @@ TAG=${1:-rXX}
 OUT=$R/gpurun_out/${TAG}_prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-roofline --no-small-batch --no-torch-gpu-baseline --no-inference --no-c5"
+ARGS="--no-cpu-baseline --no-roofline --no-small-batch --no-torch-gpu-baseline --no-inference --no-c5 --no-loss-only"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 $ARGS > $OUT/write.log 2>&1
