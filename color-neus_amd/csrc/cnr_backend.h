@@ -252,6 +252,11 @@ struct ReluChainFwd {
 bool be_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s);   // false: not handled (per-layer launches instead)
 
 void be_layer_gemm(const LayerGemm& g, cnr_stream s);
+// Second-order sweep launch of a narrow-input layer (K <= 48, 256 outputs) that also forms the gradient-chain weight-gradient pair of the layer
+// (u = sp'(z) v from the epilogue's side inputs, the launch's input rows) into be_sweep0_slots(g.P) slots of [256][ldk] floats (cnr_sweep0.hip).
+bool be_sweep0_ok(const LayerGemm& g);
+int be_sweep0_slots(long P);
+void be_sweep0_dw(const LayerGemm& g, float* partial, int ldk, cnr_stream s);
 void be_dw_gemm(const DwGemm& g, cnr_stream s);
 // Layer launch g + the single-pair weight gradient d (X[0] = the launch's input view, Y[0] = the operand its epilogue derives from its side
 // inputs, see DwFuse in cnr_views.h) with d.partial / d.colsum laid out in kFdwSlots slots.  Callers test be_fdw_enabled() && fdw_shape_ok(g)

@@ -398,6 +398,9 @@ bool be_sdf_value_chain(const SdfValueChain&, cnr_stream) { return false; }
 bool be_relu_chain_fwd(const ReluChainFwd&, cnr_stream) { return false; }
 bool be_sdf_save_chain(const SdfSaveChain&, cnr_stream) { return false; }
 bool be_sdf_grad_chain(const SdfGradChain&, cnr_stream) { return false; }
+bool be_sweep0_ok(const LayerGemm&) { return false; }   // (nor the sweep launch that forms its layer's weight-gradient pair)
+int be_sweep0_slots(long) { return 0; }
+void be_sweep0_dw(const LayerGemm&, float*, int, cnr_stream) {}
 
 void be_upsample(const UpSample& p, cnr_stream) {
 #pragma omp parallel for

@@ -373,7 +373,8 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   b.cap_slots = b.fslots + (b.nchunk > b.fslots ? b.nchunk : b.fslots);   // a fused pair + either a second fused pair or a separate GEMM over nchunk slots
   // every layer keeps its own [slots][npad][ldw] partial sums (+ bias column sums) until one batched reduction at the end
   size_t tot = 0;
-  auto upd = [&](const Lin& q) { tot += round_up_sz((size_t)b.cap_slots * q.npad * q.ldw, 64) + round_up_sz((size_t)b.cap_slots * q.npad, 64); };
+  auto upd = [&](const Lin& q) { const int cap = (q.k_int <= 48 && b.cap_slots < b.nchunk + 256) ? b.nchunk + 256 : b.cap_slots;   // (= region_slots)
+                                 tot += round_up_sz((size_t)cap * q.npad * q.ldw, 64) + round_up_sz((size_t)cap * q.npad, 64); };
   for (auto& q : m.sdf) upd(q);
   for (auto& q : m.col) upd(q);
   for (auto& q : m.rel) upd(q);
@@ -854,12 +855,15 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
 // groups of one region (SDF layers: value pair | gradient-chain pair, each either fused into its layer launch or a separate GEMM);
 // finish_region queues the one reduction over all of them.  Only the group at slot 0 carries bias column sums.
 struct DwRegion { float* part = nullptr; float* csum = nullptr; };
+// slots reserved for a layer: a narrow-input layer (K <= 48) may hold a separate GEMM over nchunk slots + a sweep launch of one slot per CU (cnr_sweep0.hip)
+static int region_slots(const Lin& q, const Bwd& b) { return (q.k_int <= 48 && b.cap_slots < b.nchunk + 256) ? b.nchunk + 256 : b.cap_slots; }
 static DwRegion take_region(const Lin& q, Bwd& b) {
   DwRegion r;
+  const int cap = region_slots(q, b);
   r.part = b.partial + b.partial_off;
-  b.partial_off += round_up_sz((size_t)b.cap_slots * q.npad * q.ldw, 64);
+  b.partial_off += round_up_sz((size_t)cap * q.npad * q.ldw, 64);
   r.csum = b.partial + b.partial_off;
-  b.partial_off += round_up_sz((size_t)b.cap_slots * q.npad, 64);
+  b.partial_off += round_up_sz((size_t)cap * q.npad, 64);
   return r;
 }
 static void finish_region(const Lin& q, const DwRegion& r, int nslots, int ncolsum, Bwd& b, const float* const* params, float* const* dparams) {
@@ -1170,6 +1174,8 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     auto ok = [&](const LayerGemm& g) { return fdw_shape_ok(g); };
     if (fdw && sq && l >= 1 && l < m.L && x.rsY[l] && ok(vback_gemm(l))) fuse_v[l] = 1;
     if (fdw && sq && l < m.L && x.rsX1[l] && ok(sweep_gemm(l))) fuse_g[l] = 1;
+    // narrow-input layer (the first SDF layer): the sweep launch forms the pair from its epilogue's side inputs, one slot per workgroup (cnr_sweep0.hip)
+    if (fdw && !fuse_g[l] && l < m.L && q.npad == 256 && be_sweep0_ok(sweep_gemm(l)) && b.nchunk + be_sweep0_slots(P) <= region_slots(q, b)) fuse_g[l] = 2;
   }
   // The top layer (F features + the sdf row, F == 256 = its input width) without launches of its own: its value-backward launch takes the
   // sdf column of the cotangent as a rank-one update of the 256-wide product (k_extra) and forms the main 256 x 256 weight gradient like any
@@ -1191,11 +1197,13 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   // fslots slots when it is fused and nchunk slots as a separate GEMM (one workgroup per slot: fewer would leave CUs idle); when neither is
   // fused one launch over nchunk slots forms both
   auto value_slots = [&](int l) { return fuse_v[l] ? b.fslots : b.nchunk; };
-  auto grad_slots = [&](int l) { return (l == m.L && top_fused) ? 0 : fuse_g[l] ? b.fslots : (fuse_v[l] ? b.nchunk : 0); };
+  auto grad_slots = [&](int l) { return (l == m.L && top_fused) ? 0 : fuse_g[l] == 2 ? be_sweep0_slots(P) : fuse_g[l] ? b.fslots : (fuse_v[l] ? b.nchunk : 0); };
   for (int l = 0; l < m.L; ++l) {
     const Lin& q = m.sdf[l];
     LayerGemm g = sweep_gemm(l);
-    if (fuse_g[l]) {
+    if (fuse_g[l] == 2) {
+      be_sweep0_dw(g, sreg[l].part + (size_t)value_slots(l) * q.npad * q.ldw, q.ldw, s);
+    } else if (fuse_g[l]) {
       DwGemm d;
       d.npairs = 1; d.P = P;
       grad_pair(l, d, 0);
