@@ -254,6 +254,20 @@ bool be_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s);   // false: not han
 void be_layer_gemm(const LayerGemm& g, cnr_stream s);
 // Second-order sweep launch of a narrow-input layer (K <= 48, 256 outputs) that also forms the gradient-chain weight-gradient pair of the layer
 // (u = sp'(z) v from the epilogue's side inputs, the launch's input rows) into be_sweep0_slots(g.P) slots of [256][ldk] floats (cnr_sweep0.hip).
+// Backward of a narrow-input layer (<= 48 input columns, 256 outputs) in one pass over its 256-wide output cotangent X (cnr_narrow_bwd.hip):
+// dW[j][c] = sum X[pt][j] Y[pt][c] and db[j] = sum X[pt][j] into be_narrow_bwd_slots(P) slots ([256][ldk] / [256] floats each), and -- with Wp --
+// dx[pt][c] = sum_j X[pt][j] Wt[c][j] for c < ndx (Wp / wscale: the f16 planes and row scales of W^T, rows = input columns, ldw = 256).
+struct NarrowBwd {
+  const float* X = nullptr; int ldx = 0;
+  const float* Y = nullptr; int ldy = 0; int ky = 0;
+  long P = 0;
+  const unsigned short* Wp = nullptr; long wp_stride = 0; int ldw = 0; int w_rows = 0; const float* wscale = nullptr;
+  float* dx = nullptr; int lddx = 0; int ndx = 0;
+  float* partial = nullptr; int ldk = 0; float* colsum = nullptr;
+};
+bool be_narrow_bwd_ok(const NarrowBwd& p);
+int be_narrow_bwd_slots(long P);
+void be_narrow_bwd(const NarrowBwd& p, cnr_stream s);
 bool be_sweep0_ok(const LayerGemm& g);
 int be_sweep0_slots(long P);
 void be_sweep0_dw(const LayerGemm& g, float* partial, int ldk, cnr_stream s);

@@ -401,6 +401,9 @@ bool be_sdf_grad_chain(const SdfGradChain&, cnr_stream) { return false; }
 bool be_sweep0_ok(const LayerGemm&) { return false; }   // (nor the sweep launch that forms its layer's weight-gradient pair)
 int be_sweep0_slots(long) { return 0; }
 void be_sweep0_dw(const LayerGemm&, float*, int, cnr_stream) {}
+bool be_narrow_bwd_ok(const NarrowBwd&) { return false; }   // (nor the one-pass backward of a narrow-input layer)
+int be_narrow_bwd_slots(long) { return 0; }
+void be_narrow_bwd(const NarrowBwd&, cnr_stream) {}
 
 void be_upsample(const UpSample& p, cnr_stream) {
 #pragma omp parallel for

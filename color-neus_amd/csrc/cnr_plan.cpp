@@ -330,6 +330,7 @@ struct Bwd {   // backward scratch
   int nchunk; long chunk_pts;
   int fslots;                         // slots (point ranges) of a fused layer + weight-gradient launch (cnr_gemm_fdw.hip)
   int cap_slots;                      // slots reserved per layer in the pool: fslots + max(nchunk, fslots)
+  int cu_slots;                       // slots of a one-workgroup-per-CU launch over 32-point tiles (cnr_sweep0.hip, cnr_narrow_bwd.hip)
 };
 
 // point ranges of a fused launch: at least four 32-point tiles per range, a multiple of 8 (two column halves per range share an XCD)
@@ -338,6 +339,13 @@ static int fdw_slots(long P) {
   if (s < 8) s = 8;
   if (s > kFdwSlots) s = kFdwSlots;
   return (int)s;
+}
+
+// slots reserved for a layer: a narrow-input layer (K <= 48) may hold two one-workgroup-per-CU launches (cnr_sweep0.hip, cnr_narrow_bwd.hip) or one
+// of them + a separate GEMM over nchunk slots
+static int region_slots(const Lin& q, const Bwd& b) {
+  const int narrow = (b.nchunk > b.cu_slots ? b.nchunk : b.cu_slots) + b.cu_slots;
+  return (q.k_int <= 48 && b.cap_slots < narrow) ? narrow : b.cap_slots;
 }
 
 static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
@@ -373,8 +381,11 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   b.cap_slots = b.fslots + (b.nchunk > b.fslots ? b.nchunk : b.fslots);   // a fused pair + either a second fused pair or a separate GEMM over nchunk slots
   // every layer keeps its own [slots][npad][ldw] partial sums (+ bias column sums) until one batched reduction at the end
   size_t tot = 0;
-  auto upd = [&](const Lin& q) { const int cap = (q.k_int <= 48 && b.cap_slots < b.nchunk + 256) ? b.nchunk + 256 : b.cap_slots;   // (= region_slots)
-                                 tot += round_up_sz((size_t)cap * q.npad * q.ldw, 64) + round_up_sz((size_t)cap * q.npad, 64); };
+  {
+    const long ntiles = (P + 31) / 32, tpw = (ntiles + 255) / 256;
+    b.cu_slots = ntiles > 0 ? (int)((ntiles + tpw - 1) / tpw) : 0;
+  }
+  auto upd = [&](const Lin& q) { const int cap = region_slots(q, b); tot += round_up_sz((size_t)cap * q.npad * q.ldw, 64) + round_up_sz((size_t)cap * q.npad, 64); };
   for (auto& q : m.sdf) upd(q);
   for (auto& q : m.col) upd(q);
   for (auto& q : m.rel) upd(q);
@@ -855,8 +866,6 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
 // groups of one region (SDF layers: value pair | gradient-chain pair, each either fused into its layer launch or a separate GEMM);
 // finish_region queues the one reduction over all of them.  Only the group at slot 0 carries bias column sums.
 struct DwRegion { float* part = nullptr; float* csum = nullptr; };
-// slots reserved for a layer: a narrow-input layer (K <= 48) may hold a separate GEMM over nchunk slots + a sweep launch of one slot per CU (cnr_sweep0.hip)
-static int region_slots(const Lin& q, const Bwd& b) { return (q.k_int <= 48 && b.cap_slots < b.nchunk + 256) ? b.nchunk + 256 : b.cap_slots; }
 static DwRegion take_region(const Lin& q, Bwd& b) {
   DwRegion r;
   const int cap = region_slots(q, b);
@@ -1052,12 +1061,25 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       g.A.kind = VK_DIRECT; g.A.a = b.D[0]; g.A.lda = m.Hr;
       g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
       g.E.kind = EK_STORE; g.E.n_out = q.k_int; g.E.o1 = b.dAUXr; g.E.ld1 = kAux;
-      be_layer_gemm(g, s);
-      DwGemm d;
-      d.npairs = 1; d.P = P;
-      d.X[0] = g.A;
-      d.Y[0] = relight_input_view(m, -1, x);
-      run_dw(m, q, d, b, params, dP, true, s);
+      // one pass over D[0] for the cotangent of the layer's inputs, its weight gradient and its bias gradient (cnr_narrow_bwd.hip) ...
+      NarrowBwd nb;
+      nb.X = b.D[0]; nb.ldx = m.Hr; nb.Y = x.AUX; nb.ldy = kAux; nb.ky = q.k_int; nb.P = P;
+      nb.Wp = q.Wtp; nb.wp_stride = (long)q.kpad * q.ldwt; nb.ldw = q.ldwt; nb.w_rows = q.kpad; nb.wscale = q.Wtps;
+      nb.dx = b.dAUXr; nb.lddx = kAux; nb.ndx = q.k_int; nb.ldk = q.ldw;
+      nb.partial = b.partial;   // (placeholder for the shape test; the region is taken below)
+      if (fdw && q.n == 256 && q.npad == 256 && m.Hr == 256 && be_narrow_bwd_ok(nb) && be_narrow_bwd_slots(P) <= region_slots(q, b)) {
+        const DwRegion r = take_region(q, b);
+        nb.partial = r.part; nb.colsum = r.csum;
+        be_narrow_bwd(nb, s);
+        finish_region(q, r, be_narrow_bwd_slots(P), be_narrow_bwd_slots(P), b, params, dP);
+      } else {   // ... or a narrow layer launch + a weight-gradient launch
+        be_layer_gemm(g, s);
+        DwGemm d;
+        d.npairs = 1; d.P = P;
+        d.X[0] = g.A;
+        d.Y[0] = relight_input_view(m, -1, x);
+        run_dw(m, q, d, b, params, dP, true, s);
+      }
     }
   }
   be_range_pop(); be_range_push("colour chain backward");
@@ -1177,6 +1199,20 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     // narrow-input layer (the first SDF layer): the sweep launch forms the pair from its epilogue's side inputs, one slot per workgroup (cnr_sweep0.hip)
     if (fdw && !fuse_g[l] && l < m.L && q.npad == 256 && be_sweep0_ok(sweep_gemm(l)) && b.nchunk + be_sweep0_slots(P) <= region_slots(q, b)) fuse_g[l] = 2;
   }
+  // The first layer (narrow input): the cotangent of its input columns (camera refinement) and its value pair in one pass over Z2[0]
+  // (cnr_narrow_bwd.hip) instead of a narrow layer launch + a weight-gradient launch
+  NarrowBwd nb0;
+  {
+    const Lin& q = m.sdf[0];
+    nb0.X = b.Z2[0]; nb0.ldx = m.Hs; nb0.Y = x.E; nb0.ldy = kEmb; nb0.ky = q.k_int; nb0.P = P;
+    if (rays_grad) {
+      nb0.Wp = q.Wtp; nb0.wp_stride = (long)q.kpad * q.ldwt; nb0.ldw = q.ldwt; nb0.w_rows = q.kpad; nb0.wscale = q.Wtps;
+      nb0.dx = b.ebar0; nb0.lddx = kEmb; nb0.ndx = m.emb;
+    }
+    nb0.partial = sreg[0].part; nb0.ldk = q.ldw; nb0.colsum = sreg[0].csum;
+  }
+  const bool use_nb0 = fdw && m.L >= 1 && !fuse_v[0] && fuse_g[0] != 0 && m.sdf[0].n == 256 && m.sdf[0].npad == 256 && m.Hs == 256 && be_narrow_bwd_ok(nb0) &&
+                       be_narrow_bwd_slots(P) + (fuse_g[0] == 2 ? be_sweep0_slots(P) : fuse_g[0] ? b.fslots : 0) <= region_slots(m.sdf[0], b);
   // The top layer (F features + the sdf row, F == 256 = its input width) without launches of its own: its value-backward launch takes the
   // sdf column of the cotangent as a rank-one update of the 256-wide product (k_extra) and forms the main 256 x 256 weight gradient like any
   // other layer; the sdf ROW of the weight gradient is made of values two launches hold anyway -- the gradient-chain pair's unit vector
@@ -1196,7 +1232,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   // slot groups of a region: the value pair first (it carries the bias column sums), the gradient-chain pair behind it; a pair takes
   // fslots slots when it is fused and nchunk slots as a separate GEMM (one workgroup per slot: fewer would leave CUs idle); when neither is
   // fused one launch over nchunk slots forms both
-  auto value_slots = [&](int l) { return fuse_v[l] ? b.fslots : b.nchunk; };
+  auto value_slots = [&](int l) { return (l == 0 && use_nb0) ? be_narrow_bwd_slots(P) : fuse_v[l] ? b.fslots : b.nchunk; };
   auto grad_slots = [&](int l) { return (l == m.L && top_fused) ? 0 : fuse_g[l] == 2 ? be_sweep0_slots(P) : fuse_g[l] ? b.fslots : (fuse_v[l] ? b.nchunk : 0); };
   for (int l = 0; l < m.L; ++l) {
     const Lin& q = m.sdf[l];
@@ -1231,7 +1267,8 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       be_layer_gemm(g, s);
     }
   }
-  if (rays_grad) {
+  if (use_nb0) be_narrow_bwd(nb0, s);
+  else if (rays_grad) {
     const Lin& q = m.sdf[0];
     LayerGemm g;
     g.A.kind = VK_DIRECT; g.A.a = b.Z2[0]; g.A.lda = m.Hs;
@@ -1250,6 +1287,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       value_pair(l, d);
       grad_pair(l, d, 1);
       dw_into_region(q, d, r, 0, b.nchunk, P, true, s);
+    } else if (l == 0 && use_nb0) {          // (formed by the one-pass launch of step 6)
     } else if (!fuse_v[l]) {                 // the value pair alone, into the leading slots
       DwGemm d;
       d.npairs = 1; d.P = P;
