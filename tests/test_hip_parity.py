@@ -202,11 +202,12 @@ def test_results_do_not_depend_on_scratch_contents():
 
 
 @pytest.mark.parametrize("switch", ["CNR_DISABLE_WS", "CNR_WS_GENERIC", "CNR_DW_BF16", "CNR_DW_FP32", "CNR_WS_SERP=0", "CNR_WS_NOSTREAM",
-                                    "CNR_NO_FUSED", "CNR_NO_CHAIN_FWD", "CNR_NO_CHAIN_SDF", "CNR_CHAIN_GRAD"])
+                                    "CNR_NO_FUSED", "CNR_NO_CHAIN_FWD", "CNR_NO_CHAIN_SDF", "CNR_CHAIN_GRAD", "CNR_NO_SWEEP0", "CNR_NO_NARROW_BWD"])
 def test_fallback_kernels_keep_parity(switch):
     """The debugging switches select the fallback kernels (FP32-MFMA layer GEMM, interpreted weight-stationary kernel, split-bf16 and
     FP32-MFMA weight-gradient tiles, one walk direction for every layer launch, the general layer kernel instead of its stream form, the
-    per-layer launches instead of the chain-fused forward kernels) or, for CNR_CHAIN_GRAD, the opt-in chain-fused gradient chain.  They are
+    per-layer launches instead of the chain-fused forward kernels, separate layer + weight-gradient launches for the narrow-input layers) or, for
+    CNR_CHAIN_GRAD, the opt-in chain-fused gradient chain.  They are
     read once per process, so the G2 gate runs in a child process."""
     name, _, val = switch.partition("=")
     env = dict(os.environ, **{name: val or "1"})
@@ -593,6 +594,32 @@ def test_streaming_strip_and_head_backward_match_gemm_launches(tmp_path):
         e = float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-300)
         if not e < 5e-6:
             bad.append((k, e))
+    assert not bad, bad
+
+
+def test_narrow_input_layer_kernels_match_separate_launches(tmp_path):
+    """sweep0_dw_kernel (cnr_sweep0.hip: sweep launch of the first SDF layer + its gradient-chain weight-gradient pair) and narrow_bwd_kernel
+    (cnr_narrow_bwd.hip: input cotangent + weight + bias gradient of the relight in_layer and of the first SDF layer in one pass) against the
+    separate layer / weight-gradient launches (CNR_NO_SWEEP0=1 CNR_NO_NARROW_BWD=1, child processes).  The sweep launch's own outputs are the same
+    arithmetic; the weight gradients and the input cotangents change from FP32-MFMA products to split-f16 products (both at fp32 round-off of
+    the result), so outputs agree to the bit and gradients to round-off of their own scale."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("fused", {}), ("separate", {"CNR_NO_SWEEP0": "1", "CNR_NO_NARROW_BWD": "1"})):
+        path = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _STREAM_CHILD, root, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = dict(np.load(path))
+    assert set(res["fused"]) == set(res["separate"])
+    bad = []
+    for k in sorted(res["fused"]):
+        a, b = res["fused"][k].astype(np.float64), res["separate"][k].astype(np.float64)
+        if k.startswith("g:") or k in ("d_o", "d_d"):
+            e = float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-300)
+            if not e < 5e-6:
+                bad.append((k, e))
+        elif not np.array_equal(a, b, equal_nan=True):
+            bad.append((k, "differs"))
     assert not bad, bad
 
 
