@@ -77,6 +77,9 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
       const unsigned short* wlane = wlane_of(S, lane);
       const f4 cw_next = cw_fetch(Sn, tid);                       // lands while the MFMAs run; parked in LDS behind the row-max barrier
       // ---- a chain starts: its input rows HBM -> registers -> exact row scale -> f16 planes (16 threads per row, 4 columns each)
+      f4 vx[RT];   // the extra input columns of the chain start's rows (x_src == 1): loaded with the row, staged after the main MFMA phase
+#pragma unroll
+      for (int pass = 0; pass < RT; ++pass) vx[pass] = f4{0.f, 0.f, 0.f, 0.f};
       if (S.in != nullptr) {
         const int ncol = 16 * S.nkb_main, xcol = S.x_src == 1 ? 16 * S.nkb_x : 0;
         const long tile0 = tile * T;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
         // all loads of the RT row groups first (one exposed memory round trip per chain start, not RT), then the conversion
         const int sc4 = (tid & 15) * 4;
         const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-        f4 v0[RT], v1[RT], v2[RT], v3[RT], vx[RT];
+        f4 v0[RT], v1[RT], v2[RT], v3[RT];
 #pragma unroll
         for (int pass = 0; pass < RT; ++pass) {
           const int row_l = pass * 32 + (tid >> 4);
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
           if (64 + sc4 < ncol) v1[pass] = *reinterpret_cast<const f4*>(src + 64 + sc4);
           if (128 + sc4 < ncol) v2[pass] = *reinterpret_cast<const f4*>(src + 128 + sc4);
           if (192 + sc4 < ncol) v3[pass] = *reinterpret_cast<const f4*>(src + 192 + sc4);
-          if (sc4 < xcol) vx[pass] = *reinterpret_cast<const f4*>(src + ncol + sc4);   // (only its magnitude is used here: one scale for the whole row)
+          if (sc4 < xcol) vx[pass] = *reinterpret_cast<const f4*>(src + ncol + sc4);   // (here only its magnitude is used: one scale for the whole row)
         }
 #pragma unroll
         for (int pass = 0; pass < RT; ++pass) {
@@ -143,10 +146,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
           if (sc4 < 16 * S.nkb_x) {
             f4 v = {0.f, 0.f, 0.f, 0.f};
             if (S.x_src == 1) {
-              const long tile0 = tile * T;
-              const int rows_left = (int)((c.P - tile0) < T ? (c.P - tile0) : T);
-              const int row_c = row_l < rows_left ? row_l : rows_left - 1;
-              v = *reinterpret_cast<const f4*>(S.in + tile0 * S.ld_in + row_c * S.ld_in + 16 * S.nkb_main + sc4);
+              v = vx[pass];                                   // (same thread, same row, same columns as at the chain start)
             } else if (sc4 == 0) {
               v = *reinterpret_cast<const f4*>(rgbs + row_l * 4);
             }
@@ -463,11 +463,13 @@ __global__ __launch_bounds__(512, 1) void sdf_save_chain_kernel(const SdfSaveCha
           if (tail_lane) {
             const int row_c = row_l < rows_left ? row_l : rows_left - 1;
             const float* erow = v.E + (tile0 + row_c) * kEmb;
+            float ev[16];   // (all 16 loads first: consumed one by one the compiler waits for each before it issues the next)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const int ei = cbase + r - L.N; ev[r] = erow[ei < 0 ? 0 : (ei < kEmb ? ei : kEmb - 1)]; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int ei = cbase + r - L.N;
-              const float e = erow[ei < 0 ? 0 : (ei < kEmb ? ei : kEmb - 1)];
-              acc[rt][r] = ei < 0 ? acc[rt][r] : ((next_skip && ei < v.emb) ? e : 0.0f);
+              acc[rt][r] = ei < 0 ? acc[rt][r] : ((next_skip && ei < v.emb) ? ev[r] : 0.0f);
             }
           }
           chain_save_block(acc[rt], tb, out_tile, out_ld, rt * 32, rows_left, lane);
