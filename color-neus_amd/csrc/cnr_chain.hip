@@ -94,31 +94,48 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
   float* pm = rs + T;                                        // [T][8] per-wave partial row maxima / partial dot products
   float* cwb = pm + T * 8;                                   // [2][512] column scales | biases of the current / next layer
   float* wtop = cwb + 1024;                                  // [256] sdf row of the top layer
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, pt = lane & 31;
-  const int cbase = wave * CB * 32 + 16 * half;              // this lane's 16 consecutive output columns of its j-th block: cbase + 32 j
+  const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const long ntiles = (c.P + T - 1) / T;
+  // per-lane indices are re-derived from a laundered copy of the thread index in every layer iteration: hoisted out of the loops they pin
+  // dozens of address registers for the whole kernel (29 - 33 spilled VGPRs before)
+#define VC_LANE_INDICES                                                                      \
+  int tid = tid0;                                                                            \
+  asm volatile("" : "+v"(tid));                                                              \
+  const int lane = tid & 63, half = lane >> 5, pt = lane & 31;                               \
+  const int cbase = wave * CB * 32 + 16 * half;   /* this lane's 16 consecutive output columns of its j-th block: cbase + 32 j */
 
   f16x8 wr1[4][CB], wr2[4][CB];                              // weight fragment ring: 4 k16 blocks in flight
-  auto wlane_of = [&](const FusedLayer& L) { return L.Wf + (long)wave * CB * (L.K >> 4) * 1024 + lane * 8; };
-  auto wprime = [&](const FusedLayer& L) { chain_wprime<CB>(wr1, wr2, wlane_of(L), L.K >> 4, 0, L.K >> 4); };
-  auto cw_fetch = [&](const FusedLayer& L) {                 // threads 0..127: one float4 of [column scales (256) | biases (256)]
+  auto wlane_of = [&](const FusedLayer& L, int lane_) __attribute__((always_inline)) { return L.Wf + (long)wave * CB * (L.K >> 4) * 1024 + lane_ * 8; };
+  auto wprime = [&](const FusedLayer& L, int lane_) __attribute__((always_inline)) { chain_wprime<CB>(wr1, wr2, wlane_of(L, lane_), L.K >> 4, 0, L.K >> 4); };
+  auto cw_fetch = [&](const FusedLayer& L, int tid_) __attribute__((always_inline)) {   // threads 0..127: one float4 of [column scales (256) | biases (256)]
     f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 64) v = *reinterpret_cast<const f4*>(L.wsc + tid * 4);
-    else if (tid < 128) v = *reinterpret_cast<const f4*>(L.bias + (tid - 64) * 4);
+    if (tid_ < 64) v = *reinterpret_cast<const f4*>(L.wsc + tid_ * 4);
+    else if (tid_ < 128) v = *reinterpret_cast<const f4*>(L.bias + (tid_ - 64) * 4);
     return v;
   };
 
-  wprime(c.lay[0]);
-  for (int i = tid; i < 256; i += THREADS) wtop[i] = c.wtop[i];
+  wprime(c.lay[0], tid0 & 63);
+  for (int i = tid0; i < 256; i += THREADS) wtop[i] = c.wtop[i];
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---- layer-0 input: E rows -> planes (16 threads per row, 4 columns each)
-    if (tid < 128) *reinterpret_cast<f4*>(cwb + tid * 4) = cw_fetch(c.lay[0]);
+    // ---- layer-0 input: E rows -> planes (16 threads per row, 4 columns each); all row groups are requested before the first is converted
+    // (consumed one by one the compiler waits for each load before it issues the next: RT exposed round trips per tile)
+    constexpr int NPASS = T * 16 / THREADS;
+    {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    if (tid < 128) *reinterpret_cast<f4*>(cwb + tid * 4) = cw_fetch(c.lay[0], tid);
+    f4 erows[NPASS];
 #pragma unroll
-    for (int pass = 0; pass < T * 16 / THREADS; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
       const int row_l = pass * (THREADS / 16) + (tid >> 4), sc4 = (tid & 15) * 4;
       long grow = tile * T + row_l; if (grow >= c.P) grow = c.P - 1;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (sc4 < kEmb) v = *reinterpret_cast<const f4*>(c.E + grow * kEmb + sc4);
+      erows[pass] = *reinterpret_cast<const f4*>(c.E + grow * kEmb + (sc4 < kEmb ? sc4 : 0));
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row_l = pass * (THREADS / 16) + (tid >> 4), sc4 = (tid & 15) * 4;
+      const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f4 v = sc4 < kEmb ? erows[pass] : z4;
       float mx = ws_absmax4(v);
 #pragma unroll
       for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
@@ -136,14 +153,16 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
       }
       if ((tid & 15) == 0) rs[row_l] = 1.0f / sc;
     }
+    }
     lds_barrier();
 
     for (int l = 0; l < c.nl; ++l) {
+      VC_LANE_INDICES
       const FusedLayer& L = c.lay[l];
       const int nkb = L.K >> 4;
       const bool last = l + 1 == c.nl;
-      const unsigned short* wlane = wlane_of(L);
-      const f4 cw_next = cw_fetch(c.lay[last ? l : l + 1]);   // lands while the MFMAs run; parked in LDS behind the row-max barrier
+      const unsigned short* wlane = wlane_of(L, lane);
+      const f4 cw_next = cw_fetch(c.lay[last ? l : l + 1], tid);   // lands while the MFMAs run; parked in LDS behind the row-max barrier
       f32x16 acc[CB][RT];
 #pragma unroll
       for (int j = 0; j < CB; ++j)
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
       if (nkb == 16) chain_mfma_blocks<RT, CB, 16>(acc, wr1, wr2, Ab, APLANE, wlane, 16, 0);
       else chain_mfma_blocks<RT, CB, 3>(acc, wr1, wr2, Ab, APLANE, wlane, 3, 0);
       // the next layer's (or the next tile's first layer's) leading weight blocks travel while the epilogue runs
-      wprime(last ? c.lay[0] : c.lay[l + 1]);
+      wprime(last ? c.lay[0] : c.lay[l + 1], lane);
 
       // ---- epilogue: z = acc * (1 / row scale) * (1 / column scale) + bias ; a = softplus(z) ; skip concat ; row max
       const float* cw = cwb + (l & 1) * 512;
@@ -170,12 +189,11 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
         const int c0 = cbase + 32 * j;
-        f4 wsc4[4], b4[4], wt4[4];
+        f4 wsc4[4], b4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           wsc4[q] = *reinterpret_cast<const f4*>(cw + c0 + 4 * q);
           b4[q] = *reinterpret_cast<const f4*>(cw + 256 + c0 + 4 * q);
-          wt4[q] = *reinterpret_cast<const f4*>(wtop + c0 + 4 * q);
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -209,7 +227,11 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
           float mx = 0.0f, dot = 0.0f;
           if (last) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dot = fmaf(acc[j][rt][r], wt4[r >> 2][r & 3], dot);
+            for (int q = 0; q < 4; ++q) {
+              const f4 wt = *reinterpret_cast<const f4*>(wtop + c0 + 4 * q);
+              dot = fmaf(acc[j][rt][4 * q], wt.x, dot); dot = fmaf(acc[j][rt][4 * q + 1], wt.y, dot);
+              dot = fmaf(acc[j][rt][4 * q + 2], wt.z, dot); dot = fmaf(acc[j][rt][4 * q + 3], wt.w, dot);
+            }
           } else {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(fabsf(acc[j][rt][r]), fabsf(acc[j][rt][r + 1])), mx);
@@ -250,6 +272,8 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
     }
   }
 }
+
+#undef VC_LANE_INDICES
 
 template <int RT, int CB>
 static void launch_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
