@@ -257,8 +257,10 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s);
 // Backward of a narrow-input layer (<= 48 input columns, 256 outputs) in one pass over its 256-wide output cotangent X (cnr_narrow_bwd.hip):
 // dW[j][c] = sum X[pt][j] Y[pt][c] and db[j] = sum X[pt][j] into be_narrow_bwd_slots(P) slots ([256][ldk] / [256] floats each), and -- with Wp --
 // dx[pt][c] = sum_j X[pt][j] Wt[c][j] for c < ndx (Wp / wscale: the f16 planes and row scales of W^T, rows = input columns, ldw = 256).
+// partial == nullptr: only dx (then X may be the view sp'(X) * Xb: the 39-column end of the forward gradient chain).
 struct NarrowBwd {
   const float* X = nullptr; int ldx = 0;
+  const float* Xb = nullptr; int ldxb = 0;   // optional: X stands for the view softplus100'(X) * Xb (launches without a weight gradient: partial == nullptr)
   const float* Y = nullptr; int ldy = 0; int ky = 0;
   long P = 0;
   const unsigned short* Wp = nullptr; long wp_stride = 0; int ldw = 0; int w_rows = 0; const float* wscale = nullptr;

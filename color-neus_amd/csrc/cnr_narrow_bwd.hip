@@ -35,7 +35,9 @@ constexpr int NB_LDS_DX = NB_OFF_W + 2 * NB_WPLANE;
 constexpr int NB_EBIG = 0x3f000000;
 static_assert(NB_LDS_DX <= 160 * 1024, "LDS budget of one CU");
 
-template <bool DX>
+// DX: the input-side product (needs Wp); DW: the weight / bias gradient (needs Y, partial); SIG: X is the view softplus100'(X) * Xb (the end of the
+// forward gradient chain: u_0 = sp'(z_0) v_0 -> the cotangent of the embedding, a DX-only launch)
+template <bool DX, bool DW, bool SIG>
 __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowBwd p, int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_n[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,10 +73,12 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
   const f4 z4 = {0.f, 0.f, 0.f, 0.f};
   // two staging register sets: tile j travels in set j & 1, so that two tiles are in flight while a third is being used (one tile in flight
   // left the launch latency-bound: 2.5 - 3.2 TB/s)
-  struct RawTile { f4 x[4]; f4 y; };
+  struct RawTile { f4 x[4]; f4 xb[SIG ? 4 : 1]; f4 y; };
   RawTile ra, rb;
 #pragma unroll
   for (int q = 0; q < 4; ++q) { ra.x[q] = z4; rb.x[q] = z4; }
+#pragma unroll
+  for (int q = 0; q < (SIG ? 4 : 1); ++q) { ra.xb[q] = z4; rb.xb[q] = z4; }
   ra.y = z4; rb.y = z4;
   const bool want_cs = p.colsum != nullptr;   // (then column ky of Y is a column of ones: ky < 48)
   auto s_fetch = [&](int i, RawTile& rt) __attribute__((always_inline)) {
@@ -83,13 +87,25 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
     const float* src = p.X + row * p.ldx + scol;
 #pragma unroll
     for (int q = 0; q < 4; ++q) rt.x[q] = *reinterpret_cast<const f4*>(src + 64 * q);
-    rt.y = *reinterpret_cast<const f4*>(p.Y + row * p.ldy + (ylive ? scol : 0));   // (every lane loads: a branch here costs the compiler its count of loads in flight)
+    if constexpr (SIG) {
+      const float* srcb = p.Xb + row * p.ldxb + scol;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rt.xb[q] = *reinterpret_cast<const f4*>(srcb + 64 * q);
+    }
+    if constexpr (DW) rt.y = *reinterpret_cast<const f4*>(p.Y + row * p.ldy + (ylive ? scol : 0));   // (every lane loads: a branch here costs the compiler its count of loads in flight)
   };
   auto s_put = [&](int i, int buf, const RawTile& rt) __attribute__((always_inline)) {
     const bool live = (t0 + i) * WS_TP + srow < Pn;
     f4 v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = live ? rt.x[q] : z4;
+    for (int q = 0; q < 4; ++q) {
+      f4 x = rt.x[q];
+      if constexpr (SIG) {
+        x.x = softplus100_d1(x.x) * rt.xb[q].x; x.y = softplus100_d1(x.y) * rt.xb[q].y;
+        x.z = softplus100_d1(x.z) * rt.xb[q].z; x.w = softplus100_d1(x.w) * rt.xb[q].w;
+      }
+      v[q] = live ? x : z4;
+    }
     f4 y = rt.y;
     y.x = (live && scol + 0 < p.ky) ? y.x : 0.0f; y.y = (live && scol + 1 < p.ky) ? y.y : 0.0f;
     y.z = (live && scol + 2 < p.ky) ? y.z : 0.0f; y.w = (live && scol + 3 < p.ky) ? y.w : 0.0f;
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
     unsigned char* dst = B + srow * NB_ALD + scol * 2;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ws_put4(v[q], sx, dst + 128 * q, NB_APLANE);
-    if (ylive) {
+    if (DW && ylive) {
       unsigned char* yb = smem_n + NB_OFF_Y + buf * NB_YBUF + scol * NB_YLD + srow * 2;
       const float ya[4] = {y.x * sy, y.y * sy, y.z * sy, y.w * sy};
 #pragma unroll
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
       const bool nonfin = !(mx < 3.0e38f) || !(my < 3.0e38f);
       int e = NB_EBIG;
       if (vx && vy) e = (int)((__float_as_uint(sx) >> 23) & 0xff) + (int)((__float_as_uint(sy) >> 23) & 0xff) - 254;
-      reinterpret_cast<int*>(rs)[32 + srow] = nonfin ? -NB_EBIG : e;
+      if (DW) reinterpret_cast<int*>(rs)[32 + srow] = nonfin ? -NB_EBIG : e;
     }
   };
 
@@ -199,6 +215,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (!DW) return;
     // ---- dW of this tile: rows c0 .. c0 + 31
     const int e_l = er[m];
     int Gt = e_l == -NB_EBIG ? NB_EBIG - 1 : e_l;        // (non-finite rows do not steer the exponent ...)
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
     cnr_lds_barrier();
   }
   if (n & 1) tile(n - 1, 0);
+  if constexpr (!DW) return;
   // ---- partial sums of this range: [256][ldk], every slot written in full
   float* out = p.partial + (long)blockIdx.x * 256 * p.ldk;
 #pragma unroll
@@ -298,8 +316,13 @@ int be_narrow_bwd_slots(long P) {
 bool be_narrow_bwd_ok(const NarrowBwd& p) {
   static const bool off = getenv("CNR_NO_NARROW_BWD") != nullptr;   // debugging aid: narrow layer launch + weight-gradient launch as before
   const bool dx_ok = p.Wp == nullptr || (p.wscale && p.dx && p.ldw == 256 && p.w_rows >= 1 && p.ndx >= 1 && p.ndx <= NB_YCOLS && p.ndx <= p.w_rows && (p.lddx & 3) == 0 && p.lddx >= ((p.ndx + 3) & ~3));
-  return !off && p.P > 0 && p.X && p.Y && p.partial && (p.ldx & 3) == 0 && p.ldx >= 256 && (p.ldy & 3) == 0 && p.ky >= 1 && p.ky <= NB_YCOLS && p.ldy >= NB_YCOLS &&
-         p.ldk >= p.ky && p.ldk <= 64 && (p.colsum == nullptr || p.ky < NB_YCOLS) && dx_ok;
+  const bool dw_ok = p.partial == nullptr ? (p.Wp != nullptr && p.colsum == nullptr)
+                                          : (p.Y && (p.ldy & 3) == 0 && p.ky >= 1 && p.ky <= NB_YCOLS && p.ldy >= NB_YCOLS && p.ldk >= p.ky && p.ldk <= 64 &&
+                                             (p.colsum == nullptr || p.ky < NB_YCOLS));
+  static const bool off_dx = getenv("CNR_NO_NARROW_DX") != nullptr;   // debugging aid: the FP32-MFMA layer kernel for the product-only launches
+  const bool sig_ok = p.Xb == nullptr || ((p.ldxb & 3) == 0 && p.ldxb >= 256 && p.partial == nullptr);   // (the view form: DX-only launches)
+  if (p.partial == nullptr && off_dx) return false;
+  return !off && p.P > 0 && p.X && (p.ldx & 3) == 0 && p.ldx >= 256 && dx_ok && dw_ok && sig_ok;
 }
 
 void be_narrow_bwd(const NarrowBwd& p, cnr_stream s) {
@@ -308,13 +331,18 @@ void be_narrow_bwd(const NarrowBwd& p, cnr_stream s) {
   const int grid = be_narrow_bwd_slots(p.P);
   static DeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_bwd_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_bwd_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_bwd_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&narrow_bwd_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  const double bytes = 4.0 * (double)p.P * (256 + p.ky + (p.Wp ? p.ndx : 0)) + 4.0 * grid * 256.0 * (p.ldk + 1);
-  TimingScope ts_("narrow_bwd", 0, 301, p.P, 256, p.ky, p.Wp ? 2 : 1, s, bytes);
-  if (p.Wp) hipLaunchKernelGGL(narrow_bwd_kernel<true>, dim3(grid), dim3(WS_THREADS), NB_LDS_DX, s, p, (int)tpw);
-  else hipLaunchKernelGGL(narrow_bwd_kernel<false>, dim3(grid), dim3(WS_THREADS), NB_LDS_NODX, s, p, (int)tpw);
+  const bool dw = p.partial != nullptr;
+  const double bytes = 4.0 * (double)p.P * (256 + (p.Xb ? 256 : 0) + (dw ? p.ky : 0) + (p.Wp ? p.ndx : 0)) + (dw ? 4.0 * grid * 256.0 * (p.ldk + 1) : 0.0);
+  TimingScope ts_(dw ? "narrow_bwd" : "narrow_dx", 0, 301, p.P, dw ? 256 : p.ndx, dw ? p.ky : 256, (p.Wp ? 1 : 0) + (dw ? 1 : 0), s, bytes);
+  if (!dw && p.Xb) hipLaunchKernelGGL((narrow_bwd_kernel<true, false, true>), dim3(grid), dim3(WS_THREADS), NB_LDS_DX, s, p, (int)tpw);
+  else if (!dw) hipLaunchKernelGGL((narrow_bwd_kernel<true, false, false>), dim3(grid), dim3(WS_THREADS), NB_LDS_DX, s, p, (int)tpw);
+  else if (p.Wp) hipLaunchKernelGGL((narrow_bwd_kernel<true, true, false>), dim3(grid), dim3(WS_THREADS), NB_LDS_DX, s, p, (int)tpw);
+  else hipLaunchKernelGGL((narrow_bwd_kernel<false, true, false>), dim3(grid), dim3(WS_THREADS), NB_LDS_NODX, s, p, (int)tpw);
   CNR_LAUNCH_CHECK("narrow_bwd");
 }
 

@@ -610,6 +610,12 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
     if (rs) g.rs_out = rs[l];
     if (l == 0) {
       g.E.kind = EK_STORE; g.E.n_out = m.emb; g.E.o1 = CE0; g.E.ld1 = kEmb;
+      // the 39-column end of the chain as one streaming pass over z_0 / v_0 with the W^T planes in LDS (cnr_narrow_bwd.hip, its product-only form)
+      NarrowBwd nb;
+      nb.X = Z[0]; nb.ldx = m.Hs; nb.Xb = g.A.b; nb.ldxb = g.A.ldb; nb.P = P;
+      nb.Wp = q.Wtp; nb.wp_stride = (long)q.kpad * q.ldwt; nb.ldw = q.ldwt; nb.w_rows = q.kpad; nb.wscale = q.Wtps;
+      nb.dx = CE0; nb.lddx = kEmb; nb.ndx = m.emb;
+      if (g.A.kind == VK_SIGMUL && g.A.scale == 1.0f && g.rs_out == nullptr && q.n == 256 && m.Hs == 256 && be_narrow_bwd_ok(nb)) { be_narrow_bwd(nb, s); continue; }
     } else if (m.skip(l)) {
       g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n;
       g.E.o1 = V[l - 1]; g.E.ld1 = m.Hs; g.E.o2 = CES; g.E.ld2 = kEmb; g.E.o2_off = skip_off(m);
