@@ -76,6 +76,12 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
       const ChainFwdStep& Sn = c.st[last_step ? 0 : s + 1];
       const unsigned short* wlane = wlane_of(S, lane);
       const f4 cw_next = cw_fetch(Sn, tid);                       // lands while the MFMAs run; parked in LDS behind the row-max barrier
+      float hbias[3] = {0.f, 0.f, 0.f};                           // a head follows this step: its biases now (same reason as for the head's weight rows below)
+      if (S.head != 0) {
+        const ChainFwdHead& Hh = S.head == 1 ? c.col_head : c.rel_head;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) hbias[j] = Hh.bias[j < Hh.n ? j : 0];
+      }
       // ---- a chain starts: its input rows HBM -> registers -> exact row scale -> f16 planes (16 threads per row, 4 columns each)
       f4 vx[RT];   // the extra input columns of the chain start's rows (x_src == 1): loaded with the row, staged after the main MFMA phase
 #pragma unroll
@@ -215,6 +221,28 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
           }
         }
       }
+      if (chain_end) {
+        // ---- the 3-wide head on the ReLU output still in registers: fp32 dot products, partial sums per (row, wave) in a fixed order.
+        // BEFORE the row stores below: a load issued behind them is waited for with vmcnt(0), i.e. with the whole store queue of the wave
+        const ChainFwdHead& H = S.head == 1 ? c.col_head : c.rel_head;
+#pragma unroll 1
+        for (int j = 0; j < 3; ++j) {
+          f4 wj[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            wj[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (j < H.n) wj[q] = *reinterpret_cast<const f4*>(H.W + (long)j * H.ldw + cbase + 4 * q);
+          }
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            float dot = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot = fmaf(acc[rt][r], wj[r >> 2][r & 3], dot);
+            dot += __shfl_xor(dot, 32);
+            if (half == 0) hp[((rt * 32 + pt) * 8 + wave) * 4 + j] = dot;
+          }
+        }
+      }
       // ---- the ReLU output rows for the backward pass: 32 x 32 block -> LDS (16 rows at a time) -> 8 rows x 128 contiguous bytes per store
       if (S.save != nullptr && !(c.dbg & 1)) {
         const long tile0 = tile * T;
@@ -248,25 +276,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
         }
       }
       if (chain_end) {
-        // ---- the 3-wide head on the ReLU output still in registers: fp32 dot products, partial sums per (row, wave) in a fixed order
         const ChainFwdHead& H = S.head == 1 ? c.col_head : c.rel_head;
-#pragma unroll 1
-        for (int j = 0; j < 3; ++j) {
-          f4 wj[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            wj[q] = f4{0.f, 0.f, 0.f, 0.f};
-            if (j < H.n) wj[q] = *reinterpret_cast<const f4*>(H.W + (long)j * H.ldw + cbase + 4 * q);
-          }
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            float dot = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dot = fmaf(acc[rt][r], wj[r >> 2][r & 3], dot);
-            dot += __shfl_xor(dot, 32);
-            if (half == 0) hp[((rt * 32 + pt) * 8 + wave) * 4 + j] = dot;
-          }
-        }
         lds_barrier();
         if (tid < T) {
           const int row_l = tid;
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
             float sum = hp[(row_l * 8) * 4 + j];
 #pragma unroll
             for (int w = 1; w < 8; ++w) sum += hp[(row_l * 8 + w) * 4 + j];
-            v[j] = j < H.n ? sum + H.bias[j] : 0.0f;
+            v[j] = j < H.n ? sum + hbias[j] : 0.0f;
           }
           if (S.head == 1) {
             f4 y = {0.f, 0.f, 0.f, 0.f};
