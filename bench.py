@@ -207,6 +207,16 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), loss
 
+    def side_rate(nsteps, r, alt=None, outputs="dict"):
+        """rays/s of a side leg (small batches, C2, loss_only): from the MEDIAN per-step event time on one GPU -- these legs are 0.1-0.4 s long,
+        and one host hiccup in them moved a mean-based figure by 30 % between otherwise identical runs -- from the total time otherwise"""
+        ts = []
+        dts, _ = timed(nsteps, 5, r, alt, per_step=ts, outputs=outputs)
+        if world == 1 and len(ts) == nsteps:
+            ts.sort()
+            return (r if r is not None else R) * 1e3 / ts[len(ts) // 2]
+        return (r if r is not None else R) * world * nsteps / dts
+
     step_times = []
     dt, loss = timed(args.steps, args.warmup, per_step=step_times)
     Rg = R * world
@@ -321,8 +331,7 @@ def main():
                 small[str(r)] = round(value, 1)
                 continue
             n = max(20, min(args.steps, 60))
-            dts, _ = timed(n, 5, r)
-            small[str(r)] = round(r * world * n / dts, 1)
+            small[str(r)] = round(side_rate(n, r), 1)
         result["small_batch"] = {"unit": "rays/s", "rays_per_step_per_gpu": small}
         # launches of a 512-ray step (the fixed per-launch costs are what separates the small-batch rate from the 4096-ray rate)
         if rank == 0 and world == 1:
@@ -339,8 +348,8 @@ def main():
                 else cn.ClipAdam(r2._ordered_params(), lr=5e-4, betas=(0.9, 0.99), eps=1e-8, max_norm=1.0, library=lib))
         alt = (r2, list(r2.parameters()), opt2)
         n = max(20, min(args.steps, 60))
-        dts, _ = timed(n, 5, 512, alt)
-        result["small_batch"]["c2_512rays_x_64samples_no_importance"] = round(512 * world * n / dts, 1)
+        result["small_batch"]["c2_512rays_x_64samples_no_importance"] = round(side_rate(n, 512, alt), 1)
+        result["small_batch"]["note"] = "side legs of 20-60 steps: rate at the median per-step event time (one GPU), total time over ranks otherwise"
 
     # ---- the same step with training_outputs="loss_only" (no [R][M][3] dict tensors, the relight term from per-ray sums of
     # the compositor); not the default because the reference's trainer consumes the dict
@@ -348,8 +357,7 @@ def main():
         lo = {}
         for r in sorted({R, 1024}):
             n = max(20, min(args.steps, 60))
-            dts, _ = timed(n, 5, r, outputs="loss_only")
-            lo[str(r)] = round(r * world * n / dts, 1)
+            lo[str(r)] = round(side_rate(n, r, None, "loss_only"), 1)
         result["loss_only"] = {"unit": "rays/s", "rays_per_step_per_gpu": lo,
                                "note": "same step (fwd + fused loss + bwd + clip + Adam) with renderer(..., training_outputs='loss_only')"}
 

@@ -1,5 +1,5 @@
 """Per-launch records of one training step (library timing scopes: name, shape, ms, algorithmic bytes).  Usage on the GPU box:
-  python tools/step_records.py [rays=4096] [min_ms=0.05]"""
+  python tools/step_records.py [rays=4096] [min_ms=0.05] [n_importance=64]"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, color_neus_amd as cn
@@ -7,7 +7,8 @@ from color_neus_amd import synthetic
 dev = torch.device("cuda:0")
 NR = int(sys.argv[1]) if len(sys.argv) > 1 else 4096   # rays per step
 THR = float(sys.argv[2]) if len(sys.argv) > 2 else 0.05   # print records above this many ms
-cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)
+NI = int(sys.argv[3]) if len(sys.argv) > 3 else 64   # importance samples per ray (0: the C2 form, 64 coarse samples only)
+cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0, n_importance=NI)
 torch.manual_seed(0)
 r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(dev)
 lib = cn.load_library()
