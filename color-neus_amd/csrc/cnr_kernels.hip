@@ -1342,6 +1342,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
         if (active) {
           if (p.d_z) { p.d_z[pt * 2] = ddepth * w[c]; p.d_z[pt * 2 + 1] = ag.d_dist; }
           p.ztop[pt * p.ldztop + p.ztop_col] = (ag.d_sdf + (p.d_sdf_s ? p.d_sdf_s[pt] : 0.0f)) / p.sdf_scale;
+          for (int k = p.ztop_col + 1; k < p.ldztop; ++k) p.ztop[pt * p.ldztop + k] = 0.0f;   // (the pad columns behind it: one launch less than zeroing them apart)
           for (int k = 0; k < 3; ++k) p.gbar[pt * 4 + k] = gb[k];
           p.gbar[pt * 4 + 3] = 0.0f;
           for (int k = 0; k < 3; ++k) {

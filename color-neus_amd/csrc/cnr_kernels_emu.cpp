@@ -578,6 +578,7 @@ void be_composite_bwd(const CompositeBwd& p, cnr_stream) {
       p.gbar[pt * 4 + 3] = 0.0f;
       if (p.d_z) { p.d_z[pt * 2] = ddepth * w[j]; p.d_z[pt * 2 + 1] = ag.d_dist; }
       p.ztop[pt * p.ldztop + p.ztop_col] = (ag.d_sdf + (p.d_sdf_s ? p.d_sdf_s[pt] : 0.0f)) / p.sdf_scale;
+          for (int k = p.ztop_col + 1; k < p.ldztop; ++k) p.ztop[pt * p.ldztop + k] = 0.0f;   // (the pad columns behind it: one launch less than zeroing them apart)
       for (int k = 0; k < 3; ++k) {
         float cbar = dcol[k] * w[j] + (p.d_color_s ? p.d_color_s[pt * 3 + k] : 0.0f);
         if (p.has_relight) {

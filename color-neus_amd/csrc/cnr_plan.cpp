@@ -1003,7 +1003,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   RangeScope range_bwd("cnr_render_backward");
   be_range_push("compositor backward");
   // ---- 1. compositor backward
-  be_zero_cols(b.ZTOP, x.ldztop, m.F + 1, x.ldztop, P, s);   // pad columns of [feat cotangent | sdf cotangent | 0]: every other column is written below
+  // (pad columns of ZTOP = [feat cotangent | sdf cotangent | 0]: written by the compositor's backward together with the sdf column)
   CompositeBwd cb;
   cb.o = in->rays_o; cb.d = in->rays_d; cb.z = out->z_vals; cb.R = R; cb.M = m.M; cb.sample_dist = 2.0f / (float)m.S;
   cb.sdf = x.sdf; cb.g = out->gradients ? out->gradients : x.gbuf; cb.color = m.has_relight ? x.relit : x.gcol; cb.ldcolor = 4;
