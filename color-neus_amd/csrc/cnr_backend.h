@@ -361,6 +361,9 @@ struct LossScalars {   // see cnr_loss_combine / cnr_loss_coef in the ABI header
 };
 void be_loss_combine(const LossScalars& c, const float* sums, const float* gerr, float* out6, cnr_stream s);
 void be_loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, cnr_stream s);
+// the forward side (partial sums, their fold, the scalar tail) and the backward side (coefficients + element-wise gradients) as ONE launch each
+void be_loss_forward(const LossArgs& a, float* partial, const LossScalars& c, const float* gerr, float* sums, float* out6, cnr_stream s);
+void be_loss_backward(const LossArgs& a, const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, float* d_color, float* d_wsum, cnr_stream s);
 // per-parameter gradient clip + Adam over up to kAdamBatch tensors per launch (clip_gradient + torch.optim.Adam, net_utils.py:174-184, :88)
 constexpr int kAdamBatch = 64;
 constexpr int kAdamChunk = 4096;   // elements per workgroup: a tensor is cut into ceil(n / kAdamChunk) chunks

@@ -815,6 +815,79 @@ void be_loss_sums(const LossArgs& a, float* partial, float* sums, cnr_stream s) 
   hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(256), 0, s, partial, kLossBlocks, sums);
   CNR_LAUNCH_CHECK("loss_sums");
 }
+// The whole forward side in ONE launch: every block writes its partial sums, takes a ticket, and the block that draws the last one folds all
+// partials in the fixed order of loss_fold_kernel and runs the scalar tail (loss_combine).  Which block is last does not matter: bitwise the same
+// sums as the two-launch form.  The ticket counter lives in the library (zero when no launch is in flight: the last block resets it), so two
+// loss evaluations must not run concurrently on one device.
+__device__ unsigned g_loss_ticket = 0;
+__global__ __launch_bounds__(256) void loss_forward_kernel(const LossArgs a, float* partial, const LossScalars c, const float* gerr, float* sums, float* out6) {
+  __shared__ float red[4];
+  __shared__ int is_last;
+  const int tid = threadIdx.x, nb = gridDim.x, b = blockIdx.x;
+  float s_rgb = 0.f, s_bce = 0.f, s_rel = 0.f;
+  const long n_rgb = a.R * 3;
+  for (long i = (long)b * 256 + tid; i < n_rgb; i += (long)nb * 256) s_rgb += loss_rgb_term(a.color[i], a.gt[i], a.rgb_l1);
+  if (a.mask)
+    for (long r = (long)b * 256 + tid; r < a.R; r += (long)nb * 256) s_bce += loss_bce_term(a.wsum[r], a.mask[r]);
+  if (a.drel) {
+    const long per_ray = a.drel_per_ray ? 1 : (long)a.M * 3, n_rel = a.R * per_ray;
+    for (long i = (long)b * 256 + tid; i < n_rel; i += (long)nb * 256) {
+      const float m = (a.include_mask && a.mask) ? a.mask[i / per_ray] : 1.0f;
+      s_rel += a.drel[i] * m;
+    }
+  }
+  s_rgb = block_sum_256(s_rgb, red);
+  s_bce = block_sum_256(s_bce, red);
+  s_rel = block_sum_256(s_rel, red);
+  if (tid == 0) {
+    partial[b * 4 + 0] = s_rgb; partial[b * 4 + 1] = s_bce; partial[b * 4 + 2] = s_rel; partial[b * 4 + 3] = 0.f;
+    __threadfence();                                               // the partials are visible device-wide before the ticket is drawn
+    const unsigned t = atomicAdd(&g_loss_ticket, 1u);
+    is_last = t == (unsigned)nb - 1u;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  float v[3] = {0.f, 0.f, 0.f};
+  for (int k = tid; k < nb; k += 256) {                            // (device-scope loads: other CUs wrote these)
+    v[0] += __hip_atomic_load(partial + k * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[1] += __hip_atomic_load(partial + k * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[2] += __hip_atomic_load(partial + k * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __shared__ float tot[4];
+  for (int j = 0; j < 3; ++j) { const float sj = block_sum_256(v[j], red); if (tid == 0) tot[j] = sj; }
+  if (tid == 0) {
+    tot[3] = 0.f;
+    sums[0] = tot[0]; sums[1] = tot[1]; sums[2] = tot[2]; sums[3] = 0.f;
+    loss_combine(c, tot, gerr, out6);
+    g_loss_ticket = 0;
+  }
+}
+void be_loss_forward(const LossArgs& a, float* partial, const LossScalars& c, const float* gerr, float* sums, float* out6, cnr_stream s) {
+  TimingScope ts_("loss_forward", 2, 0, a.R, 0, 0, 0, s);
+  hipLaunchKernelGGL(loss_forward_kernel, dim3(kLossBlocks), dim3(256), 0, s, a, partial, c, gerr, sums, out6);
+  CNR_LAUNCH_CHECK("loss_forward");
+}
+// ... and the backward side in one: every thread forms the coefficients from the upstream gradient itself (loss_coef: a dozen flops)
+__global__ __launch_bounds__(256) void loss_backward_kernel(const LossArgs a, const LossScalars c, const float* g_loss, const float* mean_rel, float* coef_out,
+                                                            float* d_color, float* d_wsum) {
+  float coef[4];
+  loss_coef(c, g_loss, c.use_relight ? mean_rel : g_loss, coef);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = coef[0]; coef_out[1] = coef[1]; coef_out[2] = coef[2]; coef_out[3] = coef[3]; }
+  const long n_rgb = a.R * 3;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_rgb; i += stride) d_color[i] = coef[0] * loss_rgb_grad(a.color[i], a.gt[i], a.rgb_l1);
+  if (d_wsum)
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < a.R; r += stride) d_wsum[r] = a.mask ? coef[1] * loss_bce_grad(a.wsum[r], a.mask[r]) : 0.0f;
+}
+void be_loss_backward(const LossArgs& a, const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, float* d_color, float* d_wsum, cnr_stream s) {
+  TimingScope ts_("loss_backward", 2, 0, a.R, 0, 0, 0, s);
+  long blocks = (a.R * 3 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(loss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, c, g_loss, mean_rel, coef4, d_color, d_wsum);
+  CNR_LAUNCH_CHECK("loss_backward");
+}
 __global__ __launch_bounds__(256) void loss_grads_kernel(const LossArgs a, const float* coef, float* d_color, float* d_wsum, float* d_drel) {
   const float c_rgb = coef[0], c_bce = coef[1], c_rel = coef[2];
   const long n_rgb = a.R * 3, per_ray = (long)a.M * 3, n_rel = a.drel || d_drel ? a.R * per_ray : 0;

@@ -1854,6 +1854,34 @@ int cnr_loss_coef(const cnr_loss_config* cfg, const float* g_loss, const float* 
   return check_backend("loss_coef");
 }
 
+int cnr_loss_forward(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight, int32_t delta_per_ray,
+                     const float* rgb_gt, const float* mask, const float* gradient_error, int64_t n_rays, int32_t n_samples, float n_rays_global,
+                     int32_t use_mask, int32_t use_relight, float* sums, float* out, void* scratch, size_t scratch_bytes, void* stream) {
+  LossArgs a;
+  LossScalars c;
+  if (loss_args(cfg, color_fine, weight_sum, delta_relight, rgb_gt, mask, n_rays, n_samples, a)) return -1;
+  if (loss_scalars(cfg, n_rays_global, n_samples, use_mask, use_relight, c)) return -1;
+  if (!sums || !out || !scratch || !gradient_error) return fail("null argument");
+  if (mask && !weight_sum) return fail("weight_sum is required with a mask");
+  if (scratch_bytes < cnr_loss_scratch_bytes(n_rays)) return fail("loss scratch too small");
+  a.drel_per_ray = delta_per_ray != 0;
+  be_loss_forward(a, static_cast<float*>(scratch), c, gradient_error, sums, out, (cnr_stream)stream);
+  return check_backend("loss_forward");
+}
+
+int cnr_loss_backward(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* rgb_gt, const float* mask,
+                      int64_t n_rays, int32_t n_samples, const float* g_loss, const float* mean_rel, float n_rays_global, int32_t use_mask,
+                      int32_t use_relight, float* coef, float* d_color_fine, float* d_weight_sum, void* stream) {
+  LossArgs a;
+  LossScalars c;
+  if (loss_args(cfg, color_fine, weight_sum, nullptr, rgb_gt, mask, n_rays, n_samples, a)) return -1;
+  if (loss_scalars(cfg, n_rays_global, n_samples, use_mask, use_relight, c)) return -1;
+  if (!g_loss || !coef || !d_color_fine || (use_relight && !mean_rel)) return fail("null argument");
+  if (d_weight_sum && mask && !weight_sum) return fail("weight_sum is required with a mask");
+  be_loss_backward(a, c, g_loss, mean_rel, coef, d_color_fine, d_weight_sum, (cnr_stream)stream);
+  return check_backend("loss_backward");
+}
+
 static int gen_rays_args(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
                          int32_t normalize, int32_t opengl, const float* origin, float radius, GenRays& g) {
   if (!c2w || !focal) return fail("null argument");

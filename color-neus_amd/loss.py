@@ -65,19 +65,17 @@ class _FusedLoss(torch.autograd.Function):
         sums = torch.empty(4, dtype=torch.float32, device=dev)
         nb = lib.lib.cnr_loss_scratch_bytes(R)
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-        fn = lib.lib.cnr_loss_sums_ray if per_ray else lib.lib.cnr_loss_sums
-        lib.check(fn(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), _p(gt_c), _p(mask_c), R, M, _p(sums),
-                     _p(scratch), nb, _stream(color_c)), "cnr_loss_sums")
         import torch.distributed as dist
         world = dist.get_world_size(group) if (dist.is_initialized() and n_rays_global is not None) else 1
         Rg = float(n_rays_global if n_rays_global is not None else R)
         eik_factor = None
         use_mask, use_rel = (lam_m != 0 and mask is not None), (lam_r != 0 and drel is not None)
         if world == 1 and gerr.dtype == torch.float32 and gerr.device == dev:
-            # single process: the scalar tail of the objective in one launch of the library (cnr_loss_combine) instead of a dozen torch ops
+            # single process: the two reduction phases and the scalar tail of the objective in ONE launch (cnr_loss_forward)
             out6 = torch.empty(6, dtype=torch.float32, device=dev)
-            lib.check(lib.lib.cnr_loss_combine(_C.byref(lcfg), _p(sums), _p(gerr.detach().reshape(-1).contiguous()), Rg, int(M), int(use_mask), int(use_rel),
-                                               _p(out6), _stream(color_c)), "cnr_loss_combine")
+            lib.check(lib.lib.cnr_loss_forward(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), int(per_ray), _p(gt_c), _p(mask_c),
+                                               _p(gerr.detach().reshape(-1).contiguous()), R, int(M), Rg, int(use_mask), int(use_rel),
+                                               _p(sums), _p(out6), _p(scratch), nb, _stream(color_c)), "cnr_loss_forward")
             loss, rgb_loss, eik, mask_out, rel_out, mean_rel = out6.unbind(0)
             ctx.lib, ctx.lcfg, ctx.lambdas, ctx.Rg, ctx.M = lib, lcfg, lambdas, Rg, M
             ctx.has = (use_mask, use_rel, False)
@@ -87,6 +85,9 @@ class _FusedLoss(torch.autograd.Function):
             ctx.mark_non_differentiable(rgb_loss, eik, mask_out, rel_out)
             return loss, rgb_loss, eik, mask_out, rel_out
         ctx.fused_scalars = False
+        fn = lib.lib.cnr_loss_sums_ray if per_ray else lib.lib.cnr_loss_sums
+        lib.check(fn(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), _p(gt_c), _p(mask_c), R, M, _p(sums),
+                     _p(scratch), nb, _stream(color_c)), "cnr_loss_sums")
         if world > 1:
             stats = torch.cat([sums[:3], eik_sums.detach().reshape(-1)[:2].to(torch.float32)])
             den_loc = stats[4].clone()
@@ -137,19 +138,21 @@ class _FusedLoss(torch.autograd.Function):
         mask_t = mask_c if mask_c.numel() else None
         # coefficients on the device from the (device-resident) upstream gradient: no host -> device copy, hence no host stall
         g = g_loss.to(torch.float32)
-        if ctx.fused_scalars:   # one launch (cnr_loss_coef); coef[3] = d loss / d gradient_error
+        d_color = torch.empty_like(color_c)
+        d_wsum = torch.empty(R, dtype=torch.float32, device=dev)
+        mask_g = mask_t if has_mask or lcfg.include_mask else None
+        if ctx.fused_scalars:   # one launch (cnr_loss_backward): coefficients + gradients; coef[3] = d loss / d gradient_error
             coef = torch.empty(4, dtype=torch.float32, device=dev)
-            lib.check(lib.lib.cnr_loss_coef(_C.byref(lcfg), _p(g.reshape(-1).contiguous()), _p(mean_rel), Rg, int(M), int(has_mask), int(has_rel),
-                                            _p(coef), _stream(color_c)), "cnr_loss_coef")
+            lib.check(lib.lib.cnr_loss_backward(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(gt_c), _p(mask_g), R, int(M), _p(g.reshape(-1).contiguous()),
+                                                _p(mean_rel), Rg, int(has_mask), int(has_rel), _p(coef), _p(d_color), _p(d_wsum), _stream(color_c)),
+                      "cnr_loss_backward")
         else:
             c_rgb = lam_f * (1.0 if lcfg.rgb_l1 else 2.0) / (Rg * 3.0)
             c_bce = (lam_m / Rg) if has_mask else 0.0
             c_rel = (lam_r * 2.0 / (Rg * M * 3.0)) if has_rel else 0.0
             coef = torch.stack([g * c_rgb, g * c_bce, g * c_rel * mean_rel, g * 0.0])
-        d_color = torch.empty_like(color_c)
-        d_wsum = torch.empty(R, dtype=torch.float32, device=dev)
-        lib.check(lib.lib.cnr_loss_grads(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(gt_c), _p(mask_t if has_mask or lcfg.include_mask else None),
-                                         R, M, _p(coef), _p(d_color), _p(d_wsum), _p(None), _stream(color_c)), "cnr_loss_grads")
+            lib.check(lib.lib.cnr_loss_grads(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(gt_c), _p(mask_g),
+                                             R, M, _p(coef), _p(d_color), _p(d_wsum), _p(None), _stream(color_c)), "cnr_loss_grads")
         d_drel = None
         if has_rel and ctx.shapes[2] is not None:
             # d mean(delta_relight * mask)^2 / d delta_relight[r, j, c] = 2 mean / n * mask[r]: one value per ray.  Handed to the renderer's

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CNR_ABI_VERSION 5
+#define CNR_ABI_VERSION 6
 
 typedef struct cnr_config {
   int32_t type;              /* 0 = NeuS (NeuS.py:68), 1 = Color_NeuS (Color_NeuS.py:10) */
@@ -158,6 +158,20 @@ int cnr_loss_combine(const cnr_loss_config* cfg, const float* sums /* device [4]
                      float n_rays_global, int32_t n_samples, int32_t use_mask, int32_t use_relight, float* out /* device [6] */, void* stream);
 int cnr_loss_coef(const cnr_loss_config* cfg, const float* g_loss /* device [1] */, const float* mean_rel /* device [1] */,
                   float n_rays_global, int32_t n_samples, int32_t use_mask, int32_t use_relight, float* coef /* device [4] */, void* stream);
+
+/* The same two sides as ONE launch each (single process; replaces NeuS_Trainer.compute_loss, NeuS_Trainer.py:129-171, and its autograd graph):
+ *   cnr_loss_forward : cnr_loss_sums (delta_per_ray == 0: delta_relight is [R][M][3]; != 0: the per-ray sums [R]) + cnr_loss_combine; the block that
+ *                      finishes last folds the partial sums in the fixed order of cnr_loss_sums -- bitwise the same sums and scalars.  The library
+ *                      keeps the completion counter: at most one cnr_loss_forward in flight per device.
+ *   cnr_loss_backward: cnr_loss_coef (also written to coef[4] for the caller: coef[2] * mask is d / d delta_relight, coef[3] is d / d gradient_error)
+ *                      + cnr_loss_grads for d_color_fine / d_weight_sum. */
+int cnr_loss_forward(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight /* or NULL */, int32_t delta_per_ray,
+                     const float* rgb_gt, const float* mask /* or NULL */, const float* gradient_error /* device [1] */, int64_t n_rays, int32_t n_samples,
+                     float n_rays_global, int32_t use_mask, int32_t use_relight, float* sums /* device [4] */, float* out /* device [6] */,
+                     void* scratch, size_t scratch_bytes, void* stream);
+int cnr_loss_backward(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* rgb_gt, const float* mask /* or NULL */,
+                      int64_t n_rays, int32_t n_samples, const float* g_loss /* device [1] */, const float* mean_rel /* device [1] */, float n_rays_global,
+                      int32_t use_mask, int32_t use_relight, float* coef /* device [4] */, float* d_color_fine, float* d_weight_sum /* or NULL */, void* stream);
 
 /* ---- ray generation for the selected pixels, the producer right in front of the path (NeuS_Trainer.render, NeuS_Trainer.py:104-120):
  * get_rays_multicam / get_rays_at (lib/models/tools/ray_utils.py:16-119) evaluated ONLY for the chosen pixels (the reference builds the

@@ -155,3 +155,52 @@ def test_loss_only_training_outputs_emu():
 @pytest.mark.parametrize("name", ["tiny_sharp", "dtu_sharp"])
 def test_loss_only_training_outputs_hip(name):
     _loss_only(None, "cuda:0", name)
+
+
+def _one_launch_forms(library, device):
+    """cnr_loss_forward / cnr_loss_backward (one launch each) against the entry points they replace (cnr_loss_sums[_ray] + cnr_loss_combine,
+    cnr_loss_coef + cnr_loss_grads) on the same inputs: the same partial sums folded in the same order and the same scalar arithmetic, so every
+    output must agree to the bit -- for both forms of the relight term, with and without a mask, several times in a row (the completion
+    counter of the forward launch has to be back at zero after each call)."""
+    import ctypes as C
+    import color_neus_amd as cn
+    from color_neus_amd._lib import CnrLossConfig
+    lib = cn.load_library(library)
+    L = lib.lib
+    g = torch.Generator().manual_seed(7)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else C.c_void_p(0)
+    for R, M, use_mask, per_ray in ((4096, 128, True, False), (1000, 16, True, True), (53, 12, False, False), (1, 8, True, True)):
+        color = torch.rand(R, 3, generator=g).to(device); gt = torch.rand(R, 3, generator=g).to(device)
+        wsum = torch.rand(R, generator=g).to(device); mask = (torch.rand(R, generator=g) > 0.3).float().to(device) if use_mask else None
+        drel = (torch.randn(R, generator=g) if per_ray else torch.randn(R, M, 3, generator=g) * 0.1).to(device)
+        gerr = torch.rand(1, generator=g).to(device); gl = torch.tensor([0.7], device=device)
+        cfg = CnrLossConfig(1.0, 0.1, 0.1, 1.0, 0, 1)
+        nb = L.cnr_loss_scratch_bytes(R)
+        for rep in range(3):
+            scr = torch.empty(nb, dtype=torch.uint8, device=device)
+            s1, o1 = torch.empty(4, device=device), torch.empty(6, device=device)
+            fn = L.cnr_loss_sums_ray if per_ray else L.cnr_loss_sums
+            lib.check(fn(C.byref(cfg), p(color), p(wsum), p(drel), p(gt), p(mask), R, M, p(s1), p(scr), nb, st), "sums")
+            lib.check(L.cnr_loss_combine(C.byref(cfg), p(s1), p(gerr), float(R), M, int(use_mask), 1, p(o1), st), "combine")
+            s2, o2 = torch.empty(4, device=device), torch.empty(6, device=device)
+            lib.check(L.cnr_loss_forward(C.byref(cfg), p(color), p(wsum), p(drel), int(per_ray), p(gt), p(mask), p(gerr), R, M, float(R), int(use_mask), 1,
+                                         p(s2), p(o2), p(scr), nb, st), "forward")
+            assert torch.equal(s1, s2) and torch.equal(o1, o2), (R, M, rep, s1, s2, o1, o2)
+            c1, dc1, dw1 = torch.empty(4, device=device), torch.empty(R, 3, device=device), torch.empty(R, device=device)
+            lib.check(L.cnr_loss_coef(C.byref(cfg), p(gl), p(o1[5:6].contiguous()), float(R), M, int(use_mask), 1, p(c1), st), "coef")
+            lib.check(L.cnr_loss_grads(C.byref(cfg), p(color), p(wsum), p(gt), p(mask), R, M, p(c1), p(dc1), p(dw1), p(None), st), "grads")
+            c2, dc2, dw2 = torch.empty(4, device=device), torch.empty(R, 3, device=device), torch.empty(R, device=device)
+            lib.check(L.cnr_loss_backward(C.byref(cfg), p(color), p(wsum), p(gt), p(mask), R, M, p(gl), p(o2[5:6].contiguous()), float(R), int(use_mask), 1,
+                                          p(c2), p(dc2), p(dw2), st), "backward")
+            assert torch.equal(c1, c2) and torch.equal(dc1, dc2) and torch.equal(dw1, dw2), (R, M, rep)
+
+
+@pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
+def test_one_launch_loss_forms_emu():
+    _one_launch_forms(N.EMU_LIB, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_one_launch_loss_forms_hip():
+    _one_launch_forms(None, torch.device("cuda:0"))
