@@ -366,12 +366,17 @@ static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   b.ebars = a.f((size_t)P * kEmb);
   b.pbar = a.f((size_t)P * 4);
   b.dzparts = m.I == 0 ? a.f((size_t)P * 2) : nullptr;
-  b.D.resize(m.NR);
-  for (int i = 0; i < m.NR; ++i) b.D[i] = a.f((size_t)P * m.Hr);
-  b.DC.resize(m.NC - 1);
-  for (int l = 0; l + 1 < m.NC; ++l) b.DC[l] = a.f((size_t)P * m.Hc);
   b.VB.resize(m.L); b.Z2.resize(m.L);
   for (int l = 0; l < m.L; ++l) { b.VB[l] = a.f((size_t)P * m.Hs); b.Z2[l] = a.f((size_t)P * m.Hs); }
+  // The cotangents of the relight / colour hidden layers (steps 2 and 3 of the backward pass) are dead before the second-order sweep (step 5)
+  // writes the first VB / Z2 buffer, and everything runs on one stream: they share that memory where the widths agree (7 KB per point less)
+  b.D.resize(m.NR);
+  b.DC.resize(m.NC > 0 ? m.NC - 1 : 0);
+  const int nshare = m.NR + (int)b.DC.size();
+  const bool share = (m.NR == 0 || m.Hr == m.Hs) && m.Hc == m.Hs && nshare <= 2 * m.L;
+  auto shared = [&](int k) { return (k & 1) ? b.Z2[k >> 1] : b.VB[k >> 1]; };
+  for (int i = 0; i < m.NR; ++i) b.D[i] = share ? shared(i) : a.f((size_t)P * m.Hr);
+  for (int l = 0; l + 1 < m.NC; ++l) b.DC[l] = share ? shared(m.NR + l) : a.f((size_t)P * m.Hc);
   long nch = P / 128;   // one workgroup per CU as soon as every chunk has a few 16-point slabs
   if (nch < 1) nch = 1;
   if (nch > 256) nch = 256;
