@@ -12,8 +12,10 @@
 // 2 x 32 columns; the f16 planes of W^T (48 rows) sit in LDS for the whole launch (K = 256: 16 k16 blocks x 3 MFMAs per tile and wave).
 // dW: wave w owns rows j in [32 w, 32 w + 32): A fragments are gathered from the X planes (two-byte reads), B fragments are 16-byte reads of
 // the transposed Y planes.  The planes carry ss[pt] sy[pt] X Y; every A element is multiplied by the exact power of two 2^(Gt - e[pt]) <= 1,
-// e = log2(ss sy), Gt = min of e over the tile (an f16 multiply: exact unless it underflows, where the term is < 2^-24 of the tile's largest),
-// so a tile's MFMAs form 2^Gt sum X Y; the tile result is folded into the fp32 totals with 2^-Gt.  Fixed order: bitwise deterministic.
+// e = log2(ss sy), Gt = min of e over the tile (an f16 multiply by a power of two down to the subnormal 2^-24: the product keeps the f16 subnormal
+// grid, i.e. an absolute error of 2^-25 per element like any other split operand), so a tile's MFMAs form 2^Gt sum X Y; the tile result is folded
+// into the fp32 totals with 2^-Gt.  Two staging register sets keep two tiles in flight; fixed order: bitwise deterministic.
+// The same kernel without the weight gradient (DX only, optionally with X = sp'(X) * Xb) ends the forward gradient chain.
 #include "cnr_gemm_ws.h"
 
 namespace cnr {
