@@ -148,14 +148,25 @@ __global__ __launch_bounds__(512) void head_bwd_kernel(const HeadBwd p, long pts
   const f4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 4; ++j) { acc[j] = z4; w[j] = (live && j < p.n) ? *reinterpret_cast<const f4*>(p.W + (long)j * p.ldw + k) : z4; }
+  // the rows of the next trip are requested before this trip's arithmetic and STORES: a load issued behind the stores would be waited for
+  // together with the wave's whole store queue (one in-order counter), and one workgroup per CU has nothing else to hide the latency with
+  f4 an[8], dn[8];
+  const int kl = live ? k : 0;
+  auto fetch = [&](long pt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      long q = pt + 8 * u < p1 ? pt + 8 * u : p1 - 1;
+      if (q < 0) q = 0;
+      an[u] = *reinterpret_cast<const f4*>(p.aux + q * p.ldaux + kl);   // (every lane loads from a clamped address; dead column groups are masked below)
+      dn[u] = *reinterpret_cast<const f4*>(p.dtop + q * p.ldt);     // (ldt is a multiple of 4; columns >= n are zero padding)
+    }
+  };
+  fetch(p0 + rl);
   for (long pt = p0 + rl; pt < p1; pt += 64) {
     f4 a[8], d[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long q = pt + 8 * u < p1 ? pt + 8 * u : p1 - 1;
-      a[u] = live ? *reinterpret_cast<const f4*>(p.aux + q * p.ldaux + k) : z4;
-      d[u] = *reinterpret_cast<const f4*>(p.dtop + q * p.ldt);     // (ldt is a multiple of 4; columns >= n are zero padding)
-    }
+    for (int u = 0; u < 8; ++u) { a[u] = live ? an[u] : z4; d[u] = dn[u]; }
+    fetch(pt + 64);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (pt + 8 * u < p1) {
@@ -220,15 +231,28 @@ __global__ __launch_bounds__(512) void strip_bwd_kernel(const StripBwd p, long p
 #pragma unroll
   for (int j = 0; j < NT; ++j) { acc[j] = z4; w[j] = j < p.nt ? *reinterpret_cast<const f4*>(p.Wt + (long)(256 + j) * p.ldwt + k) : z4; }
   const int yu = lane / NT, yj = lane % NT;       // the (point, column) whose y value this lane fetches and whose dot product it ends up with
+  // the rows of the next trip are requested before this trip's arithmetic (one workgroup of 8 waves per CU: nothing else hides the latency)
+  f4 dn[PTS];
+  float yn = 0.0f;
+  auto fetch = [&](long pt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+      long q = pt + u < p1 ? pt + u : p1 - 1;
+      if (q < p0) q = p0 < p.P ? p0 : p.P - 1;          // (an empty slot: never used)
+      dn[u] = *reinterpret_cast<const f4*>(p.dout + q * p.ldo + k);
+    }
+    long qy = pt + yu < p1 ? pt + yu : p1 - 1;
+    if (qy < 0) qy = 0;
+    yn = p.y[qy * p.ldy + (yj < p.nt ? yj : 0)];        // (every lane loads from a clamped address; masked below)
+  };
+  fetch(p0 + (long)wv * PTS);
   for (long pt = p0 + (long)wv * PTS; pt < p1; pt += 8 * PTS) {
     f4 d[PTS];
 #pragma unroll
-    for (int u = 0; u < PTS; ++u) {
-      const long q = pt + u < p1 ? pt + u : p1 - 1;
-      d[u] = *reinterpret_cast<const f4*>(p.dout + q * p.ldo + k);
-    }
+    for (int u = 0; u < PTS; ++u) d[u] = dn[u];
     const bool mine = pt + yu < p1 && yj < p.nt;
-    const float yl = mine ? p.y[(pt + yu) * p.ldy + yj] : 0.0f;
+    const float yl = mine ? yn : 0.0f;
+    fetch(pt + 8 * PTS);
     float v[64];
 #pragma unroll
     for (int u = 0; u < PTS; ++u) {
