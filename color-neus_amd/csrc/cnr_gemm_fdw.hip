@@ -113,6 +113,10 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
   float* out = f.partial + (long)range * f.Npad * f.ldk;
   const bool isP = wave < 4;
   const int nlast = n > 0 ? n - 1 : 0;
+  // f.rev: this launch walks every range downwards (the loop counter i maps to tile t0 + nlast - i): consecutive launches of a backward chain
+  // alternate, so a launch starts on the rows its producer wrote last (still in L2 / Infinity Cache).  Fixed per launch site: deterministic
+  const int rev = f.rev;
+#define FD_TILE(i_) (t0 + (rev ? nlast - (i_) : (i_)))
 
   if (isP) {
     // ================================================================ P waves
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     }
     // one tile: product, epilogue, Ep' tile; `ern` holds this tile's side inputs and receives those of tile i + ahead (clamped to the range)
     auto p_tile = [&](const int i, const int ab, EpiRaw4 (&ern)[4], const int ahead) {
-      const long t = t0 + i;
+      const long t = FD_TILE(i);
       const unsigned char* B = smem + ab * FD_ABUF;
       {
         const int* qi = info + ab * 4;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * FD_TLD + cl] = acc[r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      const long tn = t0 + (i + ahead < nlast ? i + ahead : nlast);
+      const long tn = FD_TILE(i + ahead < nlast ? i + ahead : nlast);
       unsigned char* Yb = smem + FD_OFF_Y + (i & 1) * FD_YBUF;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -222,8 +226,8 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     EpiRaw4 ernA[4], ernB[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      ernA[q] = fetch_side(t0 * FD_TP + (lane >> 3) + 8 * q, ecol);   // (a range past the end is clamped to tile 0 of the launch: loaded, never used)
-      if (DP) ernB[q] = fetch_side((t0 + (1 < nlast ? 1 : nlast)) * FD_TP + (lane >> 3) + 8 * q, ecol);
+      ernA[q] = fetch_side(FD_TILE(0) * FD_TP + (lane >> 3) + 8 * q, ecol);   // (a range past the end is clamped to tile 0 of the launch: loaded, never used)
+      if (DP) ernB[q] = fetch_side(FD_TILE(1 < nlast ? 1 : nlast) * FD_TP + (lane >> 3) + 8 * q, ecol);
     }
     cnr_lds_barrier();   // tile 0 staged
     int ab = 0;
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     const float ascale = g.A.scale;
 
     auto d_fetch = [&](int i, RawTile& rt) {
-      const long t = t0 + (i < nlast ? i : nlast);   // (clamped: the redundant request at the end of a range is never converted)
+      const long t = FD_TILE(i < nlast ? i : nlast);   // (clamped: the redundant request at the end of a range is never converted)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const long row = t * FD_TP + srow + 16 * p;
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         if ((dt & 15) == 0) {
           rs[row_l] = 1.0f / sc;
           rs[32 + row_l] = ssv;
-          if (g.rs_out && half == 0) g.rs_out[(t0 + i) * FD_TP + row_l] = ssv;
+          if (g.rs_out && half == 0) g.rs_out[FD_TILE(i) * FD_TP + row_l] = ssv;
         }
         const float se = rt.se[p];
         if (valid && se > 0.0f) {
@@ -483,6 +487,8 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     }
   }
 }
+
+#undef FD_TILE
 
 template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0, bool TAILF = false, bool SPLITF = false>
 static void launch_fdw_v(const LayerGemm& g, const DwFuse& f, cnr_stream s) {

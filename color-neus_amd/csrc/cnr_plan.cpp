@@ -911,10 +911,13 @@ static void dw_into_region(const Lin& q, DwGemm& g, const DwRegion& r, int slot0
 // layer launch + its weight-gradient pair (d.X[0] / d.Y[0]: the pair as a plain weight-gradient GEMM -- what the CPU emulation and the HIP
 // backend's unfused fallback run; se = row scales of the epilogue-side operand) into slots [slot0, slot0 + b.fslots) of a region
 static void fused_into_region(const Lin& q, const LayerGemm& g, DwGemm& d, const float* se, int transposed, const DwRegion& r, int slot0, Bwd& b,
-                              bool with_bias, cnr_stream s, int kmain = 0, const DwFuse* xrow = nullptr) {
+                              bool with_bias, cnr_stream s, int kmain = 0, const DwFuse* xrow = nullptr, int rev = 0) {
   with_bias = with_bias && slot0 == 0 && !transposed;
   DwFuse f;
   if (xrow) f = *xrow;   // (the extra-row request; everything else is set below)
+  static const bool no_rev = getenv("CNR_FDW_NOREV") != nullptr;   // tuning aid: every fused launch walks its ranges upwards
+  static const int rev_mode = getenv("CNR_FDW_REVMODE") ? atoi(getenv("CNR_FDW_REVMODE")) : 0;   // tuning aid: 1 = the opposite parities, 2 = every launch downwards
+  f.rev = no_rev ? 0 : (rev_mode == 1 ? !rev : (rev_mode == 2 ? 1 : rev));
   f.se = se; f.partial = r.part + (size_t)slot0 * q.npad * q.ldw; f.Npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? r.csum : nullptr;
   f.transposed = transposed; f.nslots = b.fslots;
   d.npairs = 1; d.P = g.P; d.N = q.n; d.K = kmain > 0 ? kmain : q.k_int; d.nchunk = b.fslots; d.chunk_pts = round_up((int)((g.P + b.fslots - 1) / b.fslots), 16);
@@ -1053,7 +1056,8 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       if (strips) sb = take_strips(q, g, d, r, b);
       const int kmain = strips ? 256 : 0;
       if (fdw && fdw_shape_ok(g) && x.rsR[i] && q.npad == 256 && q.ldw <= 320) {
-        fused_into_region(q, g, d, x.rsR[i], 0, r, 0, b, true, s, kmain);
+        // (walk direction: opposite to the launch that wrote this one's input -- the head kernel walks upwards, then the chain alternates)
+        fused_into_region(q, g, d, x.rsR[i], 0, r, 0, b, true, s, kmain, nullptr, ((m.NR - 1 - i) & 1));
         if (strips) be_strip_bwd(sb, s);
         finish_region(q, r, b.fslots, b.fslots, b, params, dP);
       } else {
@@ -1124,7 +1128,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     if (strips) sb = take_strips(q, g, d, r, b);
     const int kmain = strips ? 256 : 0;
     if (fdw && fdw_shape_ok(g) && x.rsC[l] && q.npad == 256 && q.ldw <= 320) {
-      fused_into_region(q, g, d, x.rsC[l], 0, r, 0, b, true, s, kmain);
+      fused_into_region(q, g, d, x.rsC[l], 0, r, 0, b, true, s, kmain, nullptr, ((m.NC - 1 - l) & 1));
       if (strips) be_strip_bwd(sb, s);
       finish_region(q, r, b.fslots, b.fslots, b, params, dP);
     } else {
@@ -1255,7 +1259,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       d.npairs = 1; d.P = P;
       grad_pair(l, d, 0);
       d.sy[0] = nullptr;   // (a fused launch does not need qbar_l's row scales; the unfused fallback then takes the split-bf16 tiles)
-      fused_into_region(q, g, d, x.rsX1[l], 1, sreg[l], value_slots(l), b, false, s, 0, (top_fused && l == m.L - 1) ? &xrow1 : nullptr);
+      fused_into_region(q, g, d, x.rsX1[l], 1, sreg[l], value_slots(l), b, false, s, 0, (top_fused && l == m.L - 1) ? &xrow1 : nullptr, l & 1);
     } else {
       g.rs_out = b.rsY1[l];
       be_layer_gemm(g, s);
@@ -1272,7 +1276,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       d.npairs = 1; d.P = P;
       value_pair(l, d);
       d.sx[0] = nullptr;
-      fused_into_region(q, g, d, x.rsY[l], 0, sreg[l], 0, b, true, s, 0, top ? &xrow2 : nullptr);
+      fused_into_region(q, g, d, x.rsY[l], 0, sreg[l], 0, b, true, s, 0, top ? &xrow2 : nullptr, ((m.L - l) & 1) ^ 1);
     } else {
       g.rs_out = b.rsX0[l];
       be_layer_gemm(g, s);

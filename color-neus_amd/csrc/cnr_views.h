@@ -436,6 +436,7 @@ struct DwFuse {
   float* colsum = nullptr;    // optional [nslots][Npad]: column sums of S (bias gradient); only with transposed == 0
   int transposed = 0;         // 0: dW[n = column of S][k = column of Ep] ; 1: dW[n = column of Ep][k = column of S]
   int nslots = 0;             // point ranges = partial-sum slots of this launch: a multiple of 8, <= kFdwSlots
+  int rev = 0;                // 1: every range is walked downwards (see cnr_gemm_fdw.hip); the separate-kernel fallback ignores it
   // One extra weight-gradient row formed from values the epilogue holds anyway: the sdf row (internal row 256) of the 257-wide top SDF layer.
   //   xrow_mode 1 (EK_SWEEP launch of the layer below):   xrow[range][c]  = xrow_scale * sum over the range's points of o2[pt][c]
   //   xrow_mode 2 (EK_VBACK launch with k_extra == 1):    xrow[range][c] += sum of A[pt][K] * Ep[pt][c];  xbias[range] = sum of A[pt][K]
