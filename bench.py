@@ -2,6 +2,7 @@
 """Benchmark of the Color-NeuS render hot path on MI355X.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N ...          starts the N ranks itself (a child torch.distributed.run, before any GPU call); same as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
     ... --scaling strong --rays-total 4096      BASELINE config C4: a fixed 4096-ray batch split over the N ranks (512 per GPU at N = 8)
 
@@ -80,10 +81,34 @@ def clip_per_parameter_(params, max_norm=1.0):
     torch._foreach_mul_(grads, coefs)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD `torch.distributed.run` (never an exec: this process
+    has made no GPU call, and stays that way), let the children inherit stdout / stderr (rank 0 prints the JSON line) and exit with
+    their status.  Replaces the reference's single-GPU assert (train.py:111) with a launcher that cannot run as fewer ranks than asked."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:   # a record must never claim a GPU count it did not run on
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus (or plainly as "
+                         "`python bench.py --gpus N`, which starts the N ranks itself)" % (args.gpus, world))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # CNR_BENCH_EMU_LIB=<tests/_build/libcolorneus_emu.so>: TEST INFRASTRUCTURE ONLY (tests/test_bench_harness.py).  The harness -- rank set-up, ray
     # sharding, collectives, the JSON line -- then runs on CPU tensors with the CPU emulation of the kernel layer and gloo, so that the code the
@@ -98,6 +123,8 @@ def main():
         # CNR_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box with fewer GPUs than ranks (ranks then share
         # devices, collectives go through the host); the measured configuration is always one rank per GPU over RCCL ("nccl")
         backend = os.environ.get("CNR_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s): one rank per GPU" % (world, torch.cuda.device_count()))
         dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
         torch.cuda.set_device(dev_index)
         dev = torch.device("cuda", dev_index)

@@ -24,10 +24,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, rays_total, extra=()):
-    env = dict(os.environ, CNR_BENCH_EMU_LIB=N.EMU_LIB, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+def _run(world, rays_total, extra=(), launcher=True):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(CNR_BENCH_EMU_LIB=N.EMU_LIB, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
     args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--rays-total", str(rays_total), *extra]
-    if world == 1:
+    if world == 1 or not launcher:     # plain `python bench.py --gpus N`: bench.py starts its N ranks itself
         cmd = [sys.executable] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
@@ -53,3 +54,23 @@ def test_bench_two_ranks_strong_scaling_line_matches_single_process():
     # backward and the gradients after it -- so after the same 3 optimiser steps (1 warm-up + 2 timed) the reported loss of the last step
     # equals the single-process one up to the summation order of the reductions
     assert abs(one["config"]["final_loss"] - two["config"]["final_loss"]) <= 2e-5 * abs(one["config"]["final_loss"]), (one["config"]["final_loss"], two["config"]["final_loss"])
+
+
+def test_plain_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must run TWO ranks (it used to run one and print n_gpus 1)."""
+    d = _run(2, 16, launcher=False)
+    assert d["n_gpus"] == 2 and d["config"]["rays_per_step_per_gpu"] == 8 and d["config"]["parallelism"] == "ray-sharded dp2"
+    assert "allreduce" in d["config"]["step"]
+
+
+def test_world_size_mismatch_fails():
+    """--gpus that disagrees with the launcher's WORLD_SIZE is an error, never a record with the wrong GPU count."""
+    env = dict(os.environ, CNR_BENCH_EMU_LIB=N.EMU_LIB, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
