@@ -96,7 +96,7 @@ def c_config(cfg) -> CnrConfig:
 EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_count", "cnr_param_info", "cnr_ctx_bytes",
            "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_sdf_grid_slab_scratch_bytes", "cnr_sdf_grid_slab", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
-           "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_sums_ray", "cnr_loss_grads", "cnr_loss_combine", "cnr_loss_coef", "cnr_loss_forward", "cnr_loss_backward",
+           "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_sums_ray", "cnr_loss_grads", "cnr_loss_combine", "cnr_loss_coef", "cnr_loss_forward", "cnr_loss_backward", "cnr_loss_shard_stats", "cnr_loss_shard_combine",
            "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward", "cnr_sample_z", "cnr_mc_scratch_bytes", "cnr_mc_count", "cnr_mc_emit",
            "cnr_linear_scratch_bytes", "cnr_linear_forward", "cnr_linear_backward",
            "cnr_nerf_param_count", "cnr_nerf_param_info", "cnr_outside_z", "cnr_outside_z_backward", "cnr_background_ctx_bytes",
@@ -148,8 +148,10 @@ class RenderLibrary:
         L.cnr_loss_coef.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, C.c_float, C.c_int32, C.c_int32, C.c_int32, _FP, _FP]
         L.cnr_loss_forward.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, C.c_int32, _FP, _FP, _FP, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                        _FP, _FP, _FP, C.c_size_t, _FP]
-        L.cnr_loss_backward.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_float, C.c_int32, C.c_int32,
-                                        _FP, _FP, _FP, _FP]
+        L.cnr_loss_backward.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, _FP, C.c_float, C.c_int32, C.c_int32,
+                                        _FP, _FP, _FP, _FP, _FP]
+        L.cnr_loss_shard_stats.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, C.c_int32, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_size_t, _FP]
+        L.cnr_loss_shard_combine.argtypes = [C.POINTER(CnrLossConfig), _FP, C.c_float, C.c_int32, C.c_int32, C.c_int32, _FP, _FP]
         L.cnr_sample_pdf.argtypes = [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, _FP]
         L.cnr_up_sample.argtypes = [_FP, _FP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_float, _FP, _FP]
         L.cnr_clip_adam_step.argtypes = [C.POINTER(CnrAdamConfig), C.c_int32, C.POINTER(C.c_int64), C.POINTER(_FP), C.POINTER(_FP), _FP, _FP, _FP,
@@ -184,7 +186,7 @@ class RenderLibrary:
         L.cnr_composite_background_forward.argtypes = [C.POINTER(CnrBgCompositeIn), C.POINTER(CnrOutputs), _FP, C.c_size_t, _FP]
         L.cnr_composite_background_backward.argtypes = [C.POINTER(CnrBgCompositeIn), C.POINTER(CnrOutputs), C.POINTER(CnrOutGrads),
                                                         C.POINTER(CnrBgCompositeGrads), _FP, C.c_size_t, _FP]
-        if L.cnr_abi_version() != 6:
+        if L.cnr_abi_version() != 7:
             raise RuntimeError("colorneus library ABI mismatch")
 
     @property

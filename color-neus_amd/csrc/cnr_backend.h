@@ -362,8 +362,13 @@ struct LossScalars {   // see cnr_loss_combine / cnr_loss_coef in the ABI header
 void be_loss_combine(const LossScalars& c, const float* sums, const float* gerr, float* out6, cnr_stream s);
 void be_loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, cnr_stream s);
 // the forward side (partial sums, their fold, the scalar tail) and the backward side (coefficients + element-wise gradients) as ONE launch each
-void be_loss_forward(const LossArgs& a, float* partial, const LossScalars& c, const float* gerr, float* sums, float* out6, cnr_stream s);
-void be_loss_backward(const LossArgs& a, const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, float* d_color, float* d_wsum, cnr_stream s);
+// (ticket: a zero-initialised 4-byte completion counter in the caller's scratch, left zero)
+void be_loss_forward(const LossArgs& a, float* partial, unsigned* ticket, const LossScalars& c, const float* gerr, float* sums, float* out6, cnr_stream s);
+void be_loss_backward(const LossArgs& a, const LossScalars& c, const float* g_loss, const float* mean_rel, const float* eik_factor /* or null */, float* coef4,
+                      float* d_color, float* d_wsum, float* d_drel_ray /* [R] or null */, cnr_stream s);
+// ray-sharded runs: this rank's statistics for the one all-reduce of the objective (one launch), and the scalar tail on the reduced statistics
+void be_loss_shard_stats(const LossArgs& a, float* partial, unsigned* ticket, const float* eik_sums /* [2] */, float* stats8, cnr_stream s);
+void be_loss_shard_combine(const LossScalars& c, const float* stats8, float* out8, cnr_stream s);
 // per-parameter gradient clip + Adam over up to kAdamBatch tensors per launch (clip_gradient + torch.optim.Adam, net_utils.py:174-184, :88)
 constexpr int kAdamBatch = 64;
 constexpr int kAdamChunk = 4096;   // elements per workgroup: a tensor is cut into ceil(n / kAdamChunk) chunks

@@ -161,9 +161,18 @@ CNR_HD void body_pbar_finish(const PbarFinish& p, long pt) {
 }
 
 // one ray of GenRays
+// An index outside [0, n_cams * H * W) (only a caller-supplied list can hold one) reads nothing: every output of that ray is NaN -- which
+// the loss then shows -- where the reference's torch indexing would raise; the backward kernel gives such a ray no contribution.
 CNR_HD void body_gen_rays(const GenRays& p, long i) {
   const long hw = (long)p.H * p.W;
   const long idx = p.pix_idx ? p.pix_idx[i] : i;
+  if (idx < 0 || idx >= hw * p.n_cams) {
+    const float nan_ = __builtin_nanf("");
+    for (int k = 0; k < 3; ++k) { p.rays_o[i * 3 + k] = nan_; p.rays_d[i * 3 + k] = nan_; if (p.rgb) p.rgb[i * 3 + k] = nan_; }
+    if (p.mask_sel) p.mask_sel[i] = nan_;
+    if (p.near_ && p.far_) { p.near_[i] = nan_; p.far_[i] = nan_; }
+    return;
+  }
   const int cam = (int)(idx / hw);
   const long pix = idx - (long)cam * hw;
   const int py = (int)(pix / p.W), px = (int)(pix - (long)py * p.W);
@@ -190,6 +199,11 @@ CNR_HD void body_gen_rays_bwd1(const GenRaysBwd& q, long i, int* cam_out, float 
   const GenRays& p = q.f;
   const long hw = (long)p.H * p.W;
   const long idx = p.pix_idx ? p.pix_idx[i] : i;
+  if (idx < 0 || idx >= hw * p.n_cams) {   // (see body_gen_rays: no camera owns this ray)
+    for (int k = 0; k < 14; ++k) out[k] = 0.0f;
+    *cam_out = -1;
+    return;
+  }
   const int cam = (int)(idx / hw);
   const long pix = idx - (long)cam * hw;
   const int py = (int)(pix / p.W), px = (int)(pix - (long)py * p.W);

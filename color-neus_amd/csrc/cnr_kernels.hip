@@ -841,10 +841,12 @@ void be_loss_sums(const LossArgs& a, float* partial, float* sums, cnr_stream s) 
 }
 // The whole forward side in ONE launch: every block writes its partial sums, takes a ticket, and the block that draws the last one folds all
 // partials in the fixed order of loss_fold_kernel and runs the scalar tail (loss_combine).  Which block is last does not matter: bitwise the same
-// sums as the two-launch form.  The ticket counter lives in the library (zero when no launch is in flight: the last block resets it), so two
-// loss evaluations must not run concurrently on one device.
-__device__ unsigned g_loss_ticket = 0;
-__global__ __launch_bounds__(256) void loss_forward_kernel(const LossArgs a, float* partial, const LossScalars c, const float* gerr, float* sums, float* out6) {
+// sums as the two-launch form.  The ticket counter is a 4-byte slot of the CALLER's scratch (zero before the first use of the buffer; the last
+// block leaves it zero): calls on one stream may share a buffer, calls that may overlap (other streams, other threads) bring their own.
+// shard != 0 (ray-sharded runs): no scalar tail; the last block writes the rank's statistics for the all-reduce instead:
+// stats[0..2] = the three sums, stats[3..4] = the rank's eikonal sums, stats[5] = a second copy of stats[4] that the all-reduce leaves alone.
+__global__ __launch_bounds__(256) void loss_forward_kernel(const LossArgs a, float* partial, unsigned* ticket, const LossScalars c, const float* gerr, float* sums,
+                                                           float* out6, const int shard, const float* eik_sums) {
   __shared__ float red[4];
   __shared__ int is_last;
   const int tid = threadIdx.x, nb = gridDim.x, b = blockIdx.x;
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(256) void loss_forward_kernel(const LossArgs a, flo
   if (tid == 0) {
     partial[b * 4 + 0] = s_rgb; partial[b * 4 + 1] = s_bce; partial[b * 4 + 2] = s_rel; partial[b * 4 + 3] = 0.f;
     __threadfence();                                               // the partials are visible device-wide before the ticket is drawn
-    const unsigned t = atomicAdd(&g_loss_ticket, 1u);
+    const unsigned t = atomicAdd(ticket, 1u);
     is_last = t == (unsigned)nb - 1u;
   }
   __syncthreads();
@@ -882,34 +884,53 @@ __global__ __launch_bounds__(256) void loss_forward_kernel(const LossArgs a, flo
   for (int j = 0; j < 3; ++j) { const float sj = block_sum_256(v[j], red); if (tid == 0) tot[j] = sj; }
   if (tid == 0) {
     tot[3] = 0.f;
-    sums[0] = tot[0]; sums[1] = tot[1]; sums[2] = tot[2]; sums[3] = 0.f;
-    loss_combine(c, tot, gerr, out6);
-    g_loss_ticket = 0;
+    if (shard) {
+      const float num = eik_sums[0], den = eik_sums[1];
+      sums[0] = tot[0]; sums[1] = tot[1]; sums[2] = tot[2]; sums[3] = num; sums[4] = den; sums[5] = den; sums[6] = 0.f; sums[7] = 0.f;
+    } else {
+      sums[0] = tot[0]; sums[1] = tot[1]; sums[2] = tot[2]; sums[3] = 0.f;
+      loss_combine(c, tot, gerr, out6);
+    }
+    *ticket = 0;
   }
 }
-void be_loss_forward(const LossArgs& a, float* partial, const LossScalars& c, const float* gerr, float* sums, float* out6, cnr_stream s) {
+void be_loss_forward(const LossArgs& a, float* partial, unsigned* ticket, const LossScalars& c, const float* gerr, float* sums, float* out6, cnr_stream s) {
   TimingScope ts_("loss_forward", 2, 0, a.R, 0, 0, 0, s);
-  hipLaunchKernelGGL(loss_forward_kernel, dim3(kLossBlocks), dim3(256), 0, s, a, partial, c, gerr, sums, out6);
+  hipLaunchKernelGGL(loss_forward_kernel, dim3(kLossBlocks), dim3(256), 0, s, a, partial, ticket, c, gerr, sums, out6, 0, (const float*)nullptr);
   CNR_LAUNCH_CHECK("loss_forward");
 }
+void be_loss_shard_stats(const LossArgs& a, float* partial, unsigned* ticket, const float* eik_sums, float* stats8, cnr_stream s) {
+  TimingScope ts_("loss_shard_stats", 2, 0, a.R, 0, 0, 0, s);
+  hipLaunchKernelGGL(loss_forward_kernel, dim3(kLossBlocks), dim3(256), 0, s, a, partial, ticket, LossScalars{}, (const float*)nullptr, stats8, (float*)nullptr, 1, eik_sums);
+  CNR_LAUNCH_CHECK("loss_shard_stats");
+}
+__global__ void loss_shard_combine_kernel(const LossScalars c, const float* stats, float* out8) { if (threadIdx.x == 0 && blockIdx.x == 0) loss_shard_combine(c, stats, out8); }
+void be_loss_shard_combine(const LossScalars& c, const float* stats8, float* out8, cnr_stream s) {
+  TimingScope ts_("loss_shard_combine", 2, 0, 1, 0, 0, 0, s);
+  hipLaunchKernelGGL(loss_shard_combine_kernel, dim3(1), dim3(64), 0, s, c, stats8, out8);
+  CNR_LAUNCH_CHECK("loss_shard_combine");
+}
 // ... and the backward side in one: every thread forms the coefficients from the upstream gradient itself (loss_coef: a dozen flops)
-__global__ __launch_bounds__(256) void loss_backward_kernel(const LossArgs a, const LossScalars c, const float* g_loss, const float* mean_rel, float* coef_out,
-                                                            float* d_color, float* d_wsum) {
+__global__ __launch_bounds__(256) void loss_backward_kernel(const LossArgs a, const LossScalars c, const float* g_loss, const float* mean_rel, const float* eik_factor,
+                                                            float* coef_out, float* d_color, float* d_wsum, float* d_drel_ray) {
   float coef[4];
-  loss_coef(c, g_loss, c.use_relight ? mean_rel : g_loss, coef);
+  loss_coef(c, g_loss, c.use_relight ? mean_rel : g_loss, eik_factor, coef);
   if (blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = coef[0]; coef_out[1] = coef[1]; coef_out[2] = coef[2]; coef_out[3] = coef[3]; }
   const long n_rgb = a.R * 3;
   const long stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_rgb; i += stride) d_color[i] = coef[0] * loss_rgb_grad(a.color[i], a.gt[i], a.rgb_l1);
   if (d_wsum)
     for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < a.R; r += stride) d_wsum[r] = a.mask ? coef[1] * loss_bce_grad(a.wsum[r], a.mask[r]) : 0.0f;
+  if (d_drel_ray)   // d mean(delta_relight * mask)^2 / d delta_relight[r][j][c]: one value per ray
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < a.R; r += stride) d_drel_ray[r] = (a.include_mask && a.mask) ? coef[2] * a.mask[r] : coef[2];
 }
-void be_loss_backward(const LossArgs& a, const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, float* d_color, float* d_wsum, cnr_stream s) {
+void be_loss_backward(const LossArgs& a, const LossScalars& c, const float* g_loss, const float* mean_rel, const float* eik_factor, float* coef4, float* d_color,
+                      float* d_wsum, float* d_drel_ray, cnr_stream s) {
   TimingScope ts_("loss_backward", 2, 0, a.R, 0, 0, 0, s);
   long blocks = (a.R * 3 + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(loss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, c, g_loss, mean_rel, coef4, d_color, d_wsum);
+  hipLaunchKernelGGL(loss_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, c, g_loss, mean_rel, eik_factor, coef4, d_color, d_wsum, d_drel_ray);
   CNR_LAUNCH_CHECK("loss_backward");
 }
 __global__ __launch_bounds__(256) void loss_grads_kernel(const LossArgs a, const float* coef, float* d_color, float* d_wsum, float* d_drel) {
@@ -923,7 +944,7 @@ __global__ __launch_bounds__(256) void loss_grads_kernel(const LossArgs a, const
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_rel; i += stride) d_drel[i] = c_rel * ((a.include_mask && a.mask) ? a.mask[i / per_ray] : 1.0f);
 }
 __global__ void loss_combine_kernel(const LossScalars c, const float* sums, const float* gerr, float* out) { if (threadIdx.x == 0 && blockIdx.x == 0) loss_combine(c, sums, gerr, out); }
-__global__ void loss_coef_kernel(const LossScalars c, const float* g_loss, const float* mean_rel, float* coef) { if (threadIdx.x == 0 && blockIdx.x == 0) loss_coef(c, g_loss, mean_rel, coef); }
+__global__ void loss_coef_kernel(const LossScalars c, const float* g_loss, const float* mean_rel, float* coef) { if (threadIdx.x == 0 && blockIdx.x == 0) loss_coef(c, g_loss, mean_rel, nullptr, coef); }
 void be_loss_combine(const LossScalars& c, const float* sums, const float* gerr, float* out6, cnr_stream s) {
   hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, s, c, sums, gerr, out6);
   CNR_LAUNCH_CHECK("loss_combine");

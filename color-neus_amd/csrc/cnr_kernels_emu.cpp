@@ -38,15 +38,25 @@ void be_loss_sums(const LossArgs& a, float* partial, float* sums, cnr_stream) {
   sums[0] = (float)s_rgb; sums[1] = (float)s_bce; sums[2] = (float)s_rel; sums[3] = 0.f;
 }
 void be_loss_combine(const LossScalars& c, const float* sums, const float* gerr, float* out6, cnr_stream) { loss_combine(c, sums, gerr, out6); }
-void be_loss_forward(const LossArgs& a, float* partial, const LossScalars& c, const float* gerr, float* sums, float* out6, cnr_stream s) {
+void be_loss_forward(const LossArgs& a, float* partial, unsigned* ticket, const LossScalars& c, const float* gerr, float* sums, float* out6, cnr_stream s) {
+  (void)ticket;
   be_loss_sums(a, partial, sums, s);
   loss_combine(c, sums, gerr, out6);
 }
-void be_loss_backward(const LossArgs& a, const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, float* d_color, float* d_wsum, cnr_stream s) {
-  loss_coef(c, g_loss, c.use_relight ? mean_rel : g_loss, coef4);
-  be_loss_grads(a, coef4, d_color, d_wsum, nullptr, s);
+void be_loss_shard_stats(const LossArgs& a, float* partial, unsigned* ticket, const float* eik_sums, float* stats8, cnr_stream s) {
+  (void)ticket;
+  float sums[4];
+  be_loss_sums(a, partial, sums, s);
+  stats8[0] = sums[0]; stats8[1] = sums[1]; stats8[2] = sums[2]; stats8[3] = eik_sums[0]; stats8[4] = eik_sums[1]; stats8[5] = eik_sums[1]; stats8[6] = stats8[7] = 0.0f;
 }
-void be_loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, cnr_stream) { loss_coef(c, g_loss, mean_rel, coef4); }
+void be_loss_shard_combine(const LossScalars& c, const float* stats8, float* out8, cnr_stream) { loss_shard_combine(c, stats8, out8); }
+void be_loss_backward(const LossArgs& a, const LossScalars& c, const float* g_loss, const float* mean_rel, const float* eik_factor, float* coef4, float* d_color,
+                      float* d_wsum, float* d_drel_ray, cnr_stream s) {
+  loss_coef(c, g_loss, c.use_relight ? mean_rel : g_loss, eik_factor, coef4);
+  be_loss_grads(a, coef4, d_color, d_wsum, nullptr, s);
+  if (d_drel_ray) for (long r = 0; r < a.R; ++r) d_drel_ray[r] = (a.include_mask && a.mask) ? coef4[2] * a.mask[r] : coef4[2];
+}
+void be_loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef4, cnr_stream) { loss_coef(c, g_loss, mean_rel, nullptr, coef4); }
 void be_loss_grads(const LossArgs& a, const float* coef, float* d_color, float* d_wsum, float* d_drel, cnr_stream) {
   for (long i = 0; i < a.R * 3; ++i) d_color[i] = coef[0] * loss_rgb_grad(a.color[i], a.gt[i], a.rgb_l1);
   if (d_wsum) for (long r = 0; r < a.R; ++r) d_wsum[r] = a.mask ? coef[1] * loss_bce_grad(a.wsum[r], a.mask[r]) : 0.0f;

@@ -27,12 +27,22 @@ CNR_HD void loss_combine(const LossScalars& c, const float* sums, const float* g
   if (c.use_relight) { mean_rel = sums[2] / c.den_rel; rel = mean_rel * mean_rel; loss = loss + c.lr * rel; }
   out[0] = loss; out[1] = rgb; out[2] = eik; out[3] = mask; out[4] = rel; out[5] = mean_rel;
 }
-CNR_HD void loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, float* coef) {
+// ray-sharded runs: the scalar tail on the all-reduced statistics (stats[0..4] summed over the ranks, stats[5] = this rank's own sum of the relax mask).
+// The eikonal term is the ratio of the GLOBAL sums (Color_NeuS.py:122-123); out[6] = d (global ratio) / d (this rank's gradient_error output)
+// = (den_local + 1e-5) / (den_global + 1e-5), because the rank's output is num_local / (den_local + 1e-5).
+CNR_HD void loss_shard_combine(const LossScalars& c, const float* stats, float* out) {
+  const float den = stats[4] + 1e-5f;
+  const float eik = stats[3] / den;
+  loss_combine(c, stats, &eik, out);
+  out[6] = (stats[5] + 1e-5f) / den;
+  out[7] = 0.0f;
+}
+CNR_HD void loss_coef(const LossScalars& c, const float* g_loss, const float* mean_rel, const float* eik_factor /* or null */, float* coef) {
   const float g = g_loss[0];
   coef[0] = g * c.c_rgb;
   coef[1] = c.use_mask ? g * c.c_bce : 0.0f;
   coef[2] = c.use_relight ? g * c.c_rel * mean_rel[0] : 0.0f;
-  coef[3] = g * c.le;
+  coef[3] = eik_factor ? g * c.le * eik_factor[0] : g * c.le;
 }
 
 }  // namespace cnr

@@ -1786,7 +1786,9 @@ int cnr_render_backward(const cnr_config* cfg, const float* const* params, const
 
 void cnr_timing_enable(int on) { be_timing_enable(on); }
 
-size_t cnr_loss_scratch_bytes(int64_t n_rays) { (void)n_rays; return (size_t)kLossBlocks * 4 * sizeof(float); }
+// [kLossBlocks][4] partial sums + 16 bytes whose first 4 are the completion counter of the one-launch forms
+constexpr size_t kLossTicketOff = (size_t)kLossBlocks * 4 * sizeof(float);
+size_t cnr_loss_scratch_bytes(int64_t n_rays) { (void)n_rays; return kLossTicketOff + 16; }
 
 static int loss_args(const cnr_loss_config* cfg, const float* color, const float* wsum, const float* drel, const float* gt, const float* mask,
                      int64_t n_rays, int32_t n_samples, LossArgs& a) {
@@ -1874,20 +1876,43 @@ int cnr_loss_forward(const cnr_loss_config* cfg, const float* color_fine, const 
   if (mask && !weight_sum) return fail("weight_sum is required with a mask");
   if (scratch_bytes < cnr_loss_scratch_bytes(n_rays)) return fail("loss scratch too small");
   a.drel_per_ray = delta_per_ray != 0;
-  be_loss_forward(a, static_cast<float*>(scratch), c, gradient_error, sums, out, (cnr_stream)stream);
+  be_loss_forward(a, static_cast<float*>(scratch), reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + kLossTicketOff), c, gradient_error, sums, out, (cnr_stream)stream);
   return check_backend("loss_forward");
 }
 
+int cnr_loss_shard_stats(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight, int32_t delta_per_ray,
+                         const float* rgb_gt, const float* mask, const float* eik_sums, int64_t n_rays, int32_t n_samples, float* stats, void* scratch,
+                         size_t scratch_bytes, void* stream) {
+  LossArgs a;
+  if (loss_args(cfg, color_fine, weight_sum, delta_relight, rgb_gt, mask, n_rays, n_samples, a)) return -1;
+  if (!stats || !scratch || !eik_sums) return fail("null argument");
+  if (mask && !weight_sum) return fail("weight_sum is required with a mask");
+  if (scratch_bytes < cnr_loss_scratch_bytes(n_rays)) return fail("loss scratch too small");
+  a.drel_per_ray = delta_per_ray != 0;
+  be_loss_shard_stats(a, static_cast<float*>(scratch), reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + kLossTicketOff), eik_sums, stats, (cnr_stream)stream);
+  return check_backend("loss_shard_stats");
+}
+
+int cnr_loss_shard_combine(const cnr_loss_config* cfg, const float* stats, float n_rays_global, int32_t n_samples, int32_t use_mask, int32_t use_relight,
+                           float* out, void* stream) {
+  LossScalars c;
+  if (loss_scalars(cfg, n_rays_global, n_samples, use_mask, use_relight, c)) return -1;
+  if (!stats || !out) return fail("null argument");
+  be_loss_shard_combine(c, stats, out, (cnr_stream)stream);
+  return check_backend("loss_shard_combine");
+}
+
 int cnr_loss_backward(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* rgb_gt, const float* mask,
-                      int64_t n_rays, int32_t n_samples, const float* g_loss, const float* mean_rel, float n_rays_global, int32_t use_mask,
-                      int32_t use_relight, float* coef, float* d_color_fine, float* d_weight_sum, void* stream) {
+                      int64_t n_rays, int32_t n_samples, const float* g_loss, const float* mean_rel, const float* eik_factor, float n_rays_global,
+                      int32_t use_mask, int32_t use_relight, float* coef, float* d_color_fine, float* d_weight_sum, float* d_delta_relight_per_ray,
+                      void* stream) {
   LossArgs a;
   LossScalars c;
   if (loss_args(cfg, color_fine, weight_sum, nullptr, rgb_gt, mask, n_rays, n_samples, a)) return -1;
   if (loss_scalars(cfg, n_rays_global, n_samples, use_mask, use_relight, c)) return -1;
   if (!g_loss || !coef || !d_color_fine || (use_relight && !mean_rel)) return fail("null argument");
   if (d_weight_sum && mask && !weight_sum) return fail("weight_sum is required with a mask");
-  be_loss_backward(a, c, g_loss, mean_rel, coef, d_color_fine, d_weight_sum, (cnr_stream)stream);
+  be_loss_backward(a, c, g_loss, mean_rel, eik_factor, coef, d_color_fine, d_weight_sum, d_delta_relight_per_ray, (cnr_stream)stream);
   return check_backend("loss_backward");
 }
 

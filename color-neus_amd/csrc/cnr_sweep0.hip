@@ -88,7 +88,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
     float sc = 1.0f;
     if (valid) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); }
     unsigned char* B = smem_s + buf * S0_ABUF;
-    if (pv) ws_put4(v, sc, B + srow * S0_ALD + scol * 2, S0_APLANE);
+    // every column the product loop reads (S0_NKB k16 blocks) is written: columns in [kpad, 48) of a K <= 32 layer get zeros, not whatever
+    // an earlier kernel left in LDS (NaN / Inf bit patterns times the zero weights of those blocks would poison the accumulators)
+    if (scol < S0_NKB * 16) ws_put4(v, sc, B + srow * S0_ALD + scol * 2, S0_APLANE);
     if ((tid & 15) == 0) {
       float* rs = reinterpret_cast<float*>(B + 2 * S0_APLANE);
       const float ssv = valid ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf(""));

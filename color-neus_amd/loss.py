@@ -34,8 +34,8 @@ def compute_loss(render_dict, rgb_gt, mask=None, lambda_fine=1.0, lambda_eikonal
 # ---------------------------------------------------------------------------------------------------------------------
 # Fused version: the same objective through two kernels of the render library (cnr_loss_sums /
 # cnr_loss_grads, include/colorneus_render.h) instead of ~25 element-wise / reduction launches and their autograd graph.
-# Ray-sharded runs pass n_rays_global (+ group): one 5-float all-reduce between the two phases reproduces the single-GPU
-# objective exactly (same construction as parallel.sharded_loss).
+# Ray-sharded runs pass n_rays_global (+ group): cnr_loss_shard_stats, one 5-float all-reduce, cnr_loss_shard_combine reproduce the
+# single-GPU objective exactly (same construction as parallel.sharded_loss); three library launches between forward and backward.
 # ---------------------------------------------------------------------------------------------------------------------
 import ctypes as _C
 
@@ -48,10 +48,25 @@ def _stream(t):
     return _C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else _C.c_void_p(0)
 
 
+_SCRATCH = {}   # (library path, device, stream) -> the loss scratch of that stream
+
+
+def _loss_scratch(lib, dev, R):
+    """The scratch of the loss kernels for the current stream of ``dev``.  Its tail holds the completion counter of the one-launch forms
+    (include/colorneus_render.h: zero before the first use, left zero by every call), so the buffer is created zeroed ONCE per stream and
+    reused: calls on one stream are ordered, calls on different streams get different buffers."""
+    nb = lib.lib.cnr_loss_scratch_bytes(R)
+    key = (lib.path, str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nb:
+        t = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        _SCRATCH[key] = t
+    return t, nb
+
+
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lib, lcfg, lambdas, n_rays_global, group, color, wsum, gerr, eik_sums, drel, gt, mask, n_samples_=0):
-        from ._lib import CnrLossConfig  # noqa: F401
         lam_f, lam_e, lam_m, lam_r = lambdas
         ctx.set_materialize_grads(False)   # (the four logging outputs are non-differentiable: no zero tensors for them in backward)
         R = color.shape[0]
@@ -62,66 +77,40 @@ class _FusedLoss(torch.autograd.Function):
         wsum_c = wsum.reshape(-1).contiguous()
         drel_c = drel.contiguous() if drel is not None else None
         mask_c = mask.contiguous() if mask is not None else None
-        sums = torch.empty(4, dtype=torch.float32, device=dev)
-        nb = lib.lib.cnr_loss_scratch_bytes(R)
-        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        scratch, nb = _loss_scratch(lib, dev, R)
         import torch.distributed as dist
         world = dist.get_world_size(group) if (dist.is_initialized() and n_rays_global is not None) else 1
         Rg = float(n_rays_global if n_rays_global is not None else R)
-        eik_factor = None
         use_mask, use_rel = (lam_m != 0 and mask is not None), (lam_r != 0 and drel is not None)
-        if world == 1 and gerr.dtype == torch.float32 and gerr.device == dev:
+        f32 = dict(dtype=torch.float32, device=dev)
+        if n_rays_global is None:
             # single process: the two reduction phases and the scalar tail of the objective in ONE launch (cnr_loss_forward)
-            out6 = torch.empty(6, dtype=torch.float32, device=dev)
-            lib.check(lib.lib.cnr_loss_forward(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), int(per_ray), _p(gt_c), _p(mask_c),
-                                               _p(gerr.detach().reshape(-1).contiguous()), R, int(M), Rg, int(use_mask), int(use_rel),
-                                               _p(sums), _p(out6), _p(scratch), nb, _stream(color_c)), "cnr_loss_forward")
-            loss, rgb_loss, eik, mask_out, rel_out, mean_rel = out6.unbind(0)
-            ctx.lib, ctx.lcfg, ctx.lambdas, ctx.Rg, ctx.M = lib, lcfg, lambdas, Rg, M
-            ctx.has = (use_mask, use_rel, False)
-            ctx.fused_scalars = True
-            ctx.shapes = (color.shape, wsum.shape, tuple(drel.shape) if drel is not None else None)
-            ctx.save_for_backward(color_c, wsum_c, gt_c, mask_c if mask_c is not None else torch.empty(0, device=dev), mean_rel, mean_rel)
-            ctx.mark_non_differentiable(rgb_loss, eik, mask_out, rel_out)
-            return loss, rgb_loss, eik, mask_out, rel_out
-        ctx.fused_scalars = False
-        fn = lib.lib.cnr_loss_sums_ray if per_ray else lib.lib.cnr_loss_sums
-        lib.check(fn(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), _p(gt_c), _p(mask_c), R, M, _p(sums),
-                     _p(scratch), nb, _stream(color_c)), "cnr_loss_sums")
-        if world > 1:
-            stats = torch.cat([sums[:3], eik_sums.detach().reshape(-1)[:2].to(torch.float32)])
-            den_loc = stats[4].clone()
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-            eik = stats[3] / (stats[4] + 1e-5)
-            eik_factor = (den_loc + 1e-5) / (stats[4] + 1e-5)
-            tot = stats
+            sums, out8 = torch.empty(4, **f32), torch.empty(8, **f32)
+            gerr_c = gerr.detach().reshape(-1).to(**f32).contiguous()
+            lib.check(lib.lib.cnr_loss_forward(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), int(per_ray), _p(gt_c), _p(mask_c), _p(gerr_c), R, int(M), Rg,
+                                               int(use_mask), int(use_rel), _p(sums), _p(out8), _p(scratch), nb, _stream(color_c)), "cnr_loss_forward")
+            eik_factor = None
         else:
-            eik = gerr.detach()
-            tot = sums
-        rgb_loss = tot[0] / (Rg * 3.0)
-        loss = lam_f * rgb_loss + lam_e * eik
-        parts = [rgb_loss, eik]
-        mask_loss = relight_loss = None
-        if lam_m != 0 and mask is not None:
-            mask_loss = tot[1] / Rg
-            loss = loss + lam_m * mask_loss
-        mean_rel = None
-        if lam_r != 0 and drel is not None:
-            mean_rel = tot[2] / (Rg * M * 3.0)
-            relight_loss = mean_rel * mean_rel
-            loss = loss + lam_r * relight_loss
-        ctx.lib, ctx.lcfg, ctx.lambdas, ctx.Rg, ctx.M = lib, lcfg, lambdas, Rg, M
-        ctx.has = (mask is not None and lam_m != 0, drel is not None and lam_r != 0, eik_factor is not None)
+            # ray-sharded: this rank's statistics (one launch), ONE 5-float all-reduce, the scalar tail on the reduced statistics (one launch);
+            # no torch arithmetic in between (include/colorneus_render.h, cnr_loss_shard_*)
+            stats, out8 = torch.empty(8, **f32), torch.empty(8, **f32)
+            eik_c = eik_sums.detach().reshape(-1).to(**f32).contiguous()
+            lib.check(lib.lib.cnr_loss_shard_stats(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(drel_c), int(per_ray), _p(gt_c), _p(mask_c), _p(eik_c), R, int(M),
+                                                   _p(stats), _p(scratch), nb, _stream(color_c)), "cnr_loss_shard_stats")
+            if world > 1:
+                dist.all_reduce(stats[:5], op=dist.ReduceOp.SUM, group=group)
+            lib.check(lib.lib.cnr_loss_shard_combine(_C.byref(lcfg), _p(stats), Rg, int(M), int(use_mask), int(use_rel), _p(out8), _stream(color_c)),
+                      "cnr_loss_shard_combine")
+            eik_factor = out8[6]
+        loss, rgb_loss, eik, mask_out, rel_out, mean_rel = out8[:6].unbind(0)
+        ctx.lib, ctx.lcfg, ctx.Rg, ctx.M = lib, lcfg, Rg, M
+        ctx.has = (use_mask, use_rel, eik_factor is not None)
         ctx.shapes = (color.shape, wsum.shape, tuple(drel.shape) if drel is not None else None)
-        ctx.save_for_backward(color_c, wsum_c, gt_c, mask_c if mask_c is not None else torch.empty(0, device=dev),
-                              mean_rel if mean_rel is not None else torch.zeros((), device=dev),
-                              eik_factor if eik_factor is not None else torch.ones((), device=dev))
+        ctx.save_for_backward(color_c, wsum_c, gt_c, mask_c if mask_c is not None else torch.empty(0, device=dev), mean_rel,
+                              eik_factor if eik_factor is not None else mean_rel)
         # only ``loss`` carries gradients: the four components are logging values (the reference's loss_dict entries are read with
         # .item(), NeuS_Trainer.py:155-171); back-propagating through them would bypass the fused coefficients, so they are all
         # non-differentiable outputs rather than some silently yielding zero gradients
-        zero = torch.zeros((), device=dev)
-        mask_out = mask_loss if mask_loss is not None else zero
-        rel_out = relight_loss if relight_loss is not None else zero
         ctx.mark_non_differentiable(rgb_loss, eik, mask_out, rel_out)
         return loss, rgb_loss, eik, mask_out, rel_out
 
@@ -130,8 +119,7 @@ class _FusedLoss(torch.autograd.Function):
         if g_loss is None:   # nothing depends on ``loss`` (cannot happen through the components: they are non-differentiable)
             return (None,) * 13
         color_c, wsum_c, gt_c, mask_c, mean_rel, eik_factor = ctx.saved_tensors
-        lam_f, lam_e, lam_m, lam_r = ctx.lambdas
-        has_mask, has_rel, _ = ctx.has
+        has_mask, has_rel, has_factor = ctx.has
         lib, lcfg, Rg, M = ctx.lib, ctx.lcfg, ctx.Rg, ctx.M
         dev = color_c.device
         R = color_c.shape[0]
@@ -141,25 +129,20 @@ class _FusedLoss(torch.autograd.Function):
         d_color = torch.empty_like(color_c)
         d_wsum = torch.empty(R, dtype=torch.float32, device=dev)
         mask_g = mask_t if has_mask or lcfg.include_mask else None
-        if ctx.fused_scalars:   # one launch (cnr_loss_backward): coefficients + gradients; coef[3] = d loss / d gradient_error
-            coef = torch.empty(4, dtype=torch.float32, device=dev)
-            lib.check(lib.lib.cnr_loss_backward(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(gt_c), _p(mask_g), R, int(M), _p(g.reshape(-1).contiguous()),
-                                                _p(mean_rel), Rg, int(has_mask), int(has_rel), _p(coef), _p(d_color), _p(d_wsum), _stream(color_c)),
-                      "cnr_loss_backward")
-        else:
-            c_rgb = lam_f * (1.0 if lcfg.rgb_l1 else 2.0) / (Rg * 3.0)
-            c_bce = (lam_m / Rg) if has_mask else 0.0
-            c_rel = (lam_r * 2.0 / (Rg * M * 3.0)) if has_rel else 0.0
-            coef = torch.stack([g * c_rgb, g * c_bce, g * c_rel * mean_rel, g * 0.0])
-            lib.check(lib.lib.cnr_loss_grads(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(gt_c), _p(mask_g),
-                                             R, M, _p(coef), _p(d_color), _p(d_wsum), _p(None), _stream(color_c)), "cnr_loss_grads")
+        # one launch (cnr_loss_backward): coefficients + gradients; coef[3] = d loss / d gradient_error (incl. the shard's eikonal factor)
+        coef = torch.empty(4, dtype=torch.float32, device=dev)
+        want_drel = has_rel and ctx.shapes[2] is not None
+        # d mean(delta_relight * mask)^2 / d delta_relight[r, j, c] = 2 mean / n * mask[r]: one value per ray, written by the same launch
+        per_ray = torch.empty(R, dtype=torch.float32, device=dev) if want_drel else None
+        lib.check(lib.lib.cnr_loss_backward(_C.byref(lcfg), _p(color_c), _p(wsum_c), _p(gt_c), _p(mask_g), R, int(M), _p(g.reshape(-1).contiguous()),
+                                            _p(mean_rel), _p(eik_factor if has_factor else None), Rg, int(has_mask), int(has_rel), _p(coef), _p(d_color),
+                                            _p(d_wsum), _p(per_ray), _stream(color_c)), "cnr_loss_backward")
         d_drel = None
-        if has_rel and ctx.shapes[2] is not None:
-            # d mean(delta_relight * mask)^2 / d delta_relight[r, j, c] = 2 mean / n * mask[r]: one value per ray.  Handed to the renderer's
-            # backward as an expanded (stride-0) view -- its compositor backward takes the per-ray vector, no [R][M][3] buffer is written
-            per_ray = coef[2] * mask_t if (lcfg.include_mask and mask_t is not None) else coef[2].expand(R)
+        if want_drel:
+            # handed to the renderer's backward as an expanded (stride-0) view -- its compositor backward takes the per-ray vector, no
+            # [R][M][3] buffer is written
             d_drel = per_ray.reshape(R, 1, 1).expand(ctx.shapes[2]) if len(ctx.shapes[2]) == 3 else per_ray.reshape(ctx.shapes[2])
-        d_gerr = coef[3].reshape(g_loss.shape) if ctx.fused_scalars else g_loss * lam_e * eik_factor
+        d_gerr = coef[3].reshape(g_loss.shape)
         return (None, None, None, None, None, d_color.reshape(ctx.shapes[0]), d_wsum.reshape(ctx.shapes[1]), d_gerr, None, d_drel, None, None, None)
 
 

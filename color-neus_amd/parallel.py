@@ -59,7 +59,8 @@ def sharded_render_image(renderer, rays_o, rays_d, near, far, chunk=1024, group=
     m = int(renderer.rcfg.n_total) if hasattr(renderer, "rcfg") else None
     widths = {"color_fine": 3, "global_color": 3, "depth": 1, "weight_sum": 1, "weight_max": 1, "s_val": 1}
     if m is not None:
-        widths.update({"weights": m, "cdf_fine": m, "inside_sphere": m, "z_vals": m, "gradients": 3 * m, "delta_relight": 3 * m})
+        # (with N_OUTSIDE > 0 the weights cover the background samples too: NeuS.py:262-268)
+        widths.update({"weights": m + int(getattr(renderer, "n_outside", 0) or 0), "cdf_fine": m, "inside_sphere": m, "z_vals": m, "gradients": 3 * m, "delta_relight": 3 * m})
     unknown = [k for k in keys if k not in widths]
     if unknown:
         raise ValueError(f"sharded_render_image: no per-ray width known for keys {unknown} (gatherable: {sorted(widths)})")

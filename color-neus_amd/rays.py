@@ -75,8 +75,10 @@ class _GenRays(torch.autograd.Function):
         for name, t in (("image", img), ("mask", msk)):
             if t is not None and t.shape[0] != n_cams:
                 raise ValueError(f"{name} holds {t.shape[0]} cameras but c2w holds {n_cams}")
-        # range check of caller-supplied indices: two device-to-host syncs, so only on request (CNR_CHECK_INDICES=1 or check_indices=True
-        # of the public functions); the indices of choose_pixels are in range by construction
+        # range of the indices: the ray kernel checks every index on the device (an index outside [0, n_cams * H * W) reads nothing and makes
+        # that ray's outputs NaN; its backward contributes nothing) -- no host cost, no out-of-bounds access.  The host-side check below
+        # raises like the reference's torch indexing would, but costs two device-to-host syncs: on request only (CNR_CHECK_INDICES=1);
+        # the indices of choose_pixels, the only producer inside this module, are in range by construction
         if idx is not None and idx.numel() > 0 and _CHECK_INDICES:
             lo, hi = int(idx.min()), int(idx.max())
             if lo < 0 or hi >= n_cams * H * W:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CNR_ABI_VERSION 6
+#define CNR_ABI_VERSION 7
 
 typedef struct cnr_config {
   int32_t type;              /* 0 = NeuS (NeuS.py:68), 1 = Color_NeuS (Color_NeuS.py:10) */
@@ -161,17 +161,39 @@ int cnr_loss_coef(const cnr_loss_config* cfg, const float* g_loss /* device [1] 
 
 /* The same two sides as ONE launch each (single process; replaces NeuS_Trainer.compute_loss, NeuS_Trainer.py:129-171, and its autograd graph):
  *   cnr_loss_forward : cnr_loss_sums (delta_per_ray == 0: delta_relight is [R][M][3]; != 0: the per-ray sums [R]) + cnr_loss_combine; the block that
- *                      finishes last folds the partial sums in the fixed order of cnr_loss_sums -- bitwise the same sums and scalars.  The library
- *                      keeps the completion counter: at most one cnr_loss_forward in flight per device.
+ *                      finishes last folds the partial sums in the fixed order of cnr_loss_sums -- bitwise the same sums and scalars.  Its completion
+ *                      counter is the 4 bytes at offset cnr_loss_scratch_bytes() - 16 of the CALLER's scratch: zero before the first call that uses
+ *                      the buffer, left zero by every call.  A buffer may be reused call after call on one stream; calls that may overlap (other
+ *                      streams or threads) need buffers of their own.  cnr_loss_sums / cnr_loss_sums_ray never touch the counter.
  *   cnr_loss_backward: cnr_loss_coef (also written to coef[4] for the caller: coef[2] * mask is d / d delta_relight, coef[3] is d / d gradient_error)
- *                      + cnr_loss_grads for d_color_fine / d_weight_sum. */
+ *                      + cnr_loss_grads for d_color_fine / d_weight_sum.  eik_factor (device [1] or NULL = 1): coef[3] = g * lambda_eikonal * eik_factor
+ *                      (ray-sharded runs, below). */
 int cnr_loss_forward(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight /* or NULL */, int32_t delta_per_ray,
                      const float* rgb_gt, const float* mask /* or NULL */, const float* gradient_error /* device [1] */, int64_t n_rays, int32_t n_samples,
                      float n_rays_global, int32_t use_mask, int32_t use_relight, float* sums /* device [4] */, float* out /* device [6] */,
                      void* scratch, size_t scratch_bytes, void* stream);
 int cnr_loss_backward(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* rgb_gt, const float* mask /* or NULL */,
-                      int64_t n_rays, int32_t n_samples, const float* g_loss /* device [1] */, const float* mean_rel /* device [1] */, float n_rays_global,
-                      int32_t use_mask, int32_t use_relight, float* coef /* device [4] */, float* d_color_fine, float* d_weight_sum /* or NULL */, void* stream);
+                      int64_t n_rays, int32_t n_samples, const float* g_loss /* device [1] */, const float* mean_rel /* device [1] */,
+                      const float* eik_factor /* device [1] or NULL */, float n_rays_global, int32_t use_mask, int32_t use_relight,
+                      float* coef /* device [4] */, float* d_color_fine, float* d_weight_sum /* or NULL */,
+                      float* d_delta_relight_per_ray /* [R] or NULL: coef[2] (* mask[r]), what cnr_render_out_grads.delta_relight_per_ray takes */, void* stream);
+
+/* Ray-sharded runs (one process per GPU, the rays of a batch split over the ranks; the reference is single-GPU, train.py:111): the eikonal term is a
+ * ratio of sums over ALL rays (Color_NeuS.py:122-123) and the relight term the square of a mean over ALL samples (NeuS_Trainer.py:153), so the
+ * objective needs ONE exchange between the two sides.  Three launches around one 5-float all-reduce (the caller's: RCCL):
+ *   cnr_loss_shard_stats  : one launch (the fold by the last block, as cnr_loss_forward; same scratch contract): stats[0..2] = the three sums of
+ *                           cnr_loss_sums over this rank's rays, stats[3..4] = eik_sums of this rank (cnr_render_outputs.eik_sums),
+ *                           stats[5] = stats[4] again (the rank's own value survives the all-reduce there), stats[6..7] = 0
+ *   caller                : all-reduce(sum) of stats[0..5) over the ranks
+ *   cnr_loss_shard_combine: out[0..5] as cnr_loss_combine with eikonal = stats[3] / (stats[4] + 1e-5), the GLOBAL loss on every rank;
+ *                           out[6] = eik_factor = (stats[5] + 1e-5) / (stats[4] + 1e-5) = d eikonal / d (this rank's gradient_error output); out[7] = 0
+ *   cnr_loss_backward     : with n_rays_global, mean_rel = out + 5 and eik_factor = out + 6: the rank-local gradients whose sum over the ranks is the
+ *                           single-GPU gradient. */
+int cnr_loss_shard_stats(const cnr_loss_config* cfg, const float* color_fine, const float* weight_sum, const float* delta_relight /* or NULL */,
+                         int32_t delta_per_ray, const float* rgb_gt, const float* mask /* or NULL */, const float* eik_sums /* device [2] */, int64_t n_rays,
+                         int32_t n_samples, float* stats /* device [8] */, void* scratch, size_t scratch_bytes, void* stream);
+int cnr_loss_shard_combine(const cnr_loss_config* cfg, const float* stats /* device [8] */, float n_rays_global, int32_t n_samples, int32_t use_mask,
+                           int32_t use_relight, float* out /* device [8] */, void* stream);
 
 /* ---- ray generation for the selected pixels, the producer right in front of the path (NeuS_Trainer.render, NeuS_Trainer.py:104-120):
  * get_rays_multicam / get_rays_at (lib/models/tools/ray_utils.py:16-119) evaluated ONLY for the chosen pixels (the reference builds the

@@ -177,8 +177,9 @@ def _one_launch_forms(library, device):
         gerr = torch.rand(1, generator=g).to(device); gl = torch.tensor([0.7], device=device)
         cfg = CnrLossConfig(1.0, 0.1, 0.1, 1.0, 0, 1)
         nb = L.cnr_loss_scratch_bytes(R)
+        # the scratch contract of the one-launch forms: zeroed ONCE (its tail is the completion counter), then reused call after call
+        scr = torch.zeros(nb, dtype=torch.uint8, device=device)
         for rep in range(3):
-            scr = torch.empty(nb, dtype=torch.uint8, device=device)
             s1, o1 = torch.empty(4, device=device), torch.empty(6, device=device)
             fn = L.cnr_loss_sums_ray if per_ray else L.cnr_loss_sums
             lib.check(fn(C.byref(cfg), p(color), p(wsum), p(drel), p(gt), p(mask), R, M, p(s1), p(scr), nb, st), "sums")
@@ -191,9 +192,32 @@ def _one_launch_forms(library, device):
             lib.check(L.cnr_loss_coef(C.byref(cfg), p(gl), p(o1[5:6].contiguous()), float(R), M, int(use_mask), 1, p(c1), st), "coef")
             lib.check(L.cnr_loss_grads(C.byref(cfg), p(color), p(wsum), p(gt), p(mask), R, M, p(c1), p(dc1), p(dw1), p(None), st), "grads")
             c2, dc2, dw2 = torch.empty(4, device=device), torch.empty(R, 3, device=device), torch.empty(R, device=device)
-            lib.check(L.cnr_loss_backward(C.byref(cfg), p(color), p(wsum), p(gt), p(mask), R, M, p(gl), p(o2[5:6].contiguous()), float(R), int(use_mask), 1,
-                                          p(c2), p(dc2), p(dw2), st), "backward")
+            dr2 = torch.empty(R, device=device)
+            lib.check(L.cnr_loss_backward(C.byref(cfg), p(color), p(wsum), p(gt), p(mask), R, M, p(gl), p(o2[5:6].contiguous()), p(None), float(R), int(use_mask), 1,
+                                          p(c2), p(dc2), p(dw2), p(dr2), st), "backward")
             assert torch.equal(c1, c2) and torch.equal(dc1, dc2) and torch.equal(dw1, dw2), (R, M, rep)
+            assert torch.equal(dr2, c2[2] * mask if use_mask else c2[2].expand(R))
+            assert int(scr[-16:].view(torch.int32)[0]) == 0      # the counter is back at zero
+            # ---- the ray-sharded forms on the same rays: stats = {the three sums, eik_sums, eik_sums[1]}; with nothing added by other ranks the
+            # combine step must reproduce the single-process scalars for gradient_error = num / (den + 1e-5), and eik_factor = 1
+            eik = torch.tensor([0.37, 123.0], device=device)
+            st8, o8 = torch.empty(8, device=device), torch.empty(8, device=device)
+            lib.check(L.cnr_loss_shard_stats(C.byref(cfg), p(color), p(wsum), p(drel), int(per_ray), p(gt), p(mask), p(eik), R, M, p(st8), p(scr), nb, st), "stats")
+            assert torch.equal(st8[:3], s1[:3]) and torch.equal(st8[3:6], torch.stack([eik[0], eik[1], eik[1]]))
+            lib.check(L.cnr_loss_shard_combine(C.byref(cfg), p(st8), float(R), M, int(use_mask), 1, p(o8), st), "shard_combine")
+            g1 = (eik[0] / (eik[1] + 1e-5)).reshape(1)
+            o3 = torch.empty(6, device=device)
+            lib.check(L.cnr_loss_combine(C.byref(cfg), p(s1), p(g1), float(R), M, int(use_mask), 1, p(o3), st), "combine")
+            assert torch.equal(o8[:6], o3) and float(o8[6]) == 1.0
+            # a second rank's statistics added (what the all-reduce does): global ratio and this rank's factor
+            st8b = st8.clone()
+            st8b[:5] += torch.tensor([1.5, 2.5, -0.25, 0.11, 77.0], device=device)
+            lib.check(L.cnr_loss_shard_combine(C.byref(cfg), p(st8b), float(2 * R), M, int(use_mask), 1, p(o8), st), "shard_combine")
+            assert abs(float(o8[2]) - float(st8b[3] / (st8b[4] + 1e-5))) < 1e-7 and abs(float(o8[6]) - float((eik[1] + 1e-5) / (st8b[4] + 1e-5))) < 1e-7
+            c3 = torch.empty(4, device=device)
+            lib.check(L.cnr_loss_backward(C.byref(cfg), p(color), p(wsum), p(gt), p(mask), R, M, p(gl), p(o8[5:6].contiguous()), p(o8[6:7].contiguous()), float(2 * R),
+                                          int(use_mask), 1, p(c3), p(dc2), p(dw2), p(None), st), "backward")
+            assert abs(float(c3[3]) - 0.7 * 0.1 * float(o8[6])) < 1e-7
 
 
 @pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")

@@ -88,6 +88,43 @@ def _backward(library, dev):
         assert float(cd.grad[:, 3].abs().max()) == 0.0     # bottom row of the pose matrices
 
 
+def _bad_indices(library, dev):
+    """A caller-supplied index outside [0, n_cams * H * W): the kernel reads nothing for it (the image / mask / pose reads would be out of
+    bounds), that ray's outputs are NaN, its backward contributes nothing, and every other ray is untouched."""
+    fx = G.load("rays")
+    H, W = 12, 17
+    c2w = torch.from_numpy(fx["c2w"]).to(dev).requires_grad_(True)
+    focal = torch.from_numpy(fx["focal"]).to(dev)
+    image, mask = torch.from_numpy(fx["image"]).to(dev), torch.from_numpy(fx["mask"]).to(dev)
+    n_cams = c2w.shape[0]
+    good = torch.tensor([0, 5, H * W + 3, n_cams * H * W - 1], dtype=torch.int64)
+    bad = torch.tensor([0, -1, H * W + 3, n_cams * H * W, 5, 1 << 40], dtype=torch.int64)
+    lib = rays._library(library)
+    og, dg, rg, mg, ng, fg = rays._generate(lib, good.to(dev), 4, c2w, focal, H, W, True, False, image=image, mask=mask, want_nearfar=True)
+    ob, db, rb, mb, nb, fb = rays._generate(lib, bad.to(dev), 6, c2w, focal, H, W, True, False, image=image, mask=mask, want_nearfar=True)
+    for t in (ob, db, rb, mb, nb, fb):
+        t = t.detach().cpu().reshape(6, -1)
+        assert bool(torch.isnan(t[[1, 3, 5]]).all()) and bool(torch.isfinite(t[[0, 2, 4]]).all())
+    assert torch.equal(ob[[0, 2, 4]].detach().cpu(), og[[0, 2, 1]].detach().cpu()) and torch.equal(rb[[0, 2, 4]].cpu(), rg[[0, 2, 1]].cpu())
+    # backward: cotangents of the bad rays are ignored (zeroed here so that NaN x 0 does not enter through the caller's own arithmetic)
+    w = torch.tensor([1.0, 0.0, 1.0, 0.0, 1.0, 0.0], device=dev)[:, None]
+    (torch.nan_to_num(ob) * w).sum().backward()
+    g_bad = c2w.grad.clone()
+    c2w.grad = None
+    og[[0, 2, 1]].sum().backward()
+    assert bool(torch.isfinite(g_bad).all()) and torch.allclose(g_bad, c2w.grad, atol=1e-6)
+
+
+@emu
+def test_out_of_range_pixel_indices_emu():
+    _bad_indices(N.EMU_LIB, "cpu")
+
+
+@pytest.mark.gpu
+def test_out_of_range_pixel_indices_hip():
+    _bad_indices(None, "cuda:0")
+
+
 @emu
 def test_get_rays_multicam_same_pixels_and_values_emu():
     _multicam(N.EMU_LIB, "cpu")

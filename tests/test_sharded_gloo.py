@@ -99,10 +99,17 @@ def _eval_worker(rank, world, port, q):
     t = lambda k: torch.from_numpy(fx[k])
     torch.manual_seed(4)
     img = parallel.sharded_render_image(r, t("rays_o"), t("rays_d"), t("jit:near"), t("jit:far"), chunk=5)   # 32 rays: 7 chunks (4 + 3 per rank), the last one ragged
+    # a model with N_OUTSIDE > 0: its weights rows cover the background samples too (n_samples + n_importance + n_outside columns)
+    fo = G.load("tiny_outside")
+    ocfg_o, P_o = G.weights_of("tiny_outside", fo)
+    ro = N.make_renderer(ocfg_o, P_o, N.EMU_LIB, "cpu")
+    to = lambda k: torch.from_numpy(fo[k])
+    torch.manual_seed(6)
+    img_o = parallel.sharded_render_image(ro, to("rays_o"), to("rays_d"), to("jit:near"), to("jit:far"), chunk=3, keys=("color_fine", "weights"))
     if rank == 0:
-        q.put((u.numpy().copy(), {k: v.numpy().copy() for k, v in img.items()}))
+        q.put((u.numpy().copy(), {k: v.numpy().copy() for k, v in img.items()}, {k: v.numpy().copy() for k, v in img_o.items()}))
     else:
-        assert u is None and img is None
+        assert u is None and img is None and img_o is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -124,7 +131,13 @@ def test_two_rank_sharded_evaluation_matches_single_process():
     procs = [ctx.Process(target=_eval_worker, args=(rk, 2, port, q)) for rk in range(2)]
     for p in procs:
         p.start()
-    u2, img2 = q.get(timeout=300)
+    fo = G.load("tiny_outside")
+    ocfg_o, P_o = G.weights_of("tiny_outside", fo)
+    ro = N.make_renderer(ocfg_o, P_o, N.EMU_LIB, "cpu")
+    to = lambda k: torch.from_numpy(fo[k])
+    torch.manual_seed(6)
+    img_o1 = parallel.sharded_render_image(ro, to("rays_o"), to("rays_d"), to("jit:near"), to("jit:far"), chunk=3, keys=("color_fine", "weights"))
+    u2, img2, img_o2 = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -134,3 +147,7 @@ def test_two_rank_sharded_evaluation_matches_single_process():
     assert img2["color_fine"].shape == (n, 3) and img2["depth"].shape == (n, 1)
     for k in img1:
         assert np.array_equal(img1[k].numpy(), img2[k]), k
+    n_o = fo["rays_o"].shape[0]
+    assert img_o2["weights"].shape == (n_o, ocfg_o.n_samples + ocfg_o.n_importance + ocfg_o.n_outside)
+    for k in img_o1:
+        assert np.array_equal(img_o1[k].numpy(), img_o2[k]), k
