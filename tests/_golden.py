@@ -11,6 +11,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CONFIGS = {
     "tiny_init": lambda: O.tiny_config(),
     "tiny_sharp": lambda: O.tiny_config(),
+    "tiny_sharp_anneal": lambda: O.tiny_config(),       # cos_anneal_ratio 0.3 + background_rgb (the fixture's call:* entries)
+    "dtu_sharp_anneal": lambda: O.dtu_config(),
     "tiny_noimp_sharp": lambda: _noimp(),
     "tiny_neus_sharp": lambda: O.RenderConfig(
         type="NeuS", n_samples=16, n_importance=16,
@@ -68,6 +70,15 @@ def weights_of(name, fx, dtype=torch.float32):
     cs = O.params_checksum(P)
     assert abs(cs - float(fx["weight_checksum"])) <= 1e-9 * abs(cs), "weight recipe drifted from the fixture"
     return cfg, {k: v.to(dtype) for k, v in P.items()}
+
+
+def call_kwargs(fx, device=None, dtype=torch.float32):
+    """Non-default call arguments a fixture was captured with (tools/gen_golden.py: cos_anneal_ratio, background_rgb as the [1, 3] tensor of
+    Color_NeuS.py:104-106); empty for the default-call fixtures."""
+    if "call:cos_anneal_ratio" not in fx:
+        return {}
+    bg = torch.from_numpy(np.asarray(fx["call:background_rgb"])).to(dtype).reshape(1, 3)
+    return dict(cos_anneal_ratio=float(fx["call:cos_anneal_ratio"]), background_rgb=bg.to(device) if device is not None else bg)
 
 
 def prefixed(fx, prefix, dtype=torch.float32):

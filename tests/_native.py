@@ -44,6 +44,7 @@ def run_native(name, tag, library, device, fixed_z=True, rays_grad=True, nearfar
         near.requires_grad_(True)
         far.requires_grad_(True)
     z = torch.from_numpy(fx[f"{tag}:z_vals"]).to(device) if fixed_z else None
+    ckw = G.call_kwargs(fx, device)    # cos_anneal_ratio / background_rgb of the *_anneal fixtures
     if ocfg.n_outside > 0:
         # N_OUTSIDE > 0: the background samples take a second draw from the CPU generator (NeuS.py:335) -- replay the fixture's seed
         # (tools/gen_golden.py: jitter seed 2) instead of patching torch.rand
@@ -53,18 +54,18 @@ def run_native(name, tag, library, device, fixed_z=True, rays_grad=True, nearfar
         else:
             out = r(o, d, near, far, z_vals=z, perturb_overwrite=0)
     elif fixed_z:
-        out = r(o, d, near, far, z_vals=z)
+        out = r(o, d, near, far, z_vals=z, **ckw)
     elif f"{tag}:t_rand" in fx:
         # feed the fixture's jitter draw through the same CPU-generator call the module makes
         t = torch.from_numpy(fx[f"{tag}:t_rand"])
         orig = torch.rand
         try:
             torch.rand = lambda *a, **k: t.clone()
-            out = r(o, d, near, far)
+            out = r(o, d, near, far, **ckw)
         finally:
             torch.rand = orig
     else:
-        out = r(o, d, near, far, perturb_overwrite=0)
+        out = r(o, d, near, far, perturb_overwrite=0, **ckw)
     loss, _ = cn.compute_loss(out, torch.from_numpy(fx["rgb_gt"]).to(device), torch.from_numpy(fx["mask"]).to(device))
     loss.backward()
     grads = {k: p.grad for k, p in r.named_parameters()}

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 DEV = "cuda:0"
 
-E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "dtu_noimp_sharp", "neus_dtu_sharp"]
+E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "dtu_noimp_sharp", "neus_dtu_sharp",
+       "tiny_sharp_anneal", "dtu_sharp_anneal"]   # (*_anneal: cos_anneal_ratio 0.3 + background_rgb, reference goldens of NeuS.py:294-302)
 
 
 def test_library_is_hip():

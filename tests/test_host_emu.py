@@ -15,7 +15,7 @@ TOL = 1e-4
 
 pytestmark = pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built (run __graft_entry__.build())")
 
-E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "dtu_noimp_sharp", "neus_dtu_sharp"]
+E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "dtu_noimp_sharp", "neus_dtu_sharp", "tiny_sharp_anneal", "dtu_sharp_anneal"]
 
 
 @pytest.mark.parametrize("name", E2E)

@@ -101,13 +101,14 @@ def _run_oracle(name, tag, fixed_z):
     near, far = torch.from_numpy(fx[f"{tag}:near"]), torch.from_numpy(fx[f"{tag}:far"])
     t_rand = torch.from_numpy(fx[f"{tag}:t_rand"]) if f"{tag}:t_rand" in fx else None
     z = torch.from_numpy(fx[f"{tag}:z_vals"]) if fixed_z else None
-    out = O.render(P, cfg, o, d, near, far, t_rand=t_rand, z_vals=z)
+    out = O.render(P, cfg, o, d, near, far, t_rand=t_rand, z_vals=z, **G.call_kwargs(fx))
     loss, _ = O.compute_loss(out, torch.from_numpy(fx["rgb_gt"]), torch.from_numpy(fx["mask"]))
     loss.backward()
     return fx, cfg, P, o, d, out, loss
 
 
-E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "neus_dtu_sharp"]
+# (*_anneal: cos_anneal_ratio 0.3 and a background colour, NeuS.py:294-302 -- the oracle branches of Color_NeuS.py:69-78, 104-106)
+E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "neus_dtu_sharp", "tiny_sharp_anneal", "dtu_sharp_anneal"]
 
 
 @pytest.mark.parametrize("name", E2E)
@@ -132,9 +133,52 @@ def test_g2_render_core_at_golden_z(name, tag):
             assert G.relerr(out[k].detach(), fx[f"{tag}:out_{k}"]) < TOL, k
     assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
     bad = G.check_param_grads(fx, tag, {k: p.grad for k, p in P.items()}, TOL)
+    # d variance is ONE number in which the per-ray terms cancel to a few percent of their size: a float32 evaluation with
+    # another summation order than the reference's sits up to 2e-4 from float64 where the reference's own float32 run sits at 0.7e-4
+    # (tiny_sharp_anneal / jit).  The float64 test below pins the restatement itself far tighter; here the scalar keeps the hard cap only
+    bad = [b for b in bad if not (b[0] == "deviation_network.variance" and b[1] <= G.STRICT_TOL_CAP)]
     assert not bad, bad
     assert G.relerr(o.grad, fx[f"{tag}:grad_rays_o"]) < TOL
     assert G.relerr(d.grad, fx[f"{tag}:grad_rays_d"]) < TOL
+
+
+@pytest.mark.parametrize("name", E2E)
+@pytest.mark.parametrize("tag", ["det", "jit"])
+def test_g2_oracle_in_float64_matches_the_reference_in_float64(name, tag):
+    """The restatement itself, free of float32 round-off: the oracle evaluated in float64 at the fixture's sample positions against the
+    REFERENCE code run in float64 at the same positions (tools/gen_golden.py stores its loss, every gradient tensor -- strided beyond 8192
+    entries -- their sums, and d rays).  Two float64 evaluations of the same algorithm agree to ~1e-9; 1e-6 leaves room for the ReLU nets'
+    summation order only.  This is what pins the oracle branches behind non-default call arguments (*_anneal fixtures) as well."""
+    fx = G.load(name)
+    cfg, P = G.weights_of(name, fx, dtype=torch.float64)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    t = lambda k: torch.from_numpy(fx[k]).double()
+    o, d = t("rays_o").requires_grad_(True), t("rays_d").requires_grad_(True)
+    noimp = cfg.n_importance == 0    # z is then a closed form of near / far and the float64 reference run used its own z (no override) ...
+    if noimp:                        # ... from near / far evaluated in float64 (the fixture stores the float32 run's)
+        near, far = (x.detach().requires_grad_(True) for x in O.near_far_from_sphere(o.detach(), d.detach()))
+    else:
+        near, far = t(f"{tag}:near").requires_grad_(True), t(f"{tag}:far").requires_grad_(True)
+    t_rand = t(f"{tag}:t_rand") if (noimp and f"{tag}:t_rand" in fx) else None
+    out = O.render(P, cfg, o, d, near, far, t_rand=t_rand, z_vals=None if noimp else t(f"{tag}:z_vals"), **G.call_kwargs(fx, dtype=torch.float64))
+    loss, _ = O.compute_loss(out, t("rgb_gt"), t("mask"))
+    loss.backward()
+    # (without importance sampling the reference builds z from a float32 linspace even when it runs in float64, the oracle from a float64 one:
+    # sample positions differ by 1e-8, gradients by 2e-6 of their scale)
+    tol = 5e-5 if noimp else 1e-6   # (5e-5: d variance of tiny_noimp_sharp is a cancelled sum, 1.3e-5 there; every other tensor 2e-6)
+    assert abs(float(loss.detach()) - float(fx[f"{tag}:f64:loss"])) < tol * abs(float(fx[f"{tag}:f64:loss"]))
+    s = int(fx["grad_stride"])
+    for k, p in P.items():
+        ref = fx[f"{tag}:g64:{k}"]
+        full = p.grad.reshape(-1)
+        got = full[::(1 if full.numel() <= G.FULL_TENSOR_LIMIT else s)].numpy()
+        den = max(float(fx[f"{tag}:gmax64:{k}"]), 1e-300)
+        assert float(np.abs(got - ref).max()) / den < tol, (k, float(np.abs(got - ref).max()) / den)
+        gabs = max(float(fx[f"{tag}:gabs64:{k}"]), 1e-300)
+        assert abs(float(full.sum()) - float(fx[f"{tag}:gsum64:{k}"])) / gabs < tol and abs(float(full.abs().sum()) - gabs) / gabs < tol, k
+    assert G.relerr(o.grad, fx[f"{tag}:f64:grad_rays_o"]) < tol and G.relerr(d.grad, fx[f"{tag}:f64:grad_rays_d"]) < tol
+    if noimp:
+        assert G.relerr(near.grad, fx[f"{tag}:f64:grad_near"]) < tol and G.relerr(far.grad, fx[f"{tag}:f64:grad_far"]) < tol
 
 
 @pytest.mark.parametrize("name", ["tiny_init", "dtu_init"])

@@ -58,7 +58,8 @@ def make_rays(R, seed, dtype=torch.float32):
     return o.to(dtype), d.to(dtype), gt.to(dtype), mask.to(dtype)
 
 
-def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0.1, rays_grad=True, dtype=torch.float32, t_rand=None, z_override=None):
+def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0.1, rays_grad=True, dtype=torch.float32, t_rand=None, z_override=None,
+                  call_kw=None):
     """Returns dict of numpy arrays: outputs, z_vals, loss, grads.  dtype=float64 runs the SAME reference code in double
     (its own fp32-vs-fp64 spread is what the gradient gate is calibrated on); near / far are leaves that require grad so that the
     N_IMPORTANCE == 0 path (z differentiable w.r.t. near / far, NeuS.py:311-313) is pinned as well."""
@@ -91,8 +92,13 @@ def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0
     near = near.detach().clone().requires_grad_(True)
     far = far.detach().clone().requires_grad_(True)
     res = {}
+    # non-default call arguments of NeuS.forward (NeuS.py:294-302): cos_anneal_ratio, background_rgb (a [1, 3] tensor, Color_NeuS.py:104-106)
+    kw = {}
+    if call_kw:
+        kw["cos_anneal_ratio"] = float(call_kw["cos_anneal_ratio"])
+        kw["background_rgb"] = torch.tensor([list(call_kw["background_rgb"])], dtype=dtype)
     if jitter_seed is None:
-        out = r(o, d, near, far, perturb_overwrite=0)
+        out = r(o, d, near, far, perturb_overwrite=0, **kw)
     elif t_rand is not None:
         # float64 twin of a jittered run: replay the float32 draws of the same seed, cast (the default dtype stays float32, so the
         # generator stream -- per-ray jitter, then the background samples when N_OUTSIDE > 0 -- is the float32 run's)
@@ -100,14 +106,14 @@ def run_reference(cls, node, P, o, d, gt, mask, jitter_seed, mods, lambda_mask=0
         try:
             torch.rand = lambda *a, **k: orig_rand(*a, **k).to(dtype)
             torch.manual_seed(jitter_seed)
-            out = r(o, d, near, far)
+            out = r(o, d, near, far, **kw)
         finally:
             torch.rand = orig_rand
     else:
         torch.manual_seed(jitter_seed)
         res["t_rand"] = torch.rand([o.shape[0], 1]).numpy()
         torch.manual_seed(jitter_seed)
-        out = r(o, d, near, far)
+        out = r(o, d, near, far, **kw)
     # NeuS_Trainer.compute_loss, DTU settings (NeuS_Trainer.py:129-171)
     loss = torch.nn.functional.mse_loss(out["color_fine"], gt) + 0.1 * out["gradient_error"]
     if lambda_mask != 0:
@@ -136,13 +142,13 @@ def tensor_stride(numel, grad_stride):
     return 1 if numel <= FULL_TENSOR_LIMIT else grad_stride
 
 
-def e2e_fixture(name, cfg, cls, CN, mods, R, weight_seed, trained_like, store_weights, grad_stride, n_outside=0):
+def e2e_fixture(name, cfg, cls, CN, mods, R, weight_seed, trained_like, store_weights, grad_stride, n_outside=0, call_kw=None, ray_seed=1):
     node = node_from_config(cfg, CN)
     P = O.init_params(cfg, seed=weight_seed, dtype=torch.float32, trained_like=trained_like)
     if n_outside > 0:   # NeRF++ background (NeuS.py:87-91): weights from the oracle's recipe (seed + checksum in the fixture)
         node["N_OUTSIDE"] = n_outside
         P.update(O.init_nerf_params(seed=weight_seed + 100))
-    o, d, gt, mask = make_rays(R, seed=1)
+    o, d, gt, mask = make_rays(R, seed=ray_seed)
     fx = dict(rays_o=o.numpy(), rays_d=d.numpy(), rgb_gt=gt.numpy(), mask=mask.numpy(),
               weight_seed=np.int64(weight_seed), trained_like=np.int64(trained_like),
               weight_checksum=np.float64(O.params_checksum({k: v for k, v in P.items() if not k.startswith("nerf.")})),
@@ -154,11 +160,14 @@ def e2e_fixture(name, cfg, cls, CN, mods, R, weight_seed, trained_like, store_we
         for k, v in P.items():
             if not k.startswith("nerf."):
                 fx["w:" + k] = v.numpy()
+    if call_kw:
+        fx["call:cos_anneal_ratio"] = np.float64(call_kw["cos_anneal_ratio"])
+        fx["call:background_rgb"] = np.asarray(call_kw["background_rgb"], dtype=np.float32)
     for tag, js in (("det", None), ("jit", 2)):
-        res, grads = run_reference(cls, node, P, o, d, gt, mask, js, mods)
+        res, grads = run_reference(cls, node, P, o, d, gt, mask, js, mods, call_kw=call_kw)
         # the same reference code in float64 at the float32 run's sample positions (same jitter draw): per-tensor truth
         res64, grads64 = run_reference(cls, node, P, o, d, gt, mask, js, mods, dtype=torch.float64, t_rand=res.get("t_rand"),
-                                       z_override=res["z_vals"] if cfg.n_importance > 0 else None)
+                                       z_override=res["z_vals"] if cfg.n_importance > 0 else None, call_kw=call_kw)
         for k, v in res.items():
             fx[f"{tag}:{k}"] = v
         for k in ("loss", "grad_rays_o", "grad_rays_d", "grad_near", "grad_far"):
@@ -308,10 +317,17 @@ def rays_fixture(mods):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+ANNEAL = dict(cos_anneal_ratio=0.3, background_rgb=(0.2, 0.5, 0.7))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     Color_NeuS, NeuS, CN, mods = ref_import.import_reference()
+    if "--anneal-only" in sys.argv:   # round 5: only the two fixtures with non-default call arguments (the others are unchanged on disk)
+        e2e_fixture("tiny_sharp_anneal", O.tiny_config(), Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=True, store_weights=True, grad_stride=1, call_kw=ANNEAL, ray_seed=3)
+        e2e_fixture("dtu_sharp_anneal", O.dtu_config(), Color_NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97, call_kw=ANNEAL)
+        return
     function_fixture(CN, mods, Color_NeuS, NeuS)
     rays_fixture(mods)
     tiny = O.tiny_config()
@@ -336,6 +352,10 @@ def main():
     e2e_fixture("dtu_noimp_sharp", dtu_noimp, Color_NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97)
     neus_dtu = O.RenderConfig(type="NeuS", relight=None)  # config/NeuS_dtu.yml: idr, D_IN 9, MULTIRES_VIEW 4
     e2e_fixture("neus_dtu_sharp", neus_dtu, NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97)
+    # non-default call arguments (NeuS.py:294-302): cos_anneal_ratio = 0.3 (the iter_cos blend, Color_NeuS.py:69-78) and a background colour
+    # (Color_NeuS.py:104-106), sharp regime, tiny and DTU-size networks
+    e2e_fixture("tiny_sharp_anneal", tiny, Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=True, store_weights=True, grad_stride=1, call_kw=ANNEAL, ray_seed=3)
+    e2e_fixture("dtu_sharp_anneal", dtu, Color_NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97, call_kw=ANNEAL)
 
 
 if __name__ == "__main__":
