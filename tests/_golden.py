@@ -99,15 +99,20 @@ OUTPUT_KEYS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "g
 
 FULL_TENSOR_LIMIT = 8192   # tools/gen_golden.py stores gradient tensors up to this size in full, larger ones strided
 GRAD_TOL_MIN, GRAD_TOL_CAP, GRAD_SPREAD_FACTOR = 1e-4, 1e-3, 3.0
+# The HIP path is held RELATIVE to the float32 reference: where the reference's own float32 evaluation is further than 1e-4 from float64,
+# the product may be at most 1.5x as far (measured at C3 size: up to 1.35x on the SDF tensors, profiles/r0x_param_grad_error_table_c3.txt;
+# a regression of the split-f16 arithmetic to 2x the float32 error now fails where 3x used to pass).
+STRICT_SPREAD_FACTOR = 1.5
 
 
-def grad_tolerance(spread):
+def grad_tolerance(spread, strict=False):
     """Relative tolerance (own scale: |err|_max / |tensor|_max) of one parameter-gradient tensor against the float64 reference.
 
     1e-4 (north_star) for every tensor, widened only where the REFERENCE's own float32 evaluation is further than that from its
     float64 evaluation of the same code at the same sample positions (``gspread`` in the fixture, measured per tensor by
-    tools/gen_golden.py): there 3x the reference's own round-off, never more than 1e-3 of the tensor's own largest entry."""
-    return min(GRAD_TOL_CAP, max(GRAD_TOL_MIN, GRAD_SPREAD_FACTOR * float(spread)))
+    tools/gen_golden.py): there 3x the reference's own round-off (strict, the HIP path: 1.5x), never more than 1e-3 of the tensor's own
+    largest entry."""
+    return min(GRAD_TOL_CAP, max(GRAD_TOL_MIN, (STRICT_SPREAD_FACTOR if strict else GRAD_SPREAD_FACTOR) * float(spread)))
 
 
 GRAD_OUTLIER_FRAC = 0.25    # share of a tensor's entries that may exceed the bulk tolerance (never the cap), see check_param_grads
@@ -150,7 +155,7 @@ def param_grad_table(fx, tag, grads, strict=False):
         gabs = max(float(fx[f"{tag}:gabs64:{k}"]), 1e-300)
         sum_err = abs(float(full.sum()) - float(fx[f"{tag}:gsum64:{k}"])) / gabs
         abs_err = abs(float(full.abs().sum()) - float(fx[f"{tag}:gabs64:{k}"])) / gabs
-        lim = grad_tolerance(fx[f"{tag}:gspread:{k}"])
+        lim = grad_tolerance(fx[f"{tag}:gspread:{k}"], strict)
         allowed = _allowed(e.size, strict)
         bulk = float(np.sort(e)[-(allowed + 1)]) if e.size > allowed else 0.0
         rows.append((k, full.numel(), err64, err32, lim, sum_err, abs_err, int((e > lim).sum()), bulk))
@@ -182,10 +187,12 @@ def check_param_grads(fx, tag, grads, tol=None, strict=False):
     return bad
 
 
-def check_grads_full(ref64, ref32, got, strict=True):
+def check_grads_full(ref64, ref32, got, strict=True, rel_max=None):
     """EVERY entry of every gradient tensor (no stride) against a float64 evaluation ``ref64`` (name -> tensor) of the same algorithm
     at the same inputs -- the oracle run live by the GPU tests; ``ref32`` is its float32 evaluation, whose distance from float64
-    calibrates the per-tensor tolerance exactly like the fixtures' ``gspread``.  Same rule as check_param_grads.  Returns offenders."""
+    calibrates the per-tensor tolerance exactly like the fixtures' ``gspread``.  Same rule as check_param_grads.  Returns offenders.
+    ``rel_max`` (full-size batches, where one ReLU kink no longer moves an entry): in addition the LARGEST error of every tensor must be
+    within max(1e-4, rel_max x the float32 oracle's largest error on that tensor)."""
     bad = []
     cap = _gate(strict)[2]
     for k, r64 in ref64.items():
@@ -193,11 +200,14 @@ def check_grads_full(ref64, ref32, got, strict=True):
         den = max(float(r64.abs().max()), 1e-300)
         e = (got[k].detach().cpu().double().reshape(-1) - r64).abs() / den
         spread = float((ref32[k].detach().double().reshape(-1) - r64).abs().max()) / den
-        lim = min(cap, grad_tolerance(spread))
+        lim = min(cap, grad_tolerance(spread, strict))
         allowed = _allowed(e.numel(), strict)
         bulk = float(torch.sort(e).values[-(allowed + 1)]) if e.numel() > allowed else 0.0
-        if not (float(e.max()) <= cap and bulk <= lim):
-            bad.append((k, float(e.max()), bulk, lim, int((e > lim).sum())))
+        ok = float(e.max()) <= cap and bulk <= lim
+        if rel_max is not None:
+            ok = ok and float(e.max()) <= max(GRAD_TOL_MIN, rel_max * spread)
+        if not ok:
+            bad.append((k, float(e.max()), bulk, lim, int((e > lim).sum()), spread))
     return bad
 
 
@@ -210,7 +220,7 @@ def check_input_grad(fx, tag, key, got, strict=False):
     spread = float(np.abs(ref32.astype(np.float64) - ref64).max()) / den
     e = np.abs(torch.as_tensor(got).detach().cpu().double().numpy().reshape(ref64.shape) - ref64).reshape(-1) / den
     cap = _gate(strict)[2]
-    lim = min(cap, grad_tolerance(spread))
+    lim = min(cap, grad_tolerance(spread, strict))
     allowed = max(1, _allowed(e.size, strict))
     bulk = float(np.sort(e)[-(allowed + 1)])
     if float(e.max()) <= cap and bulk <= lim:

@@ -72,7 +72,7 @@ def _run(library, device, name="tiny_sharp", cos_anneal=0.3, bg=(0.2, 0.5, 0.7),
         spread = float((g32[k].double().reshape(-1) - r64).abs().max()) / den
         allowed = G._allowed(e.numel(), strict)
         bulk = float(torch.sort(e).values[-(allowed + 1)]) if e.numel() > allowed else 0.0
-        lim = min(G.STRICT_TOL_CAP, G.grad_tolerance(spread)) if strict else 5e-4
+        lim = min(G.STRICT_TOL_CAP, G.grad_tolerance(spread, strict)) if strict else 5e-4
         cap = KINK_CAP if (strict or k.split(".")[0] in ("color_network", "relight_network", "sdf_network", "deviation_network")) else 2e-4
         if not (float(e.max()) <= cap and bulk <= lim):
             bad["grad:" + k] = (float(e.max()), bulk, lim)

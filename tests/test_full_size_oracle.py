@@ -59,15 +59,16 @@ def test_c3_full_size_against_live_float64_oracle():
     z32 = O.sample_z(P, ocfg, o, d, near, far, t_rand)
     # The sampler amplifies last-bit differences: on a handful of rays a searchsorted / denom < 1e-5 decision flips and the
     # samples of one up-sampling step move by a fraction of a coarse section.  The band is measured here on the same batch from the oracle
-    # itself (float32 against float64: 7 rays of these 1024 beyond 1e-3, largest deviation 0.0154); the HIP sampler must stay inside it:
-    # every other ray within 1e-3 (the fixture-size gate), no sample further off than one coarse section (2 / N_SAMPLES).
+    # itself (float32 against float64: 5-7 rays of these 1024 beyond 1e-3, largest deviation 0.0154); the HIP sampler must stay inside it:
+    # at most max(6, 2 x band) rays beyond 1e-3 (measured: 4), no sample further off than HALF a coarse section (1 / N_SAMPLES = 0.0156;
+    # measured 0.0071).
     P64 = {k: v.double() for k, v in P.items()}
     z64 = O.sample_z(P64, ocfg, o.double(), d.double(), near.double(), far.double(), t_rand.double())
     band = int(((z32.double() - z64).abs().max(1).values > 1e-3).sum())
     dz = (z_hip - z32).abs()
     moved = int((dz.max(1).values > 1e-3).sum())
-    assert moved <= max(10, 3 * band), (moved, band)
-    assert float(dz.max()) <= 2.0 / ocfg.n_samples, float(dz.max())
+    assert moved <= max(6, 2 * band), (moved, band)
+    assert float(dz.max()) <= 1.0 / ocfg.n_samples, float(dz.max())
     assert bool((z_hip[:, 1:] >= z_hip[:, :-1]).all())
     # G2 at full size, identical z
     t0 = time.time()
@@ -106,11 +107,12 @@ def test_c3_full_size_against_live_float64_oracle():
         den = max(float(r64.abs().max()), 1e-300)
         e = (got[k].detach().cpu().double().reshape(-1) - r64).abs() / den
         spread = float((g32[k].double().reshape(-1) - r64).abs().max()) / den
-        lim = min(cap, G.grad_tolerance(spread))
+        lim = min(cap, G.grad_tolerance(spread, True))
         allowed = G._allowed(e.numel(), True)
         bulk = float(torch.sort(e).values[-(allowed + 1)]) if e.numel() > allowed else 0.0
         lines.append("%-44s %10d %12.2e %12.2e %12.2e %10.1e %8d" % (k, e.numel(), float(e.max()), bulk, spread, lim, int((e > lim).sum())))
-    bad += G.check_grads_full(g64, g32, got, strict=True)
+    # strict rule + at this size the LARGEST error of every tensor within max(1e-4, 1.5 x the float32 oracle's largest error on it)
+    bad += G.check_grads_full(g64, g32, got, strict=True, rel_max=G.STRICT_SPREAD_FACTOR)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
@@ -118,4 +120,73 @@ def test_c3_full_size_against_live_float64_oracle():
             f.write("\n".join(lines) + "\n")
     except OSError:
         pass
+    assert not bad, bad
+
+
+def test_c4_4096_rays_ray_separable_objective_against_float64_oracle_in_quarters():
+    """BASELINE config C4's batch (4096 rays x 128 samples) on ONE GPU against float64: a random linear functional of the per-ray outputs
+    (color_fine, weight_sum, depth, global_color, weights, gradients, delta_relight) is a sum over rays, so the float64 oracle can evaluate it
+    in four 1024-ray quarters (the host-memory footprint of the C3 test) whose parameter gradients add up to the gradient of the whole
+    batch -- the native path runs the 4096 rays as ONE call (128 tiles per point range in the fused layer + weight-gradient launches, the
+    full partial-sum pool).  Every entry of all 53 parameter gradients and d rays under the strict rule, the largest error of each tensor
+    within max(1e-4, 1.5 x the float32 oracle's)."""
+    R, Q = 4096, 4
+    O, ocfg, P, o, d, near, far, t_rand, gt, mask = _batch(R, seed=41)
+    keys = ["color_fine", "weight_sum", "depth", "global_color", "weights", "gradients", "delta_relight"]
+    g = torch.Generator().manual_seed(77)
+    M = ocfg.n_samples + ocfg.n_importance
+    shapes = {"color_fine": (R, 3), "weight_sum": (R, 1), "depth": (R,), "global_color": (R, 3), "weights": (R, M), "gradients": (R, M, 3),
+              "delta_relight": (R, M, 3)}
+    # cotangents at the scale the training loss gives these outputs (1 / R per ray; per-sample outputs another 1 / M) so that no single
+    # sample dominates an entry
+    coefs = {k: torch.randn(shapes[k], generator=g, dtype=torch.float64) / R / (M if len(shapes[k]) > 1 and shapes[k][1] == M else 1) for k in keys}
+    t0 = time.time()
+    z32 = torch.cat([O.sample_z(P, ocfg, o[a:a + R // Q], d[a:a + R // Q], near[a:a + R // Q], far[a:a + R // Q], t_rand[a:a + R // Q]) for a in range(0, R, R // Q)])
+    tot = {torch.float64: None, torch.float32: None}
+    vals = {torch.float64: 0.0, torch.float32: 0.0}
+    for dt in (torch.float64, torch.float32):
+        acc, dro, drd = None, [], []
+        for a in range(0, R, R // Q):
+            sl = slice(a, a + R // Q)
+            Pd = {k: v.to(dt).clone().requires_grad_(True) for k, v in P.items()}
+            od, dd = o[sl].to(dt).clone().requires_grad_(True), d[sl].to(dt).clone().requires_grad_(True)
+            out = O.render(Pd, ocfg, od, dd, near[sl].to(dt), far[sl].to(dt), z_vals=z32[sl].to(dt))
+            L = sum((out[k].reshape(coefs[k][sl].shape) * coefs[k][sl].to(dt)).sum() for k in keys)
+            L.backward()
+            vals[dt] += float(L.detach())
+            gq = {k: v.grad.detach().double() for k, v in Pd.items()}
+            acc = gq if acc is None else {k: acc[k] + gq[k] for k in acc}
+            dro.append(od.grad.detach().double()); drd.append(dd.grad.detach().double())
+            del out, L, Pd
+        acc["rays_o"], acc["rays_d"] = torch.cat(dro), torch.cat(drd)
+        tot[dt] = acc
+    t_oracle = time.time() - t0
+    r = N.make_renderer(ocfg, P, None, DEV)
+    og, dg = o.to(DEV).requires_grad_(True), d.to(DEV).requires_grad_(True)
+    out = r(og, dg, near.to(DEV), far.to(DEV), z_vals=z32.to(DEV))
+    L = sum((out[k].reshape(shapes[k]) * coefs[k].float().to(DEV)).sum() for k in keys)
+    L.backward()
+    assert abs(float(L.detach()) - vals[torch.float64]) < 1e-4 * max(abs(vals[torch.float64]), 1e-3), (float(L.detach()), vals)
+    got = {(k[len("renderer."):] if k.startswith("renderer.") else k): p.grad for k, p in r.named_parameters()}
+    got["rays_o"], got["rays_d"] = og.grad, dg.grad
+    g64, g32 = tot[torch.float64], tot[torch.float32]
+    lines = ["# C4 batch on one GPU (4096 rays x 128 samples as ONE call) vs the float64 oracle in four 1024-ray quarters, ray-separable random functional",
+             "# oracle float64 + float32 runs on the host: %.1f s" % t_oracle,
+             "%-44s %10s %12s %12s %12s" % ("gradient", "numel", "err_max", "err_bulk(1%)", "f32_oracle")]
+    for k, r64 in g64.items():
+        r64 = r64.reshape(-1)
+        den = max(float(r64.abs().max()), 1e-300)
+        e = (got[k].detach().cpu().double().reshape(-1) - r64).abs() / den
+        spread = float((g32[k].reshape(-1) - r64).abs().max()) / den
+        allowed = G._allowed(e.numel(), True)
+        bulk = float(torch.sort(e).values[-(allowed + 1)]) if e.numel() > allowed else 0.0
+        lines.append("%-44s %10d %12.2e %12.2e %12.2e" % (k, e.numel(), float(e.max()), bulk, spread))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "param_grad_error_table_c4.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    bad = G.check_grads_full(g64, g32, got, strict=True, rel_max=G.STRICT_SPREAD_FACTOR)
     assert not bad, bad

@@ -262,7 +262,7 @@ def test_parameter_gradients_against_float64_oracle_larger_batch():
         den = float(gr.abs().max())
         e = ((got[name].grad.detach().cpu().double() - gr).abs() / den).reshape(-1)
         spread = float((P32[k].grad.double() - gr).abs().max()) / den
-        lim = min(G.STRICT_TOL_CAP, G.grad_tolerance(spread))
+        lim = min(G.STRICT_TOL_CAP, G.grad_tolerance(spread, True))
         allowed = G._allowed(e.numel(), True)
         bulk = float(torch.sort(e).values[-(allowed + 1)]) if e.numel() > allowed else 0.0
         if not (float(e.max()) <= G.STRICT_TOL_CAP and bulk <= lim):   # own scale: hard cap on every entry + bulk tolerance (tests/_golden.py, strict gate)
