@@ -388,27 +388,42 @@ def main():
         result["loss_only"] = {"unit": "rays/s", "rays_per_step_per_gpu": lo,
                                "note": "same step (fwd + fused loss + bwd + clip + Adam) with renderer(..., training_outputs='loss_only')"}
 
-    # ---- inference use of the path (validate_image, NeuS_Trainer.py:216-277): forward only, EVAL-style chunks, without / with the
-    # early-termination compaction (colour / relight stacks only on samples with weight >= eps: ballot + popcount compaction, inference only)
+    # ---- inference use of the path (validate_image, NeuS_Trainer.py:216-277): forward only, EVAL-style chunks.  Under torch.no_grad() the module
+    # takes the library's forward-only entry point (cnr_render_forward_only: bit-identical values, nothing kept for a backward pass); reported
+    # next to it: the saving forward on the same rays (what an inference call cost before round 5) and the early-termination compaction
+    # (colour / relight stacks only on samples with weight >= eps: ballot + popcount index list, chain-fused launch reads its rows through it)
     if not args.no_inference and rank == 0:
         Ri = 8192
         o, d, near, far, _, _ = batch(0, Ri)
         inf = {}
         with torch.no_grad():
-            ref = renderer(o, d, near, far, perturb_overwrite=0)
-            for eps in (0.0, 1e-4):
+            ref = renderer(o, d, near, far, perturb_overwrite=0, forward_only=False)
+            for tag, kw in (("saving_forward", dict(forward_only=False)), ("prune_eps_0", dict()), ("prune_eps_0.0001", dict(prune_eps=1e-4))):
                 for _ in range(2):
-                    out = renderer(o, d, near, far, perturb_overwrite=0, prune_eps=eps)
+                    out = renderer(o, d, near, far, perturb_overwrite=0, **kw)
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
                 for _ in range(5):
-                    out = renderer(o, d, near, far, perturb_overwrite=0, prune_eps=eps)
+                    out = renderer(o, d, near, far, perturb_overwrite=0, **kw)
                 torch.cuda.synchronize(dev)
                 dti = (time.perf_counter() - t1) / 5
-                inf["prune_eps_%g" % eps] = {"rays_per_s": round(Ri / dti, 1), "ms": round(dti * 1e3, 2),
-                                             "kept_fraction": round(float((out["weights"] >= eps).float().mean()), 3) if eps > 0 else 1.0,
-                                             "max_abs_color_diff": float((out["color_fine"] - ref["color_fine"]).abs().max())}
-        result["inference"] = {"unit": "rays/s", "sample": "5 forward passes of %d rays x 128 samples, no jitter, DTU renderer block" % Ri, **inf}
+                eps = kw.get("prune_eps", 0.0)
+                inf[tag] = {"rays_per_s": round(Ri / dti, 1), "ms": round(dti * 1e3, 2),
+                            "kept_fraction": round(float((out["weights"] >= eps).float().mean()), 3) if eps > 0 else 1.0,
+                            "max_abs_color_diff": float((out["color_fine"] - ref["color_fine"]).abs().max())}
+            lib.timing_enable(True)
+            renderer(o, d, near, far, perturb_overwrite=0)
+            torch.cuda.synchronize(dev)
+            recs = lib.timing_collect()
+            lib.timing_enable(False)
+            fam = {}
+            for name, kind, nt, P_, N_, K_, pairs, ms, nbytes in recs:
+                fam[name] = round(fam.get(name, 0.0) + ms, 4)
+            inf["forward_only_kernel_ms"] = dict(sorted(fam.items(), key=lambda kv: -kv[1])[:8])
+            inf["scratch_GB"] = {"forward_only": round(lib.lib.cnr_infer_scratch_bytes(__import__("ctypes").byref(renderer._ccfg), Ri) / 1e9, 2),
+                                 "saving": round(lib.lib.cnr_ctx_bytes(__import__("ctypes").byref(renderer._ccfg), Ri) / 1e9, 2)}
+        result["inference"] = {"unit": "rays/s", "sample": "5 forward passes of %d rays x 128 samples, no jitter, DTU renderer block; prune_eps_0 = the forward-only "
+                                                           "entry point (what a no_grad call takes), saving_forward = cnr_render_forward on the same rays" % Ri, **inf}
 
     # ---- BASELINE config 5 (evaluation.py -rr 512): dense SDF lattice + device marching cubes + vertex colours, one pass each
     if not args.no_c5 and rank == 0:

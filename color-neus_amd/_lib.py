@@ -94,7 +94,7 @@ def c_config(cfg) -> CnrConfig:
 
 
 EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_count", "cnr_param_info", "cnr_ctx_bytes",
-           "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
+           "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_infer_scratch_bytes", "cnr_render_forward_only", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_sdf_grid_slab_scratch_bytes", "cnr_sdf_grid_slab", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
            "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_sums_ray", "cnr_loss_grads", "cnr_loss_combine", "cnr_loss_coef", "cnr_loss_forward", "cnr_loss_backward", "cnr_loss_shard_stats", "cnr_loss_shard_combine",
            "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward", "cnr_sample_z", "cnr_mc_scratch_bytes", "cnr_mc_count", "cnr_mc_emit",
@@ -118,13 +118,15 @@ class RenderLibrary:
         L.cnr_last_error.restype = C.c_char_p
         L.cnr_param_count.argtypes = [C.POINTER(CnrConfig)]
         L.cnr_param_info.argtypes = [C.POINTER(CnrConfig), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        for f in ("cnr_ctx_bytes", "cnr_bwd_scratch_bytes", "cnr_sdf_eval_scratch_bytes", "cnr_vertex_color_scratch_bytes"):
+        for f in ("cnr_ctx_bytes", "cnr_bwd_scratch_bytes", "cnr_infer_scratch_bytes", "cnr_sdf_eval_scratch_bytes", "cnr_vertex_color_scratch_bytes"):
             getattr(L, f).restype = C.c_size_t
             getattr(L, f).argtypes = [C.POINTER(CnrConfig), C.c_int64]
         L.cnr_sdf_grid_scratch_bytes.restype = C.c_size_t
         L.cnr_sdf_grid_scratch_bytes.argtypes = [C.POINTER(CnrConfig), C.c_int32]
         L.cnr_render_forward.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(CnrInputs), C.POINTER(CnrOutputs),
                                          _FP, C.c_size_t, _FP]
+        L.cnr_render_forward_only.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(CnrInputs), C.POINTER(CnrOutputs),
+                                              _FP, C.c_size_t, _FP]
         L.cnr_render_backward.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(CnrInputs), C.POINTER(CnrOutputs),
                                           _FP, C.c_size_t, C.POINTER(CnrOutGrads), C.POINTER(CnrInGrads), _FP, C.c_size_t, _FP]
         L.cnr_sdf_eval.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), _FP, C.c_int64, C.c_float, _FP, _FP, C.c_size_t, _FP]

@@ -109,8 +109,11 @@ struct PruneScan { const int* counts; long R; int* offsets /*[R+1]*/; };
 struct PruneGather {
   const float* weights; long R; int M; float eps; const int* offsets;
   int* idx;                                       // [kept] original point index
-  const float* featx; int ldfx; float* featx_c;   // rows gathered to the compact list
+  const float* featx; int ldfx; float* featx_c;   // rows gathered to the compact list (featx_c null: index list only)
   const float* aux; float* aux_c;                 // [.][kAux]
+  // index-list form (forward-only render, chain-fused ReLU stacks read their rows through idx): the per-sample outputs of the DROPPED samples
+  // are zeroed here instead of by three memsets over the whole buffers
+  float* zero_gcol = nullptr; float* zero_relit = nullptr; float* zero_delta = nullptr;   // [P][4], [P][4] or null, [P][3] or null
 };
 struct PruneScatter {
   long P; const int* count; const int* idx;
@@ -248,8 +251,12 @@ struct ReluChainFwd {
   float* delta = nullptr;                               // [P][3] relight offsets (pre-activation)
   float* relit = nullptr;                               // [P][4] relight_apply(rgb, delta)
   int dbg = 0;                                          // ablation switches (CNR_CHAIN_FWD_DBG; wrong results): 1 no saves, 2 no MFMAs, 4 stores without the LDS pass, 8 no global stores
+  // forward-only render with early-termination compaction (inference): the chains run on the first *P_dev entries of row_idx only -- chain-start
+  // rows are read from, and the heads' outputs written to, point row_idx[i]; P is then the upper bound that sizes the launch.  No saves.
+  const int* P_dev = nullptr; const int* row_idx = nullptr;
 };
 bool be_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s);   // false: not handled (per-layer launches instead)
+bool be_relu_chain_fwd_enabled();                               // the debugging switches that turn the chain-fused ReLU forward off are not set
 
 void be_layer_gemm(const LayerGemm& g, cnr_stream s);
 // Second-order sweep launch of a narrow-input layer (K <= 48, 256 outputs) that also forms the gradient-chain weight-gradient pair of the layer

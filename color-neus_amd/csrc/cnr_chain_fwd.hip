@@ -50,7 +50,9 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // (scalar: the per-wave bases below stay in SGPRs)
   unsigned char* tb = reinterpret_cast<unsigned char*>(rgbs + T * 4) + wave * 2048;   // this wave's [16 rows][128 B] transposition buffer
   float* hp = reinterpret_cast<float*>(smem);                // [T][8][4] partial head dot products (in the planes: dead at the end of a chain)
-  const long ntiles = (c.P + T - 1) / T;
+  const long P = c.P_dev != nullptr ? (long)*c.P_dev : c.P;   // (compacted runs: only the device knows how many rows there are)
+  const int* const ridx = c.row_idx;
+  const long ntiles = (P + T - 1) / T;
 
   f16x8 wr1[4][1], wr2[4][1];                                // weight fragment ring: 4 k16 blocks in flight
   auto wlane_of = [&](const ChainFwdStep& S, int lane_) __attribute__((always_inline)) { return S.Wf + (long)wave * S.nkb_w * 1024 + lane_ * 8; };
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
       if (S.in != nullptr) {
         const int ncol = 16 * S.nkb_main, xcol = S.x_src == 1 ? 16 * S.nkb_x : 0;
         const long tile0 = tile * T;
-        const int rows_left = (int)((c.P - tile0) < T ? (c.P - tile0) : T);          // rows of this tile that exist (>= 1)
-        const float* in_tile = S.in + tile0 * S.ld_in;                               // (uniform: scalar base + 32-bit lane offsets)
+        const int rows_left = (int)((P - tile0) < T ? (P - tile0) : T);              // rows of this tile that exist (>= 1)
+        const float* in_tile = S.in + (ridx != nullptr ? 0 : tile0 * S.ld_in);       // (uniform: scalar base + 32-bit lane offsets)
         // all loads of the RT row groups first (one exposed memory round trip per chain start, not RT), then the conversion
         const int sc4 = (tid & 15) * 4;
         const f4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
         for (int pass = 0; pass < RT; ++pass) {
           const int row_l = pass * 32 + (tid >> 4);
           const int row_c = row_l < rows_left ? row_l : rows_left - 1;               // rows past the end read the last row (never stored)
-          const float* src = in_tile + row_c * S.ld_in;
+          const float* src = ridx != nullptr ? in_tile + (long)ridx[tile0 + row_c] * S.ld_in : in_tile + row_c * S.ld_in;
           v0[pass] = z4; v1[pass] = z4; v2[pass] = z4; v3[pass] = z4; vx[pass] = z4;
           if (sc4 < ncol) v0[pass] = *reinterpret_cast<const f4*>(src + sc4);
           if (64 + sc4 < ncol) v1[pass] = *reinterpret_cast<const f4*>(src + 64 + sc4);
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
           if (wave == 0 && half == 0) {
             rs[row_l] = 1.0f / sc; rsf[row_l] = sc;
             const long grow = tile * T + row_l;
-            if (Sn.rs_in != nullptr && grow < c.P) Sn.rs_in[grow] = chain_rs_value(mx, sc);
+            if (Sn.rs_in != nullptr && grow < P) Sn.rs_in[grow] = chain_rs_value(mx, sc);
           }
         }
       }
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
       // ---- the ReLU output rows for the backward pass: 32 x 32 block -> LDS (16 rows at a time) -> 8 rows x 128 contiguous bytes per store
       if (S.save != nullptr && !(c.dbg & 1)) {
         const long tile0 = tile * T;
-        const int rows_left = (int)((c.P - tile0) < T ? (c.P - tile0) : T);
+        const int rows_left = (int)((P - tile0) < T ? (P - tile0) : T);
         float* save_tile = S.save + tile0 * S.ld_save + wave * 32;                   // (uniform)
         const int sv_off = (lane >> 3) * S.ld_save + (lane & 7) * 4;                 // this lane's row / 16-byte chunk within an 8-row group
 #pragma unroll
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
         if (tid < T) {
           const int row_l = tid;
           const long grow = tile * T + row_l;
+          const long orow = (ridx != nullptr && grow < P) ? (long)ridx[grow] : grow;   // where this row's head outputs go
           float v[3];
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
@@ -295,25 +298,25 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
             if (H.n > 1) y.y = c.col_squeeze ? sigmoidf_(v[1]) : v[1];
             if (H.n > 2) y.z = c.col_squeeze ? sigmoidf_(v[2]) : v[2];
             *reinterpret_cast<f4*>(rgbs + row_l * 4) = y;
-            if (grow < c.P) {
-              float* g = c.gcol + grow * 4;
+            if (grow < P) {
+              float* g = c.gcol + orow * 4;
               g[0] = y.x;
               if (H.n > 1) g[1] = y.y;
               if (H.n > 2) g[2] = y.z;
               if (c.rgb_tail != nullptr) {
                 const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-                f4* t = reinterpret_cast<f4*>(c.rgb_tail + grow * c.ld_tail);
+                f4* t = reinterpret_cast<f4*>(c.rgb_tail + orow * c.ld_tail);
                 t[0] = y; t[1] = z4; t[2] = z4; t[3] = z4;
               }
             }
-          } else if (grow < c.P) {
+          } else if (grow < P) {
             const f4 rgb = *reinterpret_cast<const f4*>(rgbs + row_l * 4);
             const float rv[3] = {rgb.x, rgb.y, rgb.z};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
               if (j < H.n) {
-                c.delta[grow * 3 + j] = v[j];
-                c.relit[grow * 4 + j] = relight_apply(rv[j], v[j], c.inv_sigmoid);
+                c.delta[orow * 3 + j] = v[j];
+                c.relit[orow * 4 + j] = relight_apply(rv[j], v[j], c.inv_sigmoid);
               }
             }
           }
@@ -897,8 +900,14 @@ static void launch_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
   hipLaunchKernelGGL((relu_chain_fwd_kernel<RT>), dim3(grid), dim3(512), lds, s, cc);
 }
 
-bool be_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
+bool be_relu_chain_fwd_enabled() {
   static const bool off = getenv("CNR_NO_FUSED") != nullptr || getenv("CNR_NO_CHAIN_FWD") != nullptr;   // debugging aids: per-layer launches
+  return !off;
+}
+
+bool be_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
+  const bool off = !be_relu_chain_fwd_enabled();
+  if ((c.row_idx != nullptr) != (c.P_dev != nullptr)) return false;
   if (off || c.P <= 0 || c.nsteps < 1 || c.nsteps > kChainSteps) return false;
   for (int i = 0; i < c.nsteps; ++i) {
     const ChainFwdStep& S = c.st[i];
@@ -909,6 +918,7 @@ bool be_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
     if (S.in != nullptr && ((S.ld_in & 3) != 0 || S.ld_in < 16 * S.nkb_main)) return false;
     if (S.x_src == 2 && S.nkb_x != 1) return false;
     if (S.save != nullptr && (S.ld_save & 3) != 0) return false;
+    if (c.row_idx != nullptr && (S.save != nullptr || S.rs_in != nullptr)) return false;   // a compacted run keeps nothing for a backward pass
     if (i == 0 && S.in == nullptr) return false;
     if (i > 0 && c.st[i - 1].head != 0 && S.in == nullptr) return false;   // a chain starts from global rows
     if (S.head == 1 && (!c.col_head.W || c.col_head.n < 1 || c.col_head.n > 3 || (c.col_head.ldw & 3) || !c.gcol || (c.rgb_tail && (c.ld_tail & 3)))) return false;

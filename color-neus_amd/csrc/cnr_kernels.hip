@@ -1574,11 +1574,19 @@ __global__ __launch_bounds__(256) void prune_gather_kernel(const PruneGather p) 
     const int pos = carry + __popcll(mask & ((1ull << lane) - 1ull));
     if (keep) list[wave][pos] = j;
     carry += __popcll(mask);
+    if (j < p.M && !keep && p.zero_gcol) {   // a dropped sample contributes nothing: its colour outputs read as zero
+      const long pt = ray * p.M + j;
+      const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f4*>(p.zero_gcol)[pt] = z4;
+      if (p.zero_relit) reinterpret_cast<f4*>(p.zero_relit)[pt] = z4;
+      if (p.zero_delta) { p.zero_delta[pt * 3] = 0.f; p.zero_delta[pt * 3 + 1] = 0.f; p.zero_delta[pt * 3 + 2] = 0.f; }
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int off = p.offsets[ray];
   for (int k = lane; k < carry; k += 64) p.idx[off + k] = (int)(ray * p.M + list[wave][k]);
+  if (p.featx_c == nullptr) return;
   const int nf4 = p.ldfx / 4;
   for (int k = 0; k < carry; ++k) {
     const long src = ray * p.M + list[wave][k];

@@ -414,6 +414,7 @@ void be_clip_adam(const AdamArgs& a, cnr_stream) {
 void be_pack_frags_many(const PackJob*, int, cnr_stream) {}
 bool be_sdf_value_chain(const SdfValueChain&, cnr_stream) { return false; }
 bool be_relu_chain_fwd(const ReluChainFwd&, cnr_stream) { return false; }
+bool be_relu_chain_fwd_enabled() { return false; }
 bool be_sdf_save_chain(const SdfSaveChain&, cnr_stream) { return false; }
 bool be_sdf_grad_chain(const SdfGradChain&, cnr_stream) { return false; }
 bool be_sweep0_ok(const LayerGemm&) { return false; }   // (nor the sweep launch that forms its layer's weight-gradient pair)
@@ -693,10 +694,18 @@ void be_prune_gather(const PruneGather& p, cnr_stream) {
     int k = p.offsets[r];
     for (int j = 0; j < p.M; ++j) {
       long pt = r * p.M + j;
-      if (!(p.weights[pt] >= p.eps)) continue;
+      if (!(p.weights[pt] >= p.eps)) {
+        if (p.zero_gcol) {
+          for (int c = 0; c < 4; ++c) { p.zero_gcol[pt * 4 + c] = 0.f; if (p.zero_relit) p.zero_relit[pt * 4 + c] = 0.f; }
+          if (p.zero_delta) for (int c = 0; c < 3; ++c) p.zero_delta[pt * 3 + c] = 0.f;
+        }
+        continue;
+      }
       p.idx[k] = (int)pt;
-      memcpy(p.featx_c + (long)k * p.ldfx, p.featx + pt * p.ldfx, sizeof(float) * p.ldfx);
-      memcpy(p.aux_c + (long)k * kAux, p.aux + pt * kAux, sizeof(float) * kAux);
+      if (p.featx_c) {
+        memcpy(p.featx_c + (long)k * p.ldfx, p.featx + pt * p.ldfx, sizeof(float) * p.ldfx);
+        memcpy(p.aux_c + (long)k * kAux, p.aux + pt * kAux, sizeof(float) * kAux);
+      }
       ++k;
     }
   }

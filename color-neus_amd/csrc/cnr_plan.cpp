@@ -243,6 +243,8 @@ struct Ctx {   // forward-saved state
   // sampler scratch (forward only)
   float *sE, *sZa, *sZb, *s_sdf0, *s_sdf, *s_newz, *s_newsdf;
   int ldztop;
+  bool infer = false;        // forward-only layout (cnr_render_forward_only): nothing is kept for a backward pass
+  bool infer_fused = false;  // ... and the colour / relight stacks run chain-fused (no hidden-layer buffers, compaction by an index list)
 };
 
 static int hr_ld(const Model& m, const Ctx& x, int i) { return i == m.c.rel_y_in_layer - 1 ? x.ldy : m.Hr; }
@@ -265,6 +267,92 @@ static void layout_weights(Model& m, Arena& a) {
   for (size_t l = 0; l < m.sdf.size(); ++l) place_lin(m.sdf[l], a, l + 1 < m.sdf.size());   // (hidden SDF layers: W^T fragments for the gradient chain)
   for (auto& q : m.col) place(q);
   for (auto& q : m.rel) place(q);
+}
+
+// shapes the chain-fused forward of the ReLU stacks takes (cnr_chain_fwd.hip; relu_chains_fused below repeats these checks on the real buffers)
+static bool relu_fused_shapes(const Model& m) {
+  if (m.Hc != 256 || m.F != 256 || m.NC < 2 || m.NC - 1 + (m.has_relight ? m.NR : 0) > kChainSteps) return false;
+  const int ldfx = round_up(m.F + kAux, 16);
+  for (int l = 0; l + 1 < m.NC; ++l) {
+    const Lin& q = m.col[l];
+    if (q.n != 256 || q.wpad < 256 || q.ldw > 304) return false;
+    if (l == 0 ? (q.k_int < 257 || q.k_int > 304 || q.ldw > ldfx) : (q.k_int != 256 || q.ldw != 256)) return false;
+  }
+  { const Lin& q = m.col[m.NC - 1]; if (q.n < 1 || q.n > 3 || q.k_int != 256 || (q.ldw & 3)) return false; }
+  if (m.has_relight) {
+    if (m.Hr != 256 || m.NR < 2) return false;
+    const int y = m.c.rel_y_in_layer - 1;
+    if (y < 1 || y > m.NR - 2) return false;
+    if (m.rel[0].n != 256 || m.rel[0].ldw > kAux || m.rel[0].ldw < 16) return false;
+    for (int i = 0; i + 1 < m.NR; ++i) {
+      const Lin& q = m.rel[1 + i];
+      if (q.n != 256 || q.wpad < 256) return false;
+      if (i == y ? (q.k_int < 257 || q.k_int > 259 || q.ldw != 272) : (q.k_int != 256 || q.ldw != 256)) return false;
+    }
+    const Lin& q = m.rel[m.NR];
+    if (q.n < 1 || q.n > 3 || q.k_int != 256 || (q.ldw & 3) || q.n != m.col[m.NC - 1].n) return false;
+  }
+  return true;
+}
+
+// Forward-only layout (cnr_render_forward_only): the same buffers as layout_ctx for everything the forward kernels exchange, but nothing that
+// only the backward pass reads: two ping-pong buffers instead of the L - 1 saved V_l, no row scales, the hidden layers of the ReLU stacks
+// not at all when they run chain-fused (two ping-pong buffers + the relight y-layer's input otherwise), compact copies for the
+// early-termination compaction only where the per-layer chains need them (the chain-fused form reads rows through the index list).
+static void layout_ctx_infer(Model& m, long R, Arena& a, Ctx& x) {
+  const long P = R * m.M;
+  x.infer = true;
+  x.infer_fused = relu_fused_shapes(m) && be_relu_chain_fwd_enabled();
+  layout_weights(m, a);
+  x.E = a.f((size_t)P * kEmb);
+  x.AUX = a.f((size_t)P * kAux);
+  x.sdf = a.f(P);
+  x.ldfx = round_up(m.F + kAux, 16);
+  x.featx = a.f((size_t)P * x.ldfx);
+  x.ldy = m.has_relight ? m.Hr + 16 : 0;
+  x.CE0 = a.f((size_t)P * kEmb);
+  x.CES = a.f((size_t)P * kEmb);
+  x.gcol = a.f((size_t)P * 4);
+  x.relit = a.f((size_t)P * 4);
+  x.eik_partial = a.f((size_t)R * 2);
+  x.eik_sums = a.f(64);
+  x.gbuf = a.f((size_t)P * 3);
+  x.delta_s = m.has_relight ? a.f((size_t)P * 3) : nullptr;
+  x.Z.resize(m.L); x.V.resize(m.L);
+  for (int l = 0; l < m.L; ++l) x.Z[l] = a.f((size_t)P * m.Hs);
+  float* vpp[2] = {m.L >= 2 ? a.f((size_t)P * m.Hs) : nullptr, m.L >= 3 ? a.f((size_t)P * m.Hs) : nullptr};
+  for (int l = 0; l + 1 < m.L; ++l) x.V[l] = vpp[l & 1];        // the gradient chain's launch l reads V[l] and writes V[l - 1]
+  if (m.L >= 1) x.V[m.L - 1] = nullptr;
+  x.HC.assign(m.NC - 1, nullptr);
+  x.HR.assign(m.NR, nullptr);
+  x.hry = nullptr;
+  x.featx_c = x.aux_c = x.gcol_c = x.relit_c = x.delta_c = nullptr;
+  if (!x.infer_fused) {
+    const int hw = m.Hc > m.Hr ? m.Hc : m.Hr;
+    float* hpp[2] = {a.f((size_t)P * hw), a.f((size_t)P * hw)};
+    x.hry = m.has_relight ? a.f((size_t)P * x.ldy) : nullptr;
+    for (int l = 0; l + 1 < m.NC; ++l) x.HC[l] = hpp[l & 1];
+    for (int i = 0; i < m.NR; ++i) x.HR[i] = (i == m.c.rel_y_in_layer - 1) ? x.hry : hpp[i & 1];
+    x.featx_c = a.f((size_t)P * x.ldfx);
+    x.aux_c = a.f((size_t)P * kAux);
+    x.gcol_c = a.f((size_t)P * 4);
+    x.relit_c = a.f((size_t)P * 4);
+    x.delta_c = a.f((size_t)P * 4);
+  }
+  const long Ps = R * m.S;
+  x.sE = a.f((size_t)Ps * kEmb);
+  x.sZa = a.f((size_t)Ps * m.Hs);
+  x.sZb = a.f((size_t)Ps * m.Hs);
+  x.s_sdf0 = a.f(Ps);
+  x.s_sdf = a.f((size_t)R * m.M);
+  x.s_newz = a.f((size_t)R * 64);
+  x.s_newsdf = a.f((size_t)R * 64);
+  x.p_idx = reinterpret_cast<int*>(a.f(P));
+  x.p_counts = reinterpret_cast<int*>(a.f(R));
+  x.p_offsets = reinterpret_cast<int*>(a.f(R + 1));
+  x.ldztop = round_up(m.F + 1, 16);
+  x.rsY.assign(m.L + 1, nullptr); x.rsX1.assign(m.L, nullptr); x.rsC.assign(m.NC, nullptr); x.rsR.assign(m.NR, nullptr);
+  a.f(1024);   // slack (see layout_ctx)
 }
 
 static void layout_ctx(Model& m, long R, Arena& a, Ctx& x) {
@@ -602,11 +690,11 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
   // V[l-1] of a skip layer is written over n < round_up(n,16) columns only (EK_SPLIT) but read back over the padded width by the
   // next GEMM of this chain: its pad columns must hold finite values whatever the caller's scratch contained (every user of the
   // chain -- render, vertex colour -- gets this here rather than at the call site)
-  for (int l = 1; l < m.L; ++l)
-    if (m.skip(l) && V[l - 1] && round_up(m.sdf[l - 1].n, 16) > m.sdf[l - 1].n)
-      be_zero_cols(V[l - 1], m.Hs, m.sdf[l - 1].n, round_up(m.sdf[l - 1].n, 16), P, s);
+  // (zeroed right in front of the launch that leaves them unwritten: the forward-only layout reuses two V buffers for all layers)
   for (int l = m.L - 1; l >= 0; --l) {
     const Lin& q = m.sdf[l];
+    if (l >= 1 && m.skip(l) && V[l - 1] && round_up(m.sdf[l - 1].n, 16) > m.sdf[l - 1].n)
+      be_zero_cols(V[l - 1], m.Hs, m.sdf[l - 1].n, round_up(m.sdf[l - 1].n, 16), P, s);
     LayerGemm g;
     g.A.a = Z[l]; g.A.lda = m.Hs;
     if (l == m.L - 1) { g.A.kind = VK_SIGMUL_ROW; g.A.b = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; g.A.scale = inv_scale; }   // v_{L-1} = W_top[0,:]/scale
@@ -708,10 +796,10 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
 
 // Colour chain + relight chain as ONE chain-fused launch (cnr_chain_fwd.hip) where the shapes allow: 256-wide hidden layers, a 256-wide
 // feature vector, heads of <= 3 outputs.  Returns false (nothing launched) otherwise: the per-layer chains above then run.
-static bool relu_chains_fused(const Model& m, long P, const Ctx& x, float* delta_out, cnr_stream s) {
+static bool relu_chains_fused(const Model& m, long P, const Ctx& x, float* delta_out, cnr_stream s, const int* P_dev = nullptr, const int* row_idx = nullptr) {
   if (m.Hc != 256 || m.F != 256 || m.NC < 2 || m.NC - 1 + (m.has_relight ? m.NR : 0) > kChainSteps) return false;
   ReluChainFwd c;
-  c.P = P;
+  c.P = P; c.P_dev = P_dev; c.row_idx = row_idx;
   auto hidden_ok = [](const Lin& q, int k_lo, int k_hi) { return q.n == 256 && q.Wf && q.wpad >= 256 && q.k_int >= k_lo && q.k_int <= k_hi; };
   auto head_ok = [](const Lin& q) { return q.n >= 1 && q.n <= 3 && q.k_int == 256 && (q.ldw & 3) == 0; };
   auto fill = [](ChainFwdStep& st, const Lin& q) { st.Wf = q.Wf; st.wsc = q.Wps; st.bias = q.bias; st.nkb_w = q.ldw / 16; };
@@ -738,7 +826,7 @@ static bool relu_chains_fused(const Model& m, long P, const Ctx& x, float* delta
     c.col_head = ChainFwdHead{q.W, q.ldw, q.bias, q.n};
     c.col_squeeze = m.c.col_squeeze_out ? 1 : 0;
     c.gcol = x.gcol;
-    if (m.has_relight) { c.rgb_tail = x.hry + m.Hr; c.ld_tail = x.ldy; }
+    if (m.has_relight && x.hry) { c.rgb_tail = x.hry + m.Hr; c.ld_tail = x.ldy; }   // (forward-only: the y-layer takes rgb from the chip, no tail is kept)
   }
   if (m.has_relight) {
     if (m.Hr != 256 || m.NR < 2) return false;
@@ -781,8 +869,10 @@ static int check_backend(const char* what) {
   return 0;
 }
 
+// infer: the forward-only form (cnr_render_forward_only): same launches for everything that produces a value -- outputs are bit-identical --
+// but nothing is written for a backward pass (no row scales, no hidden activations of the ReLU stacks, no V_l beyond the one in flight)
 static int render_forward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
-                          const cnr_render_outputs* out, void* ctx, size_t ctx_bytes, cnr_stream s) {
+                          const cnr_render_outputs* out, void* ctx, size_t ctx_bytes, cnr_stream s, bool infer = false) {
   Model m;
   if (build_model(cfg, m)) return -1;
   if (!params || !in || !out || !ctx) return fail("null argument");
@@ -790,14 +880,15 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   if (R <= 0) return fail("n_rays must be positive");
   Arena a(ctx);
   Ctx x;
-  layout_ctx(m, R, a, x);
-  if (a.off > ctx_bytes) return fail("context buffer too small: need %zu bytes, got %zu", a.off, ctx_bytes);
+  if (infer) layout_ctx_infer(m, R, a, x); else layout_ctx(m, R, a, x);
+  if (a.off > ctx_bytes) return fail("%s buffer too small: need %zu bytes, got %zu", infer ? "scratch" : "context", a.off, ctx_bytes);
   if (!out->z_vals || !out->weights || !out->color_fine || !out->cdf_fine || !out->inside_sphere ||
       !out->weight_sum || !out->weight_max || !out->depth || !out->s_val || !out->gradient_error)
     return fail("missing output buffer");
   if (m.has_relight && !out->global_color) return fail("Color_NeuS needs a global_color buffer");
   if (m.has_relight && !out->delta_relight && !out->delta_relight_ray_sum) return fail("Color_NeuS needs delta_relight or delta_relight_ray_sum");
-  if (in->prune_eps > 0.0f && m.has_relight && !out->delta_relight) return fail("prune_eps > 0 needs the delta_relight buffer");
+  if (in->prune_eps > 0.0f && m.has_relight && !out->delta_relight && !x.infer_fused) return fail("prune_eps > 0 needs the delta_relight buffer");
+  if (in->prune_eps > 0.0f && out->delta_relight_ray_sum) return fail("prune_eps > 0 (inference) does not go with the loss-only training outputs");
   float* const g_out = out->gradients ? out->gradients : x.gbuf;                       // "loss only" callers leave both to the context buffer
   float* const delta_out = m.has_relight ? (out->delta_relight ? out->delta_relight : x.delta_s) : nullptr;
   const long P = R * m.M;
@@ -834,7 +925,21 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   cf.sdf_s = out->sdf_samples; cf.color_s = out->color_samples; cf.gcolor_s = m.has_relight ? out->global_color_samples : nullptr;
   if (m.has_relight && out->delta_relight_ray_sum) { cf.delta = delta_out; cf.delta_ray_sum = out->delta_relight_ray_sum; }
 
-  if (in->prune_eps > 0.0f) {
+  if (in->prune_eps > 0.0f && x.infer_fused) {
+    // early termination on the forward-only path: weights first (they need only sdf and its gradient), a ballot / popcount pass per ray builds
+    // the list of samples with weight >= eps (and zeroes the colour outputs of the others), and the chain-fused colour + relight launch reads
+    // its rows through that list and writes the kept samples' outputs in place -- no compact copies, no scatter
+    be_composite_fwd(cf, s);
+    PruneCount pc; pc.weights = out->weights; pc.R = R; pc.M = m.M; pc.eps = in->prune_eps; pc.counts = x.p_counts;
+    be_prune_count(pc, s);
+    PruneScan ps; ps.counts = x.p_counts; ps.R = R; ps.offsets = x.p_offsets;
+    be_prune_scan(ps, s);
+    PruneGather pg; pg.weights = out->weights; pg.R = R; pg.M = m.M; pg.eps = in->prune_eps; pg.offsets = x.p_offsets; pg.idx = x.p_idx;
+    pg.featx = x.featx; pg.ldfx = x.ldfx; pg.featx_c = nullptr; pg.aux = x.AUX; pg.aux_c = nullptr;
+    pg.zero_gcol = x.gcol; pg.zero_relit = m.has_relight ? x.relit : nullptr; pg.zero_delta = delta_out;
+    be_prune_gather(pg, s);
+    if (!relu_chains_fused(m, P, x, delta_out, s, x.p_offsets + R, x.p_idx)) return fail("render_forward_only: the chain-fused colour / relight launch refused its shapes");
+  } else if (in->prune_eps > 0.0f) {
     // inference-only early termination: weights first (they need only sdf and its gradient), then the colour / relight networks
     // on the compacted list of samples with weight >= eps, scattered back into zero-filled per-sample buffers
     be_memset_zero(x.gcol, (size_t)P * 4 * sizeof(float), s);
@@ -869,7 +974,7 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   ReduceEik re;
   re.partial = x.eik_partial; re.R = R; re.sums = x.eik_sums; re.sums_out = out->eik_sums; re.gradient_error = out->gradient_error;
   be_reduce_eik(re, s);
-  return check_backend("render_forward");
+  return check_backend(infer ? "render_forward_only" : "render_forward");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1756,6 +1861,20 @@ size_t cnr_bwd_scratch_bytes(const cnr_config* cfg, int64_t n_rays) {
   Bwd b;
   layout_bwd(m, n_rays, x, sa, b);
   return sa.off;
+}
+
+size_t cnr_infer_scratch_bytes(const cnr_config* cfg, int64_t n_rays) {
+  Model m;
+  if (build_model(cfg, m) || n_rays <= 0) return 0;
+  Arena a(nullptr);
+  Ctx x;
+  layout_ctx_infer(m, n_rays, a, x);
+  return a.off;
+}
+
+int cnr_render_forward_only(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in, const cnr_render_outputs* out,
+                            void* scratch, size_t scratch_bytes, void* stream) {
+  return render_forward(cfg, params, in, out, scratch, scratch_bytes, (cnr_stream)stream, true);
 }
 
 int cnr_render_forward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,

@@ -156,6 +156,37 @@ class _RenderFunction(torch.autograd.Function):
         return res
 
 
+def _render_forward_only(owner, rays_o, rays_d, near, far, t_rand, z_override, background_rgb, cos_anneal_ratio, prune_eps, params):
+    """cnr_render_forward_only: the inference use of the path (NeuS_Trainer.validate_image, NeuS_Trainer.py:236-245; evaluation.py).  Same
+    outputs, bit-identical values; nothing is kept for a backward pass and the scratch buffer is about 60 % of the training context."""
+    lib, ccfg, cfg = owner._lib, owner._ccfg, owner.rcfg
+    dev = rays_o.device
+    R, M = rays_o.shape[0], cfg.n_total
+    f32 = dict(dtype=torch.float32, device=dev)
+    rays_o_c, rays_d_c = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+    near_c, far_c = near.detach().reshape(-1).contiguous().float(), far.detach().reshape(-1).contiguous().float()
+    color = cfg.type == "Color_NeuS"
+    out = dict(color_fine=torch.empty(R, 3, **f32), s_val=torch.empty(R, 1, **f32), cdf_fine=torch.empty(R, M, **f32),
+               weight_sum=torch.empty(R, 1, **f32), weight_max=torch.empty(R, 1, **f32), gradients=torch.empty(R, M, 3, **f32),
+               weights=torch.empty(R, M, **f32), gradient_error=torch.empty((), **f32), inside_sphere=torch.empty(R, M, **f32),
+               depth=torch.empty(R, **f32), global_color=torch.empty(R, 3, **f32) if color else None,
+               delta_relight=torch.empty(R, M, 3, **f32) if color else None, delta_relight_ray_sum=None,
+               z_vals=torch.empty(R, M, **f32), eik_sums=torch.empty(2, **f32), sdf_samples=None, color_samples=None, global_color_samples=None)
+    if z_override is not None:
+        out["z_vals"].copy_(z_override.detach().reshape(R, M))
+    plist = [p.detach().contiguous() for p in params]
+    parr = (C.c_void_p * len(plist))(*[p.data_ptr() for p in plist])
+    cin = _lib.CnrInputs(rays_o=_ptr(rays_o_c), rays_d=_ptr(rays_d_c), near_=_ptr(near_c), far_=_ptr(far_c),
+                         t_rand=_ptr(t_rand), z_vals_override=_ptr(out["z_vals"]) if z_override is not None else None,
+                         background_rgb=_ptr(background_rgb), n_rays=R, cos_anneal_ratio=float(cos_anneal_ratio), prune_eps=float(prune_eps))
+    cout = _lib.CnrOutputs(**{k: _ptr(out[k]) for k in _lib.OUTPUT_FIELDS})
+    nbytes = lib.lib.cnr_infer_scratch_bytes(C.byref(ccfg), R)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rc = lib.lib.cnr_render_forward_only(C.byref(ccfg), parr, C.byref(cin), C.byref(cout), _ptr(scratch), nbytes, _stream_of(rays_o))
+    lib.check(rc, "cnr_render_forward_only")
+    return out
+
+
 def sample_pdf(bins, weights, n_samples, det=True, library=None):
     """ray_utils.sample_pdf(bins, weights, n_samples, det=True) (lib/models/tools/ray_utils.py:123-154) on the device: the
     hierarchical sampler's own kernel (cnr_sample_pdf).  Only the deterministic variant exists -- the renderer never uses another."""
@@ -351,13 +382,16 @@ class NeuSRenderer(nn.Module):
 
     # -- NeuS.forward (NeuS.py:294-408) -------------------------------------------------------------------------------
     def forward(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0, z_vals=None,
-                prune_eps=0.0, training_outputs="dict", **kwargs):
+                prune_eps=0.0, training_outputs="dict", forward_only=None, **kwargs):
         """input: rays_o [n_rays,3], rays_d [n_rays,3], near/far [n_rays].  Extra kwarg ``z_vals`` (not in the reference)
         overrides the sampler so that render_core can be checked at fixed sample positions; ``prune_eps`` > 0 (inference only, not in the
         reference) skips the colour / relight networks for samples whose compositing weight is below it (NeuS_Trainer.validate_image
         consumes only color_fine and depth, :244-245).  ``training_outputs="loss_only"`` (not in the reference; default "dict" = the reference's
         return dict): the two [n_rays, M, 3] entries `gradients` and `delta_relight` are not materialised; the dict carries
-        `delta_relight_ray_sum` [n_rays] instead, which is all compute_loss needs (loss.compute_loss_fused accepts either form)."""
+        `delta_relight_ray_sum` [n_rays] instead, which is all compute_loss needs (loss.compute_loss_fused accepts either form).
+        ``forward_only`` (not in the reference): None = automatic -- the call takes the forward-only entry point of the library
+        (cnr_render_forward_only: identical values, nothing kept for a backward pass) whenever no gradient can be asked of it, i.e. under
+        torch.no_grad() or when neither a parameter nor an input requires grad; False forces the saving forward, True the forward-only one."""
         if training_outputs not in ("dict", "loss_only"):
             raise ValueError("training_outputs must be 'dict' or 'loss_only'")
         loss_only = training_outputs == "loss_only"
@@ -387,6 +421,19 @@ class NeuSRenderer(nn.Module):
         params = self._ordered_params()
         if self.n_outside > 0:
             return self._forward_with_background(rays_o, rays_d, near, far, perturb, t_rand, bg, cos_anneal_ratio, params, z_vals)
+        if forward_only is None:
+            forward_only = not loss_only and not (torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(
+                torch.is_tensor(t) and t.requires_grad for t in (rays_o, rays_d, near, far))))
+        if forward_only:
+            if loss_only:
+                raise ValueError("training_outputs='loss_only' belongs to the training step, not to a forward-only call")
+            out = _render_forward_only(self, rays_o, rays_d, near, far, t_rand, z_vals, bg, cos_anneal_ratio, prune_eps, params)
+            ret = {k: out[k] for k in ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",
+                                       "gradient_error", "inside_sphere", "depth"]}
+            if self.rcfg.type == "Color_NeuS":
+                ret["global_color"], ret["delta_relight"] = out["global_color"], out["delta_relight"]
+            ret["z_vals"], ret["eik_sums"] = out["z_vals"], out["eik_sums"]
+            return ret
         res = _RenderFunction.apply(self, rays_o, rays_d, near, far, t_rand, z_vals, bg, cos_anneal_ratio, prune_eps,
                                     "loss_only" if loss_only else False, *params)
         color = self.rcfg.type == "Color_NeuS"

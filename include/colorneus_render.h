@@ -240,6 +240,17 @@ size_t cnr_bwd_scratch_bytes(const cnr_config* cfg, int64_t n_rays);
 int cnr_render_forward(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in,
                        const cnr_render_outputs* out, void* ctx, size_t ctx_bytes, void* stream);
 
+/* Forward-only render -- the inference use of the path: NeuS_Trainer.validate_image (NeuS_Trainer.py:236-245 consumes color_fine and depth of every
+ * chunk) and evaluation.py.  Same inputs, same outputs, BIT-IDENTICAL values to cnr_render_forward (every value-producing launch is the same
+ * kernel on the same operands), but nothing is written for cnr_render_backward: no row scales, no hidden activations of the colour / relight
+ * stacks, two reused buffers instead of the saved V_l of the gradient chain.  `scratch` (cnr_infer_scratch_bytes, about 60 % of
+ * cnr_ctx_bytes) holds no state after the call.  prune_eps > 0 (cnr_render_inputs): the colour / relight stacks run only on the samples
+ * whose compositing weight is >= prune_eps -- per ray a wavefront ballot + popcount builds the index list, the chain-fused launch reads its
+ * rows through it; the pixel error per skipped sample is < prune_eps, the per-sample colour outputs of skipped samples are zero. */
+size_t cnr_infer_scratch_bytes(const cnr_config* cfg, int64_t n_rays);
+int cnr_render_forward_only(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in, const cnr_render_outputs* out,
+                            void* scratch, size_t scratch_bytes, void* stream);
+
 /* the hierarchical sampler on its own (NeuS.forward up to the render_core call, NeuS.py:309-356): writes the final z_vals [R][M];
  * ctx is a buffer of cnr_ctx_bytes(cfg, n_rays) bytes used as scratch */
 int cnr_sample_z(const cnr_config* cfg, const float* const* params, const cnr_render_inputs* in, float* z_vals, void* ctx, size_t ctx_bytes,
