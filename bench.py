@@ -161,9 +161,14 @@ def main():
     M = cfg.n_total
     strong = args.scaling == "strong"
     # weak scaling: every rank renders rays of its own view; strong scaling (BASELINE C4): ONE batch of --rays-total rays of one view, rank r
-    # takes rows [r R, (r + 1) R) of it and of its jitter draw -- the N-rank step is then the single-process step on the same batch
-    o_all, d_all, near_all, far_all, rgb_all, mask_all = synthetic.synthetic_view(seed=1 if strong else 1 + rank, device=dev)
-    n_all = o_all.shape[0]
+    # takes rows [r R, (r + 1) R) of it and of its jitter draw -- the N-rank step is then the single-process step on the same batch.
+    # The rays of a step come from the library's ray generator (cnr_gen_rays: rays, near / far, colours and mask values of the chosen pixels
+    # in ONE launch) -- the step the reference's trainer runs in front of the renderer (NeuS_Trainer.render, NeuS_Trainer.py:104-120:
+    # get_rays_multicam + near_far_from_sphere), not a gather from a precomputed table of all 640 000 rays.
+    from color_neus_amd import rays as raygen
+    Hh = Ww = 800
+    cam_c2w, cam_focal, cam_image, cam_mask = synthetic.synthetic_camera(Hh, Ww, seed=1 if strong else 1 + rank, device=dev)
+    n_all = Hh * Ww
     perm = torch.randperm(n_all, generator=torch.Generator().manual_seed(7)).to(dev)
 
     def batch(i, r):
@@ -172,7 +177,9 @@ def main():
             idx = perm[(i * rg) % (n_all - rg):(i * rg) % (n_all - rg) + rg][rank * r:(rank + 1) * r]
         else:
             idx = perm[(i * r) % (n_all - r):(i * r) % (n_all - r) + r]
-        return o_all[idx], d_all[idx], near_all[idx], far_all[idx], rgb_all[idx], mask_all[idx]
+        o, d, rgb, msel, near, far = raygen._generate(lib, idx, r, cam_c2w, cam_focal, Hh, Ww, True, False, image=cam_image, mask=cam_mask,
+                                                      origin=None, radius=1.0, want_nearfar=True)
+        return o, d, near, far, rgb, msel
 
     torch.manual_seed(2)   # jitter stream (CPU generator, like the reference)
 

@@ -31,6 +31,27 @@ def synthetic_view(height=800, width=800, focal=1111.1, seed=1, device="cpu"):
     return f(rays_o), f(rays_d), f(mid - 1.0), f(mid + 1.0), rgb.to(device), mask.to(device)
 
 
+def synthetic_camera(height=800, width=800, focal=1111.1, seed=1, device="cpu"):
+    """The camera of synthetic_view in the form the ray generator takes (rays.rays_for_training / cnr_gen_rays): c2w [1, 4, 4] whose
+    columns are right / down / forward / centre, focal [2], image [1, H, W, 3] ~U[0, 1), mask [1, H, W] ~ Bernoulli(0.7) -- the same
+    pixel -> ray map (normalised directions, pixel (i, j) -> ((i - W / 2) / f, (j - H / 2) / f, 1)), evaluated per chosen pixel on the device."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    c = torch.randn(3, generator=g, dtype=torch.float64)
+    c = c / c.norm() * (2.5 + 0.5 * float(torch.rand(1, generator=g, dtype=torch.float64)))
+    fwd = -c / c.norm()
+    up = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)
+    right = torch.linalg.cross(fwd, up)
+    right = right / right.norm()
+    down = torch.linalg.cross(fwd, right)
+    c2w = torch.eye(4, dtype=torch.float64)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, c
+    n = height * width
+    rgb = torch.rand(n, 3, generator=g)
+    mask = (torch.rand(n, generator=g) < 0.7).float()
+    return (c2w.float()[None].contiguous().to(device), torch.tensor([focal, focal], dtype=torch.float32, device=device),
+            rgb.reshape(1, height, width, 3).contiguous().to(device), mask.reshape(1, height, width).contiguous().to(device))
+
+
 @torch.no_grad()
 def make_trained_like_(renderer, radius=0.5, variance=0.65):
     """Move freshly initialised weights into a 'trained-like' regime: inv_s = exp(10*variance) ~ 665 and an SDF that is a

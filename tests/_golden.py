@@ -199,8 +199,10 @@ def check_grads_full(ref64, ref32, got, strict=True, rel_max=None):
     """EVERY entry of every gradient tensor (no stride) against a float64 evaluation ``ref64`` (name -> tensor) of the same algorithm
     at the same inputs -- the oracle run live by the GPU tests; ``ref32`` is its float32 evaluation, whose distance from float64
     calibrates the per-tensor tolerance exactly like the fixtures' ``gspread``.  Same rule as check_param_grads.  Returns offenders.
-    ``rel_max`` (full-size batches, where one ReLU kink no longer moves an entry): in addition the LARGEST error of every tensor must be
-    within max(1e-4, rel_max x the float32 oracle's largest error on that tensor)."""
+    ``rel_max`` (full-size batches): in addition the LARGEST error of every tensor of the smooth part of the model -- the softplus SDF
+    network, the variance, d rays -- must be within max(1e-4, rel_max x the float32 oracle's largest error on that tensor).  The ReLU stacks
+    keep the bulk rule + cap: even at 4096 rays ONE flipped unit at one sample shows in its row (measured: relight rl_mlp.2, 3 entries at
+    1.3e-4 where every other entry of the tensor is within 1e-6; profiles/r05_param_grad_error_table_c4.txt)."""
     bad = []
     cap = _gate(strict)[2]
     for k, r64 in ref64.items():
@@ -212,7 +214,7 @@ def check_grads_full(ref64, ref32, got, strict=True, rel_max=None):
         allowed = _allowed(e.numel(), strict)
         bulk = float(torch.sort(e).values[-(allowed + 1)]) if e.numel() > allowed else 0.0
         ok = float(e.max()) <= cap and bulk <= lim
-        if rel_max is not None:
+        if rel_max is not None and k.split(".")[0] in ("sdf_network", "deviation_network", "rays_o", "rays_d"):
             ok = ok and float(e.max()) <= max(GRAD_TOL_MIN, rel_max * spread)
         if not ok:
             bad.append((k, float(e.max()), bulk, lim, int((e > lim).sum()), spread))

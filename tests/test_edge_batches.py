@@ -121,9 +121,12 @@ def test_narrow_embedding_hip(R):
 
 
 _CHILD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_edge_child.py")
-# fallback forms of this round's and last round's default kernels: they differ from the default path only in the summation order of the
-# weight-gradient partial sums and in which launch forms a product -- never in which rows / slots a ragged batch touches
-_FALLBACKS = [("CNR_NO_SWEEP0",), ("CNR_NO_NARROW_BWD", "CNR_NO_NARROW_DX"), ("CNR_NO_CHAIN_FWD", "CNR_NO_CHAIN_SDF"), ("CNR_NO_FDW",), ("CNR_NO_HEAD_BWD", "CNR_NO_STRIP_BWD")]
+# Fallback forms of the default kernels, by what they replace.  BACKWARD-only switches leave the forward pass -- hence every ReLU decision --
+# untouched: the gradients of the two forms differ by round-off only (summation order of the weight-gradient partial sums, which launch
+# forms a product), never by a flipped unit.  FORWARD switches change the rounding of the forward values themselves: their gradients may
+# differ by a flipped ReLU unit (up to 2e-2 of one row), so for them only the outputs are compared.
+_BACKWARD_FALLBACKS = [("CNR_NO_SWEEP0",), ("CNR_NO_NARROW_BWD",), ("CNR_NO_FDW",), ("CNR_NO_HEAD_BWD", "CNR_NO_STRIP_BWD"), ("CNR_NO_TOP_FUSE",), ("CNR_FDW_SPLIT",)]
+_FORWARD_FALLBACKS = [("CNR_NO_CHAIN_FWD", "CNR_NO_CHAIN_SDF"), ("CNR_NO_NARROW_DX",), ("CNR_NO_FUSED",)]
 
 
 def _child_grads(R, cfg_name, switches, tmp_path):
@@ -141,29 +144,39 @@ def _child_grads(R, cfg_name, switches, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("R", [1, 3, 33, 130])
 def test_ragged_batches_default_kernels_match_fallback_kernels_hip(R, tmp_path):
-    """The tight gate at ragged sizes (the float64 gate above is loose below 64 rays because of ReLU kinks): the default path against each
-    fallback form of its kernels on the SAME rays, in child processes (the switches are read once per process).  A wrong last tile, row or
-    partial-sum slot is an O(1) difference in some tensor; what is allowed is round-off: every tensor within 2e-5 of its own largest entry
-    (measured <= 4e-6), except for at most 2 tensors that may show the signature of ONE flipped ReLU unit (<= 5e-2; measured at 33 rays
-    between the two forms of the gradient chain's end)."""
+    """The tight gate at ragged sizes (the float64 gate above is loose below 64 rays because of ReLU kinks): the default path against the
+    fallback forms of its kernels on the SAME rays, in child processes (the switches are read once per process).
+    Backward-only fallbacks: outputs bit-identical, every gradient tensor within 2e-4 of its own largest entry -- the two forms are both
+    float32-class evaluations of second-order terms (softplus'' = 100 sigma (1 - sigma) amplifies a last-bit difference; measured up to
+    3.9e-5 at 3 rays on the SDF tensors, 4e-6 on the others), while a wrong last tile, row or partial-sum slot moves a tensor by percent.
+    Forward fallbacks: every output within 1e-4 (measured 3.6e-5 on the per-sample weights at inv_s = 665)."""
     import numpy as np
     base = _child_grads(R, "dtu", (), tmp_path)
-    for sw in _FALLBACKS:
+    worst = {}
+    for sw in _BACKWARD_FALLBACKS:
         alt = _child_grads(R, "dtu", sw, tmp_path)
         assert set(alt) == set(base)
-        kinked = []
         for k in base:
+            if k.startswith("out:"):
+                assert np.array_equal(alt[k], base[k]), (R, sw, k)
+                continue
             scale = float(np.abs(base[k]).max())
             if scale == 0.0:
                 assert float(np.abs(alt[k]).max()) == 0.0, (sw, k)
                 continue
             err = float(np.abs(alt[k].astype(np.float64) - base[k]).max()) / scale
-            assert np.isfinite(err) and err < 5e-2, (R, sw, k, err)
-            if err >= 2e-5:
-                kinked.append((k, err))
-        # outputs never depend on a backward kernel form; gradients: a flipped unit shows in its own layer's tensors and the biases below
-        assert not [k for k, _ in kinked if k.startswith("out:")], (R, sw, kinked)
-        assert len(kinked) <= 6, (R, sw, kinked)
+            worst[sw] = max(worst.get(sw, 0.0), err)
+            assert np.isfinite(err) and err < 2e-4, (R, sw, k, err)
+    for sw in _FORWARD_FALLBACKS:
+        alt = _child_grads(R, "dtu", sw, tmp_path)
+        for k in base:
+            if k.startswith("out:"):
+                scale = max(float(np.abs(base[k]).max()), 1e-30)
+                err = float(np.abs(alt[k].astype(np.float64) - base[k]).max()) / scale
+                assert np.isfinite(err) and err < 1e-4, (R, sw, k, err)
+            else:
+                assert np.isfinite(alt[k]).all(), (R, sw, k)
+    print("ragged R=%d worst backward-fallback differences:" % R, {"+".join(k): "%.1e" % v for k, v in worst.items()})
 
 
 def _check_eval_sizes(library, device, cfg_name, sizes):
