@@ -97,7 +97,7 @@ EXPORTS = ["cnr_abi_version", "cnr_backend_name", "cnr_last_error", "cnr_param_c
            "cnr_bwd_scratch_bytes", "cnr_render_forward", "cnr_render_backward", "cnr_infer_scratch_bytes", "cnr_render_forward_only", "cnr_sdf_eval_scratch_bytes", "cnr_sdf_eval",
            "cnr_sdf_grid_scratch_bytes", "cnr_sdf_grid", "cnr_sdf_grid_slab_scratch_bytes", "cnr_sdf_grid_slab", "cnr_vertex_color_scratch_bytes", "cnr_vertex_color",
            "cnr_timing_enable", "cnr_timing_collect", "cnr_loss_scratch_bytes", "cnr_loss_sums", "cnr_loss_sums_ray", "cnr_loss_grads", "cnr_loss_combine", "cnr_loss_coef", "cnr_loss_forward", "cnr_loss_backward", "cnr_loss_shard_stats", "cnr_loss_shard_combine",
-           "cnr_sample_pdf", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward", "cnr_sample_z", "cnr_mc_scratch_bytes", "cnr_mc_count", "cnr_mc_emit",
+           "cnr_sample_pdf", "cnr_sample_pdf_u", "cnr_up_sample", "cnr_clip_adam_step", "cnr_clip_adam_scratch_bytes", "cnr_gen_rays", "cnr_gen_rays_backward", "cnr_sample_z", "cnr_mc_scratch_bytes", "cnr_mc_count", "cnr_mc_emit",
            "cnr_linear_scratch_bytes", "cnr_linear_forward", "cnr_linear_backward",
            "cnr_nerf_param_count", "cnr_nerf_param_info", "cnr_outside_z", "cnr_outside_z_backward", "cnr_background_ctx_bytes",
            "cnr_background_bwd_scratch_bytes", "cnr_background_forward", "cnr_background_backward", "cnr_composite_background_scratch_bytes",
@@ -155,6 +155,7 @@ class RenderLibrary:
         L.cnr_loss_shard_stats.argtypes = [C.POINTER(CnrLossConfig), _FP, _FP, _FP, C.c_int32, _FP, _FP, _FP, C.c_int64, C.c_int32, _FP, _FP, C.c_size_t, _FP]
         L.cnr_loss_shard_combine.argtypes = [C.POINTER(CnrLossConfig), _FP, C.c_float, C.c_int32, C.c_int32, C.c_int32, _FP, _FP]
         L.cnr_sample_pdf.argtypes = [_FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, _FP]
+        L.cnr_sample_pdf_u.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, _FP, _FP]
         L.cnr_up_sample.argtypes = [_FP, _FP, _FP, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_float, _FP, _FP]
         L.cnr_clip_adam_step.argtypes = [C.POINTER(CnrAdamConfig), C.c_int32, C.POINTER(C.c_int64), C.POINTER(_FP), C.POINTER(_FP), _FP, _FP, _FP,
                                          C.c_size_t, _FP]

@@ -61,6 +61,8 @@ struct UpSample {   // NeuS.py:136-181 + ray_utils.py:123-154 (det=True)
   float* new_z;                                      // [R][m]
   const float* w_in = nullptr;                       // optional [R][n-1]: section weights given by the caller (plain sample_pdf(det=True),
                                                      // ray_utils.py:123-154, bins = z); o / d / sdf / inv_s are then unused
+  const float* u_in = nullptr;                       // optional [R][m]: the uniform draws of sample_pdf(det=False) (ray_utils.py:135-136: torch.rand, drawn by the caller
+                                                     // from the CPU generator like the reference); null: det=True, u_k = (k + 0.5) / m
 };
 
 struct MergeZ {     // NeuS.py:183-197

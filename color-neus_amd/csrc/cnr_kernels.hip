@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const UpSample p) {
   if (lane == 0) cs[0] = 0.0f;
   __syncthreads();
   if (lane < p.m && active) {
-    const float u = linspace_at(0.5f / (float)p.m, 1.0f - 0.5f / (float)p.m, p.m, lane);
+    const float u = p.u_in ? p.u_in[ray * p.m + lane] : linspace_at(0.5f / (float)p.m, 1.0f - 0.5f / (float)p.m, p.m, lane);
     int lo = 0, hi = n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (cs[mid] > u) hi = mid; else lo = mid + 1; }
     const int below = lo - 1 > 0 ? lo - 1 : 0;

@@ -455,7 +455,7 @@ void be_upsample(const UpSample& p, cnr_stream) {
     float run = 0.0f;
     for (int i = 0; i < nsec; ++i) { run += w[i] / total; cdf[i + 1] = run; }
     for (int k = 0; k < p.m; ++k) {
-      float u = linspace_at(0.5f / (float)p.m, 1.0f - 0.5f / (float)p.m, p.m, k);
+      float u = p.u_in ? p.u_in[ray * p.m + k] : linspace_at(0.5f / (float)p.m, 1.0f - 0.5f / (float)p.m, p.m, k);
       int idx = (int)(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
       int below = std::max(idx - 1, 0), above = std::min(idx, n - 1);
       float den = cdf[above] - cdf[below];

@@ -2114,14 +2114,21 @@ int cnr_timing_collect(cnr_kernel_timing* out, int max_records) {
   return be_timing_collect(reinterpret_cast<KernelTiming*>(out), max_records);
 }
 
-int cnr_sample_pdf(const float* bins, const float* weights, int64_t n_rays, int32_t n, int32_t n_samples, float* out, void* stream) {
+static int sample_pdf_impl(const float* bins, const float* weights, const float* u_draws, int64_t n_rays, int32_t n, int32_t n_samples, float* out, void* stream) {
   if (!bins || !weights || !out) return fail("null argument");
   if (n_rays <= 0 || n < 2 || n > kMaxRaySamples || n_samples < 1 || n_samples > 64) return fail("sample_pdf: need 2 <= n <= %d bins and 1 <= n_samples <= 64", kMaxRaySamples);
   UpSample u;
   u.o = nullptr; u.d = nullptr; u.R = n_rays; u.z = bins; u.ldz = n; u.sdf = nullptr; u.lds = 0; u.n = n; u.m = n_samples; u.inv_s = 0.0f;
-  u.new_z = out; u.w_in = weights;
+  u.new_z = out; u.w_in = weights; u.u_in = u_draws;
   be_upsample(u, (cnr_stream)stream);
   return check_backend("sample_pdf");
+}
+int cnr_sample_pdf(const float* bins, const float* weights, int64_t n_rays, int32_t n, int32_t n_samples, float* out, void* stream) {
+  return sample_pdf_impl(bins, weights, nullptr, n_rays, n, n_samples, out, stream);
+}
+int cnr_sample_pdf_u(const float* bins, const float* weights, const float* u, int64_t n_rays, int32_t n, int32_t n_samples, float* out, void* stream) {
+  if (!u) return fail("null argument");
+  return sample_pdf_impl(bins, weights, u, n_rays, n, n_samples, out, stream);
 }
 
 int cnr_up_sample(const float* rays_o, const float* rays_d, const float* z_vals, const float* sdf, int64_t n_rays, int32_t n,

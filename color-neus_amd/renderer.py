@@ -189,9 +189,8 @@ def _render_forward_only(owner, rays_o, rays_d, near, far, t_rand, z_override, b
 
 def sample_pdf(bins, weights, n_samples, det=True, library=None):
     """ray_utils.sample_pdf(bins, weights, n_samples, det=True) (lib/models/tools/ray_utils.py:123-154) on the device: the
-    hierarchical sampler's own kernel (cnr_sample_pdf).  Only the deterministic variant exists -- the renderer never uses another."""
-    if not det:
-        raise NotImplementedError("sample_pdf: only det=True (the only mode NeuS.up_sample uses, NeuS.py:180)")
+    hierarchical sampler's own kernel (cnr_sample_pdf).  det=False (never taken by the render path, NeuS.py:180): the uniform draws come
+    from torch.rand on the CPU generator with the reference's shape and call order (ray_utils.py:135-136), the inversion runs in the same kernel."""
     lib = library if isinstance(library, _lib.RenderLibrary) else _lib.load_library(library)
     bins = bins.detach().contiguous().float()
     weights = weights.detach().contiguous().float()
@@ -199,7 +198,11 @@ def sample_pdf(bins, weights, n_samples, det=True, library=None):
     assert weights.shape[-1] == n - 1 and bins.shape[:-1] == weights.shape[:-1]
     R = bins.numel() // n
     out = torch.empty(*bins.shape[:-1], n_samples, dtype=torch.float32, device=bins.device)
-    rc = lib.lib.cnr_sample_pdf(_ptr(bins), _ptr(weights), R, n, int(n_samples), _ptr(out), _stream_of(bins))
+    if det:
+        rc = lib.lib.cnr_sample_pdf(_ptr(bins), _ptr(weights), R, n, int(n_samples), _ptr(out), _stream_of(bins))
+    else:
+        u = torch.rand(list(bins.shape[:-1]) + [int(n_samples)]).to(bins.device).contiguous()
+        rc = lib.lib.cnr_sample_pdf_u(_ptr(bins), _ptr(weights), _ptr(u), R, n, int(n_samples), _ptr(out), _stream_of(bins))
     lib.check(rc, "cnr_sample_pdf")
     return out
 

@@ -270,6 +270,10 @@ int cnr_render_backward(const cnr_config* cfg, const float* const* params, const
  * n <= 256 bins / samples per ray, n_samples (n_importance) <= 64 */
 int cnr_sample_pdf(const float* bins /* [R][n] */, const float* weights /* [R][n-1] */, int64_t n_rays, int32_t n, int32_t n_samples,
                    float* out /* [R][n_samples] */, void* stream);
+/* ray_utils.sample_pdf(..., det=False) (ray_utils.py:135-136): the same inversion of the cdf at the caller's uniform draws u [R][n_samples] -- the
+ * reference's torch.rand(list(cdf.shape[:-1]) + [n_samples]), taken by the host layer from the CPU generator exactly like the reference takes it.
+ * Not on the render path (NeuS.up_sample calls det=True, NeuS.py:180); exported so that the function is complete. */
+int cnr_sample_pdf_u(const float* bins, const float* weights, const float* u, int64_t n_rays, int32_t n, int32_t n_samples, float* out, void* stream);
 int cnr_up_sample(const float* rays_o, const float* rays_d, const float* z_vals /* [R][n] */, const float* sdf /* [R][n] */, int64_t n_rays,
                   int32_t n, int32_t n_importance, float inv_s, float* out /* [R][n_importance] */, void* stream);
 

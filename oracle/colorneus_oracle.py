@@ -398,12 +398,16 @@ def relight_forward(P, cfg: RelightConfig, rgb, pts, dirs, gradients):
 # --------------------------------------------------------------------------------------
 # sampler                                       (NeuS.py:136-197, ray_utils.py:123-154)
 # --------------------------------------------------------------------------------------
-def sample_pdf_det(bins, weights, n_samples):
+def sample_pdf_det(bins, weights, n_samples, u=None):
+    """ray_utils.sample_pdf (ray_utils.py:123-154).  u = None: det=True (the render path, NeuS.py:180); u given [..., n_samples]: the draws of
+    det=False (ray_utils.py:135-136: torch.rand of that shape on the CPU generator)."""
     w = weights + 1e-5
     pdf = w / w.sum(-1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
-    u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, n_samples, dtype=cdf.dtype, device=cdf.device)
-    u = u.expand(*cdf.shape[:-1], n_samples).contiguous()
+    if u is None:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, n_samples, dtype=cdf.dtype, device=cdf.device)
+        u = u.expand(*cdf.shape[:-1], n_samples)
+    u = u.to(cdf.dtype).contiguous()
     idx = torch.searchsorted(cdf, u, right=True)
     lo = (idx - 1).clamp(min=0)
     hi = idx.clamp(max=cdf.shape[-1] - 1)

@@ -36,6 +36,15 @@ def test_sample_pdf_edge_cases():
         assert torch.allclose(y, torch.from_numpy(fx[f"spdf:out{n}"]), rtol=0, atol=1e-6)
 
 
+def test_sample_pdf_random_draws():
+    """det=False (ray_utils.py:135-136): the oracle at the reference's draws reproduces the reference's samples."""
+    fx = G.load("sample_pdf_random")
+    bins, w = torch.from_numpy(fx["bins"]), torch.from_numpy(fx["w"])
+    for n in (16, 5):
+        y = O.sample_pdf_det(bins, w, n, u=torch.from_numpy(fx[f"u{n}"]))
+        assert torch.allclose(y, torch.from_numpy(fx[f"out{n}"]), rtol=0, atol=1e-6)
+
+
 def test_up_sample_and_merge():
     fx = G.load("functions")
     cfg = O.tiny_config()

@@ -26,6 +26,24 @@ def _sample_pdf(library, device):
         assert (np.diff(got, axis=1) >= 0).all(), "samples must be monotone"
 
 
+def _sample_pdf_random(library, device):
+    """det=False (ray_utils.py:135-136): u = torch.rand on the CPU generator with the reference's shape -- the same seed gives the reference's
+    draws, hence its samples (golden: tools/gen_golden.py --spdf-random-only)."""
+    fx = G.load("sample_pdf_random")
+    bins, w = torch.from_numpy(fx["bins"]).to(device), torch.from_numpy(fx["w"]).to(device)
+    for m in (16, 5):
+        torch.manual_seed(int(fx["seed"]))
+        got = cn.sample_pdf(bins, w, m, det=False, library=library).cpu().numpy()
+        assert np.abs(got - fx[f"out{m}"]).max() < 2e-5, m
+        # and the generator was consumed exactly like the reference consumes it
+        torch.manual_seed(int(fx["seed"]))
+        torch.rand([bins.shape[0], m])
+        nxt = torch.rand(1)
+        torch.manual_seed(int(fx["seed"]))
+        cn.sample_pdf(bins, w, m, det=False, library=library)
+        assert torch.equal(torch.rand(1), nxt)
+
+
 def _up_sample(library, device):
     fx = G.load("functions")
     from oracle import colorneus_oracle as O
@@ -60,6 +78,7 @@ def _crafted_rows(library, device):
 def test_sample_pdf_emu():
     _sample_pdf(N.EMU_LIB, "cpu")
     _crafted_rows(N.EMU_LIB, "cpu")
+    _sample_pdf_random(N.EMU_LIB, "cpu")
 
 
 @pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
@@ -71,6 +90,7 @@ def test_up_sample_emu():
 def test_sample_pdf_hip():
     _sample_pdf(None, "cuda:0")
     _crafted_rows(None, "cuda:0")
+    _sample_pdf_random(None, "cuda:0")
 
 
 @pytest.mark.gpu
@@ -86,5 +106,4 @@ def test_argument_checks():
         cn.sample_pdf(torch.zeros(2, 300), torch.zeros(2, 299), 16, library=lib)      # more than 256 bins
     with pytest.raises(RuntimeError):
         cn.sample_pdf(torch.zeros(2, 8), torch.zeros(2, 7), 65, library=lib)          # more than 64 samples
-    with pytest.raises(NotImplementedError):
-        cn.sample_pdf(torch.zeros(2, 8), torch.zeros(2, 7), 4, det=False, library=lib)
+    assert cn.sample_pdf(torch.linspace(0, 1, 8).repeat(2, 1), torch.ones(2, 7), 4, det=False, library=lib).shape == (2, 4)

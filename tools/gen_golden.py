@@ -320,15 +320,36 @@ def rays_fixture(mods):
 ANNEAL = dict(cos_anneal_ratio=0.3, background_rgb=(0.2, 0.5, 0.7))
 
 
+def sample_pdf_random_fixture(mods):
+    """ray_utils.sample_pdf(det=False) (ray_utils.py:135-136; never taken by the render path): the reference draws u from torch.rand on the CPU
+    generator -- seed, draws and result are stored (the rows of the det=True fixture incl. its zero / flat / spike / tiny-weight cases)."""
+    ray_utils = mods["ray_utils"]
+    fx = dict(np.load(os.path.join(OUT, "functions.npz")))
+    bins, w = torch.from_numpy(fx["spdf:bins"]), torch.from_numpy(fx["spdf:w"])
+    out = {"bins": bins.numpy(), "w": w.numpy(), "seed": np.int64(9)}
+    for m in (16, 5):
+        torch.manual_seed(9)
+        out[f"u{m}"] = torch.rand([bins.shape[0], m]).numpy()
+        torch.manual_seed(9)
+        out[f"out{m}"] = ray_utils.sample_pdf(bins, w, m, det=False).numpy()
+    path = os.path.join(OUT, "sample_pdf_random.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     Color_NeuS, NeuS, CN, mods = ref_import.import_reference()
+    if "--spdf-random-only" in sys.argv:   # round 5: the det=False fixture alone
+        sample_pdf_random_fixture(mods)
+        return
     if "--anneal-only" in sys.argv:   # round 5: only the two fixtures with non-default call arguments (the others are unchanged on disk)
         e2e_fixture("tiny_sharp_anneal", O.tiny_config(), Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=True, store_weights=True, grad_stride=1, call_kw=ANNEAL, ray_seed=3)
         e2e_fixture("dtu_sharp_anneal", O.dtu_config(), Color_NeuS, CN, mods, R=16, weight_seed=0, trained_like=True, store_weights=False, grad_stride=97, call_kw=ANNEAL)
         return
     function_fixture(CN, mods, Color_NeuS, NeuS)
+    sample_pdf_random_fixture(mods)
     rays_fixture(mods)
     tiny = O.tiny_config()
     e2e_fixture("tiny_init", tiny, Color_NeuS, CN, mods, R=32, weight_seed=0, trained_like=False, store_weights=True, grad_stride=1)
