@@ -1,5 +1,6 @@
-"""Child process of tests/test_edge_batches.py: one forward + backward of R rays through the HIP library under the CNR_* switches of the
-environment it was started with (the library reads them once per process); writes every output and every parameter gradient to an .npz."""
+"""Child process of tests/test_edge_batches.py: one forward + backward of R rays (for every R of a comma-separated list) through the HIP library
+under the CNR_* switches of the environment it was started with (the library reads them once per process); writes every output and every
+parameter gradient to one .npz per R (argv[3] is a path template with %d for R)."""
 import os
 import sys
 
@@ -12,7 +13,12 @@ sys.path.insert(0, HERE)
 
 
 def main():
-    R, cfg_name, out_path = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+    Rs, cfg_name, out_tmpl = [int(x) for x in sys.argv[1].split(",")], sys.argv[2], sys.argv[3]
+    for R in Rs:
+        one(R, cfg_name, out_tmpl % R)
+
+
+def one(R, cfg_name, out_path):
     import color_neus_amd as cn
     import _golden as G
     import _native as N
