@@ -12,7 +12,7 @@ export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=lib
 # leaks: CPython itself never frees its interned objects; what matters here is out-of-bounds / use-after-free / UB in the library
 export ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1" UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"
 export OMP_NUM_THREADS=4
-TESTS="tests/test_host_emu.py tests/test_edge_batches.py tests/test_sharded_gloo.py tests/test_sampler_functions.py tests/test_marching_cubes.py tests/test_fused_loss.py tests/test_linear_op.py tests/test_background_ops.py"
+TESTS="tests/test_host_emu.py tests/test_edge_batches.py tests/test_sharded_gloo.py tests/test_sampler_functions.py tests/test_marching_cubes.py tests/test_fused_loss.py tests/test_linear_op.py tests/test_background_ops.py tests/test_forward_only.py tests/test_prune.py tests/test_rays.py tests/test_mesh_reference_semantics.py"
 {
   echo "# build $(git -C "$R" rev-parse --short HEAD); g++ $(g++ -dumpversion); -fsanitize=address,undefined on cnr_plan.cpp + cnr_kernels_emu.cpp"
   echo "# python -m pytest $TESTS -m 'not gpu'"
