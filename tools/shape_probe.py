@@ -1,5 +1,6 @@
 """Value-chain tile shapes side by side (CNR_CHAIN_SHAPE is read once per process: one child per shape): time per call on 2 M points, board power and clock
-while it loops, and a checksum of the output (shapes must agree to round-off).  Usage (GPU box): python tools/shape_probe.py 41 42 22"""
+while it loops, and a checksum of the output (shapes must agree to round-off).  Usage (GPU box): python tools/shape_probe.py 41 22 12
+(the <4, 2> experiment of DESIGN.md 4.9 was `else if (shape == 42) launch_sdf_value_chain<4, 2>(c, s);` in be_sdf_value_chain with launch bounds (256, 1); not kept)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -27,5 +28,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     print("shape %s: %.3f ms per call of 2 M points   W mean %.0f   sclk %.0f MHz   sum %.9f  abs-sum %.9f" %
           (os.environ.get("CNR_CHAIN_SHAPE", "default"), dt / n * 1e3, sum(ws) / max(len(ws), 1), sum(cs) / max(len(cs), 1), float(ref.sum()), float(ref.abs().sum())), flush=True)
 else:
-    for sh in sys.argv[1:] or ["41", "42", "22"]:
+    for sh in sys.argv[1:] or ["41", "22", "12"]:
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, CNR_CHAIN_SHAPE=sh))
