@@ -965,6 +965,8 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
   } else {
     RangeScope r_("colour + relight chains");
     if (!relu_chains_fused(m, P, x, delta_out, s)) {
+      // (the forward-only layout holds no hidden-layer buffers when it counted on the chain-fused launch: never fall through to the per-layer chains then)
+      if (x.infer_fused) return fail("render_forward_only: the chain-fused colour / relight launch refused its shapes");
       color_chain(m, P, x, s);
       if (m.has_relight) relight_chain(m, P, x, delta_out, s);
     }
