@@ -427,6 +427,18 @@ def main():
             for name, kind, nt, P_, N_, K_, pairs, ms, nbytes in recs:
                 fam[name] = round(fam.get(name, 0.0) + ms, 4)
             inf["forward_only_kernel_ms"] = dict(sorted(fam.items(), key=lambda kv: -kv[1])[:8])
+            # a whole 800 x 800 view (validate_image: all rays of one camera in chunks, colour and depth kept): 79 chunks of 8192 rays
+            vo, vd = raygen.get_rays_at(cam_c2w[0], cam_focal, Hh, Ww, normalize=True, library=lib)
+            vo, vd = vo.reshape(-1, 3), vd.reshape(-1, 3)
+            vn, vf = raygen.near_far_from_sphere(vo, vd)
+            for tag, kw in ((("view_800x800_s", dict()), ("view_800x800_pruned_s", dict(prune_eps=1e-4))) if world == 1 else ()):   # (the chunk loop gathers over the process group)
+                parallel.sharded_render_image(renderer, vo[:Ri], vd[:Ri], vn[:Ri], vf[:Ri], chunk=Ri, perturb_overwrite=0, **kw)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                img = parallel.sharded_render_image(renderer, vo, vd, vn, vf, chunk=Ri, perturb_overwrite=0, **kw)
+                torch.cuda.synchronize(dev)
+                inf[tag] = round(time.perf_counter() - t1, 3)
+            del vo, vd, vn, vf
             inf["scratch_GB"] = {"forward_only": round(lib.lib.cnr_infer_scratch_bytes(__import__("ctypes").byref(renderer._ccfg), Ri) / 1e9, 2),
                                  "saving": round(lib.lib.cnr_ctx_bytes(__import__("ctypes").byref(renderer._ccfg), Ri) / 1e9, 2)}
         result["inference"] = {"unit": "rays/s", "sample": "5 forward passes of %d rays x 128 samples, no jitter, DTU renderer block; prune_eps_0 = the forward-only "
