@@ -138,15 +138,17 @@ struct CompositeBwd {
   // per-point cotangents
   float* ztop; int ldztop; int ztop_col;   // ztop[pt][ztop_col] = d sdf / scale (the sdf row is the LAST internal row of the top layer)
   float* gbar;                 // [P][4] d loss / d g through alpha, eikonal and the 'gradients' output
-  float* dtop;                 // [P][kTop] cotangent of the last relight layer output (pre-activation), zero padded
-  float* gc_a;                 // [P][kTop] cotangent of the global colour (post-sigmoid): direct + inverse-sigmoid path
+  int ldtop = kTop;            // row stride of dtop / gc_a: kTop (16: the narrow GEMM launches read 16-float rows) or 4 (packed: the streaming head kernels)
+  float* dtop;                 // [P][ldtop] cotangent of the last relight layer output (pre-activation), zero padded
+  float* gc_a;                 // [P][ldtop] cotangent of the global colour (post-sigmoid): direct + inverse-sigmoid path
   float* dinvs_partial;        // [R]
   float* d_rays_d;             // [R][3] (null when rays need no grad): sum_j d tc_j * g_j
   float* d_z;                  // [P][2] or null: {d loss / d z_j through depth, d loss / d dist_j through alpha} (near / far gradients, N_IMPORTANCE == 0)
 };
 
 struct ColTopBwd {  // cotangent of the colour net's last pre-activation
-  long P; const float* gc_a /*[P][kTop]*/; const float* gc_b /* [P][4], may be null */; const float* gcolor; int squeeze; float* out; /*[P][kTop]*/
+  long P; const float* gc_a /*[P][ldtop]*/; const float* gc_b /* [P][4], may be null */; const float* gcolor; int squeeze; float* out; /*[P][ldtop]*/
+  int ldtop = kTop;
 };
 
 struct GbarFinish { // total d g, then tangent of the embedding: cbar = J_PE (scale * gbar)

@@ -105,11 +105,11 @@ CNR_HD void body_grad_finish(const GradFinish& p, long pt) {
 
 CNR_HD void body_coltop_bwd(const ColTopBwd& p, long pt) {
   for (int c = 0; c < 3; ++c) {
-    float gc = p.gc_a[pt * kTop + c] + (p.gc_b ? p.gc_b[pt * 4 + c] : 0.0f);
+    float gc = p.gc_a[pt * p.ldtop + c] + (p.gc_b ? p.gc_b[pt * 4 + c] : 0.0f);
     float y = p.gcolor[pt * 4 + c];
-    p.out[pt * kTop + c] = p.squeeze ? gc * y * (1.0f - y) : gc;
+    p.out[pt * p.ldtop + c] = p.squeeze ? gc * y * (1.0f - y) : gc;
   }
-  for (int c = 3; c < kTop; ++c) p.out[pt * kTop + c] = 0.0f;
+  for (int c = 3; c < p.ldtop; ++c) p.out[pt * p.ldtop + c] = 0.0f;
 }
 
 CNR_HD void body_gbar_finish(const GbarFinish& p, long pt) {

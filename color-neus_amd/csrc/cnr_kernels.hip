@@ -1478,14 +1478,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwd p
                 tbar = cbar * pass * sg * (1.0f - sg);
                 gca += cbar * pass;
               }
-              p.dtop[pt * kTop + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f) + ddrel_ray;
-              p.gc_a[pt * kTop + k] = gca;
+              p.dtop[pt * p.ldtop + k] = tbar + (p.d_delta_relight ? p.d_delta_relight[pt * 3 + k] : 0.0f) + ddrel_ray;
+              p.gc_a[pt * p.ldtop + k] = gca;
             } else {
-              p.gc_a[pt * kTop + k] = cbar;
+              p.gc_a[pt * p.ldtop + k] = cbar;
             }
           }
-          if (p.has_relight) for (int k = 3; k < kTop; ++k) p.dtop[pt * kTop + k] = 0.0f;
-          for (int k = 3; k < kTop; ++k) p.gc_a[pt * kTop + k] = 0.0f;
+          if (p.has_relight) for (int k = 3; k < p.ldtop; ++k) p.dtop[pt * p.ldtop + k] = 0.0f;
+          for (int k = 3; k < p.ldtop; ++k) p.gc_a[pt * p.ldtop + k] = 0.0f;
         }
       }
     }

@@ -419,6 +419,7 @@ struct Bwd {   // backward scratch
   int fslots;                         // slots (point ranges) of a fused layer + weight-gradient launch (cnr_gemm_fdw.hip)
   int cap_slots;                      // slots reserved per layer in the pool: fslots + max(nchunk, fslots)
   int cu_slots;                       // slots of a one-workgroup-per-CU launch over 32-point tiles (cnr_sweep0.hip, cnr_narrow_bwd.hip)
+  int ldtop;                          // row stride of dtop / gc_a / dctop: 4 when both heads run the streaming head kernel, kTop for the narrow GEMM launches
 };
 
 // point ranges of a fused launch: at least four 32-point tiles per range, a multiple of 8 (two column halves per range share an XCD)
@@ -436,14 +437,26 @@ static int region_slots(const Lin& q, const Bwd& b) {
   return (q.k_int <= 48 && b.cap_slots < narrow) ? narrow : b.cap_slots;
 }
 
+// the static part of head_bwd_ok (below): the streaming backward of a <= 4-wide head on a 256-wide ReLU layer
+static bool head_bwd_static_ok(const Lin& q, int ldaux) {
+  static const bool off = getenv("CNR_NO_HEAD_BWD") != nullptr;   // debugging aid: layer launch + strip launch as before
+  return !off && q.n <= 4 && q.k_int == 256 && q.ldw == 256 && (ldaux & 3) == 0;
+}
+
 static void layout_bwd(const Model& m, long R, const Ctx& x, Arena& a, Bwd& b) {
   const long P = R * m.M;
   b.ZTOP = a.f((size_t)P * x.ldztop);
   b.gbar_a = a.f((size_t)P * 4);
-  b.dtop = a.f((size_t)P * kTop);
-  b.gc_a = a.f((size_t)P * kTop);
+  // The 3-wide cotangents of the two heads: packed 16-byte rows when both heads take the streaming head kernel (it reads one float4 per point),
+  // 16-float rows for the narrow GEMM launches otherwise (they read whole 64-byte rows: the compositor's backward then moves 58 KB per ray
+  // where 12 KB are live)
+  const bool packed = m.NC >= 2 && head_bwd_static_ok(m.col[m.NC - 1], m.Hc) && (m.Hc & 3) == 0 &&
+                      (!m.has_relight || (m.NR >= 2 && head_bwd_static_ok(m.rel[m.NR], hr_ld(m, x, m.NR - 1)) && (m.Hr & 3) == 0));
+  b.ldtop = packed ? 4 : kTop;
+  b.dtop = a.f((size_t)P * b.ldtop);
+  b.gc_a = a.f((size_t)P * b.ldtop);
   b.gc_b = a.f((size_t)P * 4);
-  b.dctop = a.f((size_t)P * kTop);
+  b.dctop = a.f((size_t)P * b.ldtop);
   b.dinvs = a.f(R);
   b.drd_alpha = a.f((size_t)R * 3);
   b.dAUXc = a.f((size_t)P * kAux);
@@ -1058,8 +1071,7 @@ static void strip_columns_of_last_finish(Bwd& b) { b.pending.back().col_hi = 256
 
 // backward of a narrow head (<= 4 outputs on a <= 256-wide ReLU layer) in one streaming launch: cotangent of the layer below + weight / bias gradient
 static bool head_bwd_ok(const Lin& q, const LayerGemm& g) {
-  static const bool off = getenv("CNR_NO_HEAD_BWD") != nullptr;   // debugging aid: layer launch + strip launch as before
-  return !off && q.n <= 4 && q.k_int == 256 && q.ldw == 256 && (g.E.ld1 & 3) == 0 && (g.E.ldaux & 3) == 0 && g.A.kind == VK_DIRECT && (g.A.lda & 3) == 0 && g.E.kind == EK_RELU_MASK &&
+  return head_bwd_static_ok(q, g.E.ldaux) && (g.E.ld1 & 3) == 0 && g.A.kind == VK_DIRECT && (g.A.lda & 3) == 0 && g.E.kind == EK_RELU_MASK &&
          g.E.split >= q.k_int && g.E.aux != nullptr && g.E.o1 != nullptr;
 }
 static void run_head_bwd(const Lin& q, const LayerGemm& g, Bwd& b, const float* const* params, float* const* dparams, cnr_stream s) {
@@ -1131,7 +1143,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   cb.d_delta_relight = m.has_relight ? go->delta_relight : nullptr;
   cb.d_delta_relight_ray = m.has_relight ? go->delta_relight_per_ray : nullptr;
   cb.d_sdf_s = go->sdf_samples; cb.d_color_s = go->color_samples; cb.d_gcolor_s = m.has_relight ? go->global_color_samples : nullptr;
-  cb.ztop = b.ZTOP; cb.ldztop = x.ldztop; cb.ztop_col = m.F; cb.gbar = b.gbar_a; cb.dtop = b.dtop; cb.gc_a = b.gc_a; cb.dinvs_partial = b.dinvs;
+  cb.ztop = b.ZTOP; cb.ldztop = x.ldztop; cb.ztop_col = m.F; cb.gbar = b.gbar_a; cb.dtop = b.dtop; cb.gc_a = b.gc_a; cb.ldtop = b.ldtop; cb.dinvs_partial = b.dinvs;
   cb.d_rays_d = rays_grad ? b.drd_alpha : nullptr; cb.d_z = nf_live ? b.dzparts : nullptr;
   be_composite_bwd(cb, s);
   VarianceFinish vf;
@@ -1146,7 +1158,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     for (int i = m.NR - 1; i >= 0; --i) {
       const Lin& q = m.rel[1 + i];
       const float* dout = (i == m.NR - 1) ? b.dtop : b.D[i + 1];
-      const int ldo = (i == m.NR - 1) ? kTop : m.Hr;
+      const int ldo = (i == m.NR - 1) ? b.ldtop : m.Hr;
       LayerGemm g;
       g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo;
       g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
@@ -1157,6 +1169,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
       d.X[0] = g.A; d.sy[0] = x.rsR[i];
       d.Y[0] = relight_input_view(m, i, x);
       if (head_bwd_ok(q, g)) { run_head_bwd(q, g, b, params, dP, s); continue; }
+      if (i == m.NR - 1 && b.ldtop != kTop) return fail("render_backward: packed head cotangents without the streaming head kernel");   // (layout_bwd decides both from the same predicate)
       const DwRegion r = take_region(q, b);
       const bool strips = strip_bwd_ok(q, g, d);
       StripBwd sb;
@@ -1208,12 +1221,12 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   // ---- 3. colour chain backward
   ColTopBwd ct;
   ct.P = P; ct.gc_a = b.gc_a; ct.gc_b = m.has_relight ? b.gc_b : nullptr; ct.gcolor = x.gcol; ct.squeeze = m.c.col_squeeze_out;
-  ct.out = b.dctop;
+  ct.out = b.dctop; ct.ldtop = b.ldtop;
   be_coltop_bwd(ct, s);
   for (int l = m.NC - 1; l >= 0; --l) {
     const Lin& q = m.col[l];
     const float* dout = (l == m.NC - 1) ? b.dctop : b.DC[l];
-    const int ldo = (l == m.NC - 1) ? kTop : m.Hc;
+    const int ldo = (l == m.NC - 1) ? b.ldtop : m.Hc;
     LayerGemm g;
     g.A.kind = VK_DIRECT; g.A.a = dout; g.A.lda = ldo;
     g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
@@ -1229,6 +1242,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     d.X[0] = g.A; d.sy[0] = x.rsC[l];
     d.Y[0] = color_input_view(m, l, x);
     if (head_bwd_ok(q, g)) { run_head_bwd(q, g, b, params, dP, s); continue; }
+    if (l == m.NC - 1 && b.ldtop != kTop) return fail("render_backward: packed head cotangents without the streaming head kernel");
     const DwRegion r = take_region(q, b);
     const bool strips = strip_bwd_ok(q, g, d);
     StripBwd sb;
