@@ -56,6 +56,15 @@ def test_bench_two_ranks_strong_scaling_line_matches_single_process():
     assert abs(one["config"]["final_loss"] - two["config"]["final_loss"]) <= 2e-5 * abs(one["config"]["final_loss"]), (one["config"]["final_loss"], two["config"]["final_loss"])
 
 
+def test_bench_four_ranks_strong_scaling_matches_single_process():
+    """The same with four ranks (the slices, the jitter rows and the two reductions do not depend on the rank count being two): the C4 form at
+    8 GPUs is this code with world = 8."""
+    one = _run(1, 16)
+    four = _run(4, 16)
+    assert four["n_gpus"] == 4 and four["config"]["rays_per_step_per_gpu"] == 4 and four["config"]["parallelism"] == "ray-sharded dp4"
+    assert abs(one["config"]["final_loss"] - four["config"]["final_loss"]) <= 2e-5 * abs(one["config"]["final_loss"]), (one["config"]["final_loss"], four["config"]["final_loss"])
+
+
 def test_plain_gpus_2_starts_two_ranks():
     """`python bench.py --gpus 2` with no launcher around it must run TWO ranks (it used to run one and print n_gpus 1)."""
     d = _run(2, 16, launcher=False)
