@@ -42,6 +42,9 @@ import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD
 F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (no sparsity)
+# What the matrix pipe ALONE sustains on this board when its operands are not constants (tools/mfma_power.py, profiles/r05_mfma_power.txt:
+# v_mfma_f32_32x32x16_f16 on all 1024 SIMDs, random f16 operands: the clock falls to 1.8 GHz at 1240-1310 W; with constant operands 2471 TFLOP/s at 1004 W)
+F16_MFMA_MEASURED_RANDOM_OPERANDS_TFLOPS = 1603.0
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s measured with a float4 copy)
 SPLIT_F16_KERNELS = ("layer_gemm_ws", "layer_dw", "dw_gemm_hx", "chain_sdf_value")   # 3 f16 MFMAs per fp32-equivalent product
 
@@ -326,6 +329,9 @@ def main():
                 "mfma_frac": round(mfma_frac, 4),
                 "mfma_achieved_tflops": round(f16_tfl, 1) if f16_tfl else round(tfl, 1),
                 "mfma_peak_tflops": F16_MFMA_PEAK_TFLOPS if f16_tfl else FP32_MFMA_PEAK_TFLOPS,
+                **({"mfma_frac_of_measured_ceiling": round(f16_tfl / F16_MFMA_MEASURED_RANDOM_OPERANDS_TFLOPS, 4),
+                    "mfma_measured_ceiling_note": "the matrix pipe alone, random f16 operands, whole chip: %.0f TFLOP/s at 1.8 GHz / 1240-1310 W "
+                                                  "(tools/mfma_power.py; 2471 TFLOP/s only with constant operands)" % F16_MFMA_MEASURED_RANDOM_OPERANDS_TFLOPS} if f16_tfl else {}),
                 "mfma_note": "f16 MFMA FLOP/s actually issued (3 per fp32-equivalent product) against the 2.5 PFLOP/s dense f16 peak" if f16_tfl
                              else "FP32 MFMA FLOP/s against the FP32 matrix peak",
                 "fp32_equiv_tflops": round(tfl, 2),
