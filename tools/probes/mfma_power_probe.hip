@@ -33,22 +33,22 @@ __global__ __launch_bounds__(512, 1) void mfma_loop(const _Float16* src, float* 
 }
 
 template <int RANDOM>
-static void run(const _Float16* src, float* out, double seconds) {
+static void run(const _Float16* src, float* out, double seconds, int wgs) {
   const int iters = 20000;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(mfma_loop<RANDOM>, dim3(256), dim3(512), 0, 0, src, out, 100);
+  hipLaunchKernelGGL(mfma_loop<RANDOM>, dim3(wgs), dim3(512), 0, 0, src, out, 100);
   CK(hipDeviceSynchronize());
   const auto t0 = std::chrono::steady_clock::now();
   double ms_tot = 0; long launches = 0;
   printf("phase %s start\n", RANDOM ? "random" : "constant"); fflush(stdout);
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
     CK(hipEventRecord(e0));
-    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(mfma_loop<RANDOM>, dim3(256), dim3(512), 0, 0, src, out, iters);
+    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(mfma_loop<RANDOM>, dim3(wgs), dim3(512), 0, 0, src, out, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms_tot += ms; launches += 4;
   }
   const double n = (double)launches * iters * 16 * 2 * 2;           // MFMAs per SIMD (2 waves x 2 chains)
-  const double flop = n * 32768.0 * 1024;
+  const double flop = n * 32768.0 * 4 * wgs;
   printf("phase %s end: %.1f ns per MFMA and SIMD, %.0f TFLOP/s of f16 MFMA (%.2f of 2500) over %.1f s\n", RANDOM ? "random" : "constant", ms_tot * 1e6 / n,
          flop / (ms_tot * 1e-3) / 1e12, flop / (ms_tot * 1e-3) / 1e12 / 2500.0, ms_tot * 1e-3);
   fflush(stdout);
@@ -56,13 +56,14 @@ static void run(const _Float16* src, float* out, double seconds) {
 
 int main(int argc, char** argv) {
   const double seconds = argc > 1 ? atof(argv[1]) : 4.0;
+  const int wgs = argc > 2 ? atoi(argv[2]) : 256;   // 256 = one workgroup per CU (the whole chip); 1 = a single CU (no power effect: the issue rate alone)
   std::vector<_Float16> h(32768);
   srand(1);
   for (auto& v : h) v = (_Float16)((rand() / (float)RAND_MAX) * 2.0f - 1.0f);
   _Float16* src; float* out;
   CK(hipMalloc(&src, h.size() * 2)); CK(hipMalloc(&out, 4));
   CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-  run<0>(src, out, seconds);
-  run<1>(src, out, seconds);
+  run<0>(src, out, seconds, wgs);
+  run<1>(src, out, seconds, wgs);
   return 0;
 }
