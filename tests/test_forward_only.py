@@ -133,8 +133,17 @@ def _check_selection_and_scratch(library, device, name):
             assert torch.equal(ref[k], got[k]), k
             assert torch.equal(ref_p[k], got_p[k]), ("pruned", k)
     # a buffer that is too small is refused, not overrun
-    small = torch.empty(max(nb_inf // 2, 16), dtype=torch.uint8, device=device)
-    assert small.numel() < nb_inf
+    real_sz = lib.lib.cnr_infer_scratch_bytes
+
+    class Half:
+        def __call__(self, *a):
+            return real_sz(*a) // 2
+    lib.lib.cnr_infer_scratch_bytes = Half()
+    try:
+        with torch.no_grad(), pytest.raises(RuntimeError, match="too small"):
+            r(o, d, near, far, z_vals=z, forward_only=True)
+    finally:
+        lib.lib.cnr_infer_scratch_bytes = real_sz
 
 
 def _check_prune(library, device, name):
