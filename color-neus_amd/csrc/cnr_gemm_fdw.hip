@@ -42,6 +42,25 @@ constexpr int FD_LDS = FD_OFF_INFO + 64;
 static_assert(FD_LDS <= 160 * 1024, "LDS budget of one CU");
 constexpr int FD_GBIG = 0x3f000000;              // "no point with two non-zero rows yet"
 
+// Round 6: the weight-gradient waves take their S' fragments with the LDS transpose read (ds_read_b64_tr_b16: a 16-lane group reads a
+// [4 points][16 columns] block of the row-major plane, 8 contiguous bytes per lane, and every lane receives one column of it) instead of
+// 8 two-byte reads per fragment: 16 LDS instructions per wave and tile instead of 64.  The four rows of a block are points 4 apart
+// (row stride 528 B = 4 banks mod 64: rows 4 points apart sit 16 banks apart, so the 2 x 4 x 4 eight-byte pieces of a 32-lane half cover
+// the 64 banks exactly once), i.e. position q = 4 h + r of k group kg in k16 block kb holds point 16 kb + 4 r + 2 kg + h; the Ep' tile is
+// written in the same point order (fd_slot), the order of the k index being free as long as both operands agree.  CNR_FDW_TR=0: the
+// two-byte gathers in natural point order (A/B builds).
+#ifndef CNR_FDW_TR
+#define CNR_FDW_TR 1
+#endif
+__device__ __forceinline__ int fd_slot(int pt) {   // position of point pt (0..31) in the k order of the weight-gradient MFMAs
+#if CNR_FDW_TR
+  return (pt & 16) | ((pt & 2) << 2) | ((pt & 1) << 2) | ((pt >> 2) & 3);
+#else
+  return pt;
+#endif
+}
+typedef short fd_s16x4 __attribute__((ext_vector_type(4)));
+
 // 2^G / sx for a power-of-two sx > 0 by exponent arithmetic (0 stays 0, NaN stays NaN, underflow flushes to 0)
 __device__ __forceinline__ float fd_yscale(float sx, int G) {
   const unsigned bits = __float_as_uint(sx);
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         ern[q] = fetch_side(tn * FD_TP + rr, ecol);
         const float ys = fd_yscale(ssr[rr], G);
         ep.x *= ys; ep.y *= ys; ep.z *= ys; ep.w *= ys;
-        unsigned char* yrow = Yb + (wave * 32 + cc) * FD_YLD + rr * 2;
+        unsigned char* yrow = Yb + (wave * 32 + cc) * FD_YLD + fd_slot(rr) * 2;
         if (!(dbg & 2))
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -351,9 +370,17 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         for (int it = 0; it < 2; ++it)
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
+#if CNR_FDW_TR
+            const unsigned char* src = B + pl * FD_APLANE + (kb * 16 + kg * 2 + 4 * ((lane & 15) >> 2)) * FD_ALD + (wd * 64 + it * 32 + (m & 16) + (lane & 3) * 4) * 2;
+            typedef __attribute__((address_space(3))) fd_s16x4* lds_s16x4;
+            const fd_s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src));
+            const fd_s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + FD_ALD));
+            a[it][pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+#else
             const unsigned char* src = B + pl * FD_APLANE + (kb * 16 + kg * 8) * FD_ALD + (wd * 64 + it * 32 + m) * 2;
 #pragma unroll
             for (int q = 0; q < 8; ++q) a[it][pl][q] = *reinterpret_cast<const _Float16*>(src + q * FD_ALD);
+#endif
           }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
