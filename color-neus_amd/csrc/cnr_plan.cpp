@@ -116,6 +116,11 @@ static int build_model(const cnr_config* cfg, Model& m) {
   if (m.F < 1 || m.F > 256 || m.F != c.col_d_feature) return fail("sdf d_out - 1 must equal colour d_feature (<= 256)");
   if (c.sdf_skip_mask & 1) return fail("skip connection at layer 0 is not supported");
   if ((c.sdf_skip_mask >> m.L) & 1) return fail("skip connection at the top layer is not supported");
+  // ONE skip connection (every shipped YAML: SKIP_IN [4], fields.py:23): the embedding cotangents of the gradient chain and of the backward
+  // pass have one buffer each (Ctx::CES, ebars).  A two-skip network used to be accepted and rendered WRONG normals (round 6: found by
+  // capturing a SKIP_IN [2, 4] fixture from the reference); it is rejected here until those buffers accumulate over the skips.
+  { int nskip = 0; for (int l = 1; l < m.L; ++l) nskip += (c.sdf_skip_mask >> l) & 1;
+    if (nskip > 1) return fail("at most one SDF skip connection is supported (SKIP_IN has %d entries)", nskip); }
   m.has_relight = c.type == 1;
   m.Hc = c.col_d_hidden; m.NC = c.col_n_layers + 1;
   if (m.Hc < 16 || m.Hc > 256 || m.Hc % 16 || c.col_n_layers < 1 || c.col_n_layers >= kMaxLayers) return fail("colour d_hidden must be a multiple of 16 in [16,256]");

@@ -187,9 +187,9 @@ def _render_forward_only(owner, rays_o, rays_d, near, far, t_rand, z_override, b
     return out
 
 
-def sample_pdf(bins, weights, n_samples, det=True, library=None):
-    """ray_utils.sample_pdf(bins, weights, n_samples, det=True) (lib/models/tools/ray_utils.py:123-154) on the device: the
-    hierarchical sampler's own kernel (cnr_sample_pdf).  det=False (never taken by the render path, NeuS.py:180): the uniform draws come
+def sample_pdf(bins, weights, n_samples, det=False, library=None):
+    """ray_utils.sample_pdf(bins, weights, n_samples, det=False) (lib/models/tools/ray_utils.py:121-154; same default as the reference) on the
+    device: the hierarchical sampler's own kernel (cnr_sample_pdf; NeuS.up_sample passes det=True, NeuS.py:180).  det=False: the uniform draws come
     from torch.rand on the CPU generator with the reference's shape and call order (ray_utils.py:135-136), the inversion runs in the same kernel."""
     lib = library if isinstance(library, _lib.RenderLibrary) else _lib.load_library(library)
     bins = bins.detach().contiguous().float()

@@ -20,6 +20,9 @@ DEV = "cuda:0"
 
 E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "dtu_noimp_sharp", "neus_dtu_sharp",
        "tiny_sharp_anneal", "dtu_sharp_anneal"]   # (*_anneal: cos_anneal_ratio 0.3 + background_rgb, reference goldens of NeuS.py:294-302)
+# round 6: the configuration branches no shipped YAML takes (WEIGHT_NORM / SQUEEZE_OUT / INCLUDE_GRAD / INV_SIGMOID False, MODE no_normal,
+# Y_IN_LAYER 2 and == N_LAYERS, the skip connection at another layer) at the tiny size and at the DTU widths -- reference goldens, tests/_golden.py VARIANTS
+E2E += list(G.VARIANTS)
 
 
 def test_library_is_hip():
@@ -50,6 +53,20 @@ def test_g2_render_core_forward_backward(name, tag):
     assert not bad, bad
     for key, got in checks:
         assert G.check_input_grad(fx, tag, key, got, strict=True) is None, G.check_input_grad(fx, tag, key, got, strict=True)
+
+
+def test_variance_gradient_population():
+    """deviation_network.variance is ONE number per run -- a cancelling sum that carries the float32 round-off of the network outputs it is
+    made of.  The 1.5x-of-the-reference's-own-float32-error rule is held on the population of all fixture runs (RMS over fixtures x tags:
+    tests/_golden.py scalar_tolerance / check_scalar_population); each single run keeps max(3e-4, 3x) under the cap inside the G2 gate."""
+    pairs = []
+    for name in E2E:
+        for tag in ("det", "jit"):
+            if "noimp" in name:
+                continue
+            res = N.run_native(name, tag, None, DEV, fixed_z=True)
+            pairs.append(G.scalar_error(res[0], tag, res[4]))
+    assert G.check_scalar_population(pairs) is None, G.check_scalar_population(pairs)
 
 
 @pytest.mark.parametrize("name", ["dtu_sharp", "dtu_init", "neus_dtu_sharp"])
@@ -123,7 +140,7 @@ def test_param_grad_error_table():
 def test_g1_sampler(name, tag):
     fx, r, out, loss, grads, o, d = N.run_native(name, tag, None, DEV, fixed_z=False, rays_grad=False)
     z = out["z_vals"].cpu()
-    assert float((z - torch.from_numpy(fx[f"{tag}:z_vals"])).abs().max()) < 1e-3
+    assert G.check_g1(z, fx, tag) is None, G.check_g1(z, fx, tag)
     assert bool((z[:, 1:] >= z[:, :-1]).all()), "z_vals must be sorted"
 
 

@@ -118,6 +118,8 @@ def _run_oracle(name, tag, fixed_z):
 
 # (*_anneal: cos_anneal_ratio 0.3 and a background colour, NeuS.py:294-302 -- the oracle branches of Color_NeuS.py:69-78, 104-106)
 E2E = ["tiny_init", "tiny_sharp", "tiny_neus_sharp", "tiny_noimp_sharp", "dtu_init", "dtu_sharp", "neus_dtu_sharp", "tiny_sharp_anneal", "dtu_sharp_anneal"]
+# round 6: the configuration branches no shipped YAML takes (tests/_golden.py VARIANTS), captured from the reference
+E2E += list(G.VARIANTS)
 
 
 @pytest.mark.parametrize("name", E2E)
@@ -130,7 +132,7 @@ def test_g1_sampler(name, tag):
     assert torch.allclose(near, torch.from_numpy(fx[f"{tag}:near"]), atol=1e-6)
     t_rand = torch.from_numpy(fx[f"{tag}:t_rand"]) if f"{tag}:t_rand" in fx else None
     z = O.sample_z(P, cfg, o, d, near, far, t_rand)
-    assert float((z - torch.from_numpy(fx[f"{tag}:z_vals"])).abs().max()) < 1e-3
+    assert G.check_g1(z, fx, tag) is None, G.check_g1(z, fx, tag)
 
 
 @pytest.mark.parametrize("name", E2E)

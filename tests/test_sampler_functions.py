@@ -40,8 +40,9 @@ def _sample_pdf_random(library, device):
         torch.rand([bins.shape[0], m])
         nxt = torch.rand(1)
         torch.manual_seed(int(fx["seed"]))
-        cn.sample_pdf(bins, w, m, det=False, library=library)
+        dflt = cn.sample_pdf(bins, w, m, library=library)   # the DEFAULT call is the reference's default: det=False (ray_utils.py:121)
         assert torch.equal(torch.rand(1), nxt)
+        assert np.array_equal(dflt.cpu().numpy(), got)
 
 
 def _up_sample(library, device):
