@@ -70,7 +70,7 @@ def _crafted_rows(library, device):
     w[4] = torch.tensor([1e-5, 0, 0, 0, 0, 0, 0, 1e-5])      # cdf jumps comparable to the 1e-5 switch
     w[5] = 3e-6                                              # all sections below the switch
     for m in (4, 16, 64):
-        got = cn.sample_pdf(bins.to(device), w.to(device), m, library=library).cpu()
+        got = cn.sample_pdf(bins.to(device), w.to(device), m, det=True, library=library).cpu()
         ref = O.sample_pdf_det(bins, w, m)
         assert float((got - ref).abs().max()) < 2e-5, m
 
