@@ -283,7 +283,7 @@ static void launch_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
   if (attr_once.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_value_chain_kernel<RT, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = (c.P + T - 1) / T;
-  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
+  const int wgs_env = debug_flags().chain_wgs;
   const long wgs = wgs_env > 0 ? wgs_env : (lds * 2 <= 160 * 1024 ? 512 : 256);   // persistent: as many workgroups as the chip holds at once
   const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
   double macs = 0.0;
@@ -293,11 +293,11 @@ static void launch_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
 }
 
 bool be_sdf_value_chain(const SdfValueChain& c, cnr_stream s) {
-  static const bool off = getenv("CNR_NO_FUSED") != nullptr;   // debugging aid: per-layer kernels everywhere
+  const bool off = debug_flags().no_fused;   // debugging aid: per-layer kernels everywhere
   if (off || c.P <= 0) return false;
   for (int l = 0; l < c.nl; ++l)
     if ((c.lay[l].K != 256 && c.lay[l].K != 48) || c.lay[l].N > 256 || c.lay[l].N < 1) return false;   // k16 block counts the kernel pins
-  static const int force = getenv("CNR_CHAIN_SHAPE") ? atoi(getenv("CNR_CHAIN_SHAPE")) : 0;   // tuning aid: 41, 22, 12
+  const int force = debug_flags().chain_shape;   // tuning aid: 41, 22, 12
   const int shape = force ? force : (c.P >= 256L * 128 ? 41 : (c.P >= 256L * 64 ? 22 : 12));
   if (shape == 41) launch_sdf_value_chain<4, 1>(c, s);
   else if (shape == 22) launch_sdf_value_chain<2, 2>(c, s);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
         else if (nkb == 2) chain_mfma_blocks<RT, 1, 2>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, kb0);
         else chain_mfma_blocks<RT, 1, 1>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, kb0);
       };
-      if (!(c.dbg & 2)) mfma_phase(S.nkb_main, 0);
+      if (!(CNR_ABLATION(c.dbg) & 2)) mfma_phase(S.nkb_main, 0);
       if (S.nkb_x > 0) {
         // ---- the extra input columns, staged over the main ones with the SAME row scale
         chain_wprime<1>(wr1, wr2, wlane, S.nkb_w, S.nkb_main, S.nkb_x);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
           }
         }
         lds_barrier();
-        if (!(c.dbg & 2)) {
+        if (!(CNR_ABLATION(c.dbg) & 2)) {
           if (S.nkb_x == 3) chain_mfma_blocks<RT, 1, 3>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, S.nkb_main);
           else if (S.nkb_x == 2) chain_mfma_blocks<RT, 1, 2>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, S.nkb_main);
           else chain_mfma_blocks<RT, 1, 1>(acc1, wr1, wr2, Ab, APLANE, wlane, S.nkb_w, S.nkb_main);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
         }
       }
       // ---- the ReLU output rows for the backward pass: 32 x 32 block -> LDS (16 rows at a time) -> 8 rows x 128 contiguous bytes per store
-      if (S.save != nullptr && !(c.dbg & 1)) {
+      if (S.save != nullptr && !(CNR_ABLATION(c.dbg) & 1)) {
         const long tile0 = tile * T;
         const int rows_left = (int)((P - tile0) < T ? (P - tile0) : T);
         float* save_tile = S.save + tile0 * S.ld_save + wave * 32;                   // (uniform)
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
               const int r = (lane >> 3) + 8 * i, ch = lane & 7;
               const f4 v = *reinterpret_cast<const f4*>(tb + r * 128 + ((ch ^ (r & 7)) << 4));
               const int row0 = rt * 32 + hpass * 16 + 8 * i;                         // first row of this 8-row group within the tile
-              if (row0 + (lane >> 3) < rows_left && !(c.dbg & 8)) *reinterpret_cast<f4*>(save_tile + row0 * S.ld_save + sv_off) = v;
+              if (row0 + (lane >> 3) < rows_left && !(CNR_ABLATION(c.dbg) & 8)) *reinterpret_cast<f4*>(save_tile + row0 * S.ld_save + sv_off) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -560,7 +560,7 @@ static void launch_sdf_save_chain(const SdfSaveChain& c, cnr_stream s) {
   if (attr_once.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_save_chain_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = (c.v.P + T - 1) / T;
-  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
+  const int wgs_env = debug_flags().chain_wgs;
   const long wgs = wgs_env > 0 ? wgs_env : 256;
   const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
   double macs = 256.0 * 256.0, bytes = (double)c.v.P * ((kEmb + 1) * 4.0 + 1024.0);
@@ -572,7 +572,7 @@ static void launch_sdf_save_chain(const SdfSaveChain& c, cnr_stream s) {
 }
 
 bool be_sdf_save_chain(const SdfSaveChain& c, cnr_stream s) {
-  static const bool off = getenv("CNR_NO_FUSED") != nullptr || getenv("CNR_NO_CHAIN_SDF") != nullptr;   // debugging aids: per-layer launches
+  const bool off = debug_flags().no_fused || debug_flags().no_chain_sdf;   // debugging aids: per-layer launches
   const SdfValueChain& v = c.v;
   if (off || v.P <= 0 || v.nl < 1 || v.nl >= kMaxLayers) return false;
   for (int l = 0; l < v.nl; ++l) {
@@ -580,7 +580,7 @@ bool be_sdf_save_chain(const SdfSaveChain& c, cnr_stream s) {
     if (l + 1 < v.nl && v.lay[l].N < 256 && !((v.skip_mask >> (l + 1)) & 1)) return false;   // a narrow layer only in front of a skip connection
   }
   if (v.lay[v.nl - 1].N != 256 || c.top.K != 256 || c.top.N != 256 || !c.top.Wf || !c.feat || (c.ld_feat & 3) || (c.ldz & 3) || c.ldz < 256) return false;
-  static const int force = getenv("CNR_CHAIN_FWD_RT") ? atoi(getenv("CNR_CHAIN_FWD_RT")) : 0;
+  const int force = debug_flags().chain_fwd_rt;
   const int rt = force ? force : (v.P >= 256L * 128 ? 4 : (v.P >= 256L * 64 ? 2 : 1));
   if (rt == 4) launch_sdf_save_chain<4>(c, s);
   else if (rt == 2) launch_sdf_save_chain<2>(c, s);
@@ -839,7 +839,7 @@ static void launch_sdf_grad_chain(const SdfGradChain& c, cnr_stream s) {
   if (attr_once.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_grad_chain_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = (c.P + T - 1) / T;
-  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
+  const int wgs_env = debug_flags().chain_wgs;
   const long wgs = wgs_env > 0 ? wgs_env : 256;
   const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
   double macs = 0.0, bytes = (double)c.P * (2.0 * kEmb * 4.0);
@@ -853,7 +853,7 @@ bool be_sdf_grad_chain(const SdfGradChain& c, cnr_stream s) {
   // 0.35 ms) -- each step's epilogue has to fetch z_{l-1} (1 KB per point, through the LDS transposition in the other direction) and run a
   // sigmoid per element before the next MFMA phase can start, and none of that overlaps the matrix work.  Kept as a
   // tested alternative (CNR_CHAIN_GRAD=1; tests/test_hip_parity.py runs the strict gate on it).
-  static const bool on = getenv("CNR_CHAIN_GRAD") != nullptr && getenv("CNR_NO_FUSED") == nullptr;
+  const bool on = debug_flags().chain_grad && !debug_flags().no_fused;
   if (!on || c.P <= 0 || c.nl < 2 || c.nl > kMaxLayers || !c.vrow || !c.ce0 || (c.ldz & 3) || c.ldz < 256) return false;
   for (int l = 0; l < c.nl; ++l) {
     const FusedLayer& Q = c.lay[l];
@@ -864,7 +864,7 @@ bool be_sdf_grad_chain(const SdfGradChain& c, cnr_stream s) {
     if (l > 0 && c.lay[l - 1].K < c.n_out[l]) return false;   // the planes of step l - 1 hold the v part
   }
   if (c.lay[0].N > kEmb) return false;
-  static const int force = getenv("CNR_CHAIN_FWD_RT") ? atoi(getenv("CNR_CHAIN_FWD_RT")) : 0;
+  const int force = debug_flags().chain_fwd_rt;
   const int rt = force ? force : (c.P >= 256L * 128 ? 4 : (c.P >= 256L * 64 ? 2 : 1));
   if (rt == 4) launch_sdf_grad_chain<4>(c, s);
   else if (rt == 2) launch_sdf_grad_chain<2>(c, s);
@@ -881,7 +881,7 @@ static void launch_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
   if (attr_once.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relu_chain_fwd_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const long ntiles = (c.P + T - 1) / T;
-  static const int wgs_env = getenv("CNR_CHAIN_WGS") ? atoi(getenv("CNR_CHAIN_WGS")) : 0;
+  const int wgs_env = debug_flags().chain_wgs;
   const long wgs = wgs_env > 0 ? wgs_env : 256;   // persistent, one workgroup per CU
   const unsigned grid = (unsigned)(ntiles < wgs ? ntiles : wgs);
   double macs = 0.0, bytes = 0.0;
@@ -894,14 +894,14 @@ static void launch_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
     if (S.head) bytes += (double)c.P * (S.head == 1 ? (c.rgb_tail ? 80.0 : 16.0) : 28.0);
   }
   TimingScope ts_("chain_fwd", 3, RT * 10 + 1, c.P, (int)(macs / 256.0), 256, 1, s, bytes);
-  static const int dbg = getenv("CNR_CHAIN_FWD_DBG") ? atoi(getenv("CNR_CHAIN_FWD_DBG")) : 0;
+  const int dbg = debug_flags().chain_fwd_dbg;
   ReluChainFwd cc = c;
   cc.dbg = dbg;
   hipLaunchKernelGGL((relu_chain_fwd_kernel<RT>), dim3(grid), dim3(512), lds, s, cc);
 }
 
 bool be_relu_chain_fwd_enabled() {
-  static const bool off = getenv("CNR_NO_FUSED") != nullptr || getenv("CNR_NO_CHAIN_FWD") != nullptr;   // debugging aids: per-layer launches
+  const bool off = debug_flags().no_fused || debug_flags().no_chain_fwd;   // debugging aids: per-layer launches
   return !off;
 }
 
@@ -925,7 +925,7 @@ bool be_relu_chain_fwd(const ReluChainFwd& c, cnr_stream s) {
     if (S.head == 2 && (!c.rel_head.W || c.rel_head.n < 1 || c.rel_head.n > 3 || (c.rel_head.ldw & 3) || !c.delta || !c.relit)) return false;
   }
   if (c.st[c.nsteps - 1].head == 0) return false;
-  static const int force = getenv("CNR_CHAIN_FWD_RT") ? atoi(getenv("CNR_CHAIN_FWD_RT")) : 0;   // tuning aid: 4, 2, 1
+  const int force = debug_flags().chain_fwd_rt;   // tuning aid: 4, 2, 1
   const int rt = force ? force : (c.P >= 256L * 128 ? 4 : (c.P >= 256L * 64 ? 2 : 1));
   if (rt == 4) launch_relu_chain_fwd<4>(c, s);
   else if (rt == 2) launch_relu_chain_fwd<2>(c, s);

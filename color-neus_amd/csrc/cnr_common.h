@@ -10,6 +10,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include "cnr_debug.h"
 
 #if defined(CNR_CPU_EMU)
 #define CNR_HD inline

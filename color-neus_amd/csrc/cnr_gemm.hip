@@ -58,8 +58,8 @@ __global__ void row_scale_kernel(const LayerGemm g) {
 }
 
 void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
-  static const bool ws_off = getenv("CNR_DISABLE_WS") != nullptr;   // debugging aid: force the FP32-MFMA kernel everywhere
-  static const int ws_kinds = getenv("CNR_WS_KINDS") ? atoi(getenv("CNR_WS_KINDS")) : 0xffff;   // bit mask of epilogue kinds
+  const bool ws_off = debug_flags().disable_ws;   // debugging aid: force the FP32-MFMA kernel everywhere
+  const int ws_kinds = debug_flags().ws_kinds;    // tuning aid: bit mask of epilogue kinds
   int ncols = g.N;
   if (g.E.tail_src && g.E.n_out + g.E.tail_n > ncols) ncols = g.E.n_out + g.E.tail_n;   // tail-fill columns need a tile too
   // layers wider than 256 columns (257 = sdf + features, 259/262 = cotangents of concatenated inputs) run as a 256-wide launch
@@ -71,7 +71,7 @@ void be_layer_gemm(const LayerGemm& g, cnr_stream s) {
     part.N = w;   // (only used for the timing record; the kernel takes its extents from K, P and the epilogue)
     const bool k_ok = g.K <= 256 || (g.K <= 272 && ws_k17_supported(g));
     part.rs_out = c0 == 0 ? g.rs_out : nullptr;   // one launch per operand writes the row scales
-    static const int ws_minw = getenv("CNR_WS_MINW") ? atoi(getenv("CNR_WS_MINW")) : 96;   // tuning knob: narrower launches take the FP32-MFMA kernel
+    const int ws_minw = debug_flags().ws_minw;   // tuning knob (96): narrower launches take the FP32-MFMA kernel
     const bool use_ws = !ws_off && ((ws_kinds >> g.E.kind) & 1) && g.Wp != nullptr && g.wscale != nullptr && w >= ws_minw && k_ok && (g.A.lda & 3) == 0;
     // the row dot is formed by the weight-stationary kernels while they stage the rows (K <= 256, first column range); otherwise by a
     // one-column launch of its own

@@ -745,8 +745,8 @@ static void launch_dw_skinny(const DwGemm& g, int n0, int k0, int ncnt, cnr_stre
 
 void be_dw_gemm(const DwGemm& g, cnr_stream s) {
   // tile the [Npad x ldk] output: 256x256 main tiles, 256x64 column tails, 32x256 row tails
-  static const bool dw_fp32 = getenv("CNR_DW_FP32") != nullptr;   // debugging aid: FP32-MFMA kernel for the main tiles too
-  static const bool dw_bf16 = getenv("CNR_DW_BF16") != nullptr;   // debugging aid: split-bf16 kernel even when row scales are available
+  const bool dw_fp32 = debug_flags().dw_fp32;   // debugging aid: FP32-MFMA kernel for the main tiles too
+  const bool dw_bf16 = debug_flags().dw_bf16;   // debugging aid: split-bf16 kernel even when row scales are available
   for (int n0 = 0; n0 < g.N; n0 += 256) {
     const int nrem = g.N - n0;
     for (int k0 = 0; k0 < g.K;) {

@@ -97,7 +97,8 @@ __device__ __forceinline__ float fd_sel4(const f4& v, int j) {   // v[j] for a p
 // TAILF: the epilogue keeps its tail fill (sweep launch of the layer below a skip connection) and runs the general 16-byte epilogue code
 // SPLITF: the value-backward epilogue keeps its split point (layer fed by a skip connection; see fdw_shape_ok), general 16-byte epilogue code
 template <int EK, bool DP, bool DD, int NKB = 16, int XR = 0, bool TAILF = false, bool SPLITF = false>
-__global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, const DwFuse f, int tiles_per_range, int dbg) {
+__global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, const DwFuse f, int tiles_per_range, int dbg_in) {
+  const int dbg = CNR_ABLATION(dbg_in);   // (CNR_FDW_DBG of the tuning build: parts of the kernel switched off; the constant 0 in the product build)
   LayerGemm g = g_in;
   g.A.kind = VK_DIRECT; g.E.kind = EK;
   if (!SPLITF) g.E.split = 1 << 30;
@@ -525,31 +526,32 @@ static void launch_fdw_v(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
   const long ntiles = g.P / FD_TP;
   const int tpr = (int)((ntiles + f.nslots - 1) / f.nslots);
   TimingScope ts_("layer_dw", 0, 200 + EK, g.P, 256, g.K, 2, s, fdw_bytes(g, f));   // pairs = 2: the layer product + the weight-gradient product
-  static const int dbg = getenv("CNR_FDW_DBG") ? atoi(getenv("CNR_FDW_DBG")) : 0;   // ablation switches (timing experiments only: results are wrong)
+  const int dbg = debug_flags().fdw_dbg;   // ablation word of the tuning build (timing experiments only: results are wrong); 0 in the product build
   hipLaunchKernelGGL((layer_dw_kernel<EK, DP, DD, NKB, XR, TAILF, SPLITF>), dim3(2 * f.nslots), dim3(512), FD_LDS, s, g, f, tpr, dbg);
 }
 template <int EK>
 static void launch_fdw(const LayerGemm& g, const DwFuse& f, cnr_stream s) {
-  static const int deep = getenv("CNR_FDW_DEEP") ? atoi(getenv("CNR_FDW_DEEP")) : 0;   // tuning aid: bit 0 = DP, bit 1 = DD
-  switch (deep & 3) {
+#ifdef CNR_TUNING
+  switch (debug_flags().fdw_deep & 3) {   // tuning aid: bit 0 = DP, bit 1 = DD (deeper prefetch: 1-5 % slower, spills; instantiated in the tuning build only)
     case 0: launch_fdw_v<EK, false, false>(g, f, s); break;
     case 1: launch_fdw_v<EK, true, false>(g, f, s); break;
     case 2: launch_fdw_v<EK, false, true>(g, f, s); break;
     default: launch_fdw_v<EK, true, true>(g, f, s); break;
   }
+#else
+  launch_fdw_v<EK, false, false>(g, f, s);
+#endif
 }
 
 bool be_fdw_enabled() {
-  static const bool off = getenv("CNR_NO_FDW") != nullptr;   // debugging aid: separate layer and weight-gradient launches everywhere
-  return !off;
+  return !debug_flags().no_fdw;   // debugging aid: separate layer and weight-gradient launches everywhere
 }
 bool be_fdw_xrow() {   // the fused launches can carry DwFuse::xrow_mode (not when their slots are filled by the separate kernels)
-  static const bool split_env = getenv("CNR_FDW_SPLIT") != nullptr;
-  return be_fdw_enabled() && !split_env;
+  return be_fdw_enabled() && !debug_flags().fdw_split;
 }
 
 void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s) {
-  static const bool split_env = getenv("CNR_FDW_SPLIT") != nullptr;   // debugging aid: the same slots filled by the two separate kernels
+  const bool split_env = debug_flags().fdw_split;   // debugging aid: the same slots filled by the two separate kernels
   const bool slots_ok = f.se != nullptr && f.nslots >= 8 && (f.nslots & 7) == 0 && f.nslots <= kFdwSlots;
   if (split_env || !slots_ok || !fdw_shape_ok(g) || f.Npad < 224 || f.Npad > 288 || f.ldk < 256 || f.ldk > 320) {
     if (f.xrow_mode != 0 || g.k_extra != 0) { if (g_first_error == hipSuccess) { g_first_error = hipErrorInvalidValue; g_first_error_where = "layer_dw: the extra-row form needs the fused launch (callers test be_fdw_xrow() and the shape)"; } return; }

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
 
 // host-side test for the stream form: every wave has weights and a live 32-column epilogue block, every lane the 16-byte epilogue path
 inline bool ws_stream_ok(const LayerGemm& g, int wrows) {
-  static const bool off = getenv("CNR_WS_NOSTREAM") != nullptr;   // debugging aid: the general kernel for every launch
+  const bool off = debug_flags().ws_nostream;   // debugging aid: the general kernel for every launch
   if (off || g.K <= 240 || g.K > 256 || g.P_dev != nullptr || (g.P % WS_TP) != 0) return false;
   if (g.dot_w != nullptr && g.E.kind != EK_SDF_TOP) return false;   // (the row dot lives in that instantiation of the stream form only)
   const int live = g.E.n_out + (g.E.tail_src ? g.E.tail_n : 0);
@@ -600,7 +600,7 @@ static void launch_ws_stream(const LayerGemm& g, cnr_stream s) {
   const size_t lds = (size_t)2 * abuf + (size_t)8 * 32 * WS_TLD * sizeof(float);
   const long ntiles = (g.P + WS_TP - 1) / WS_TP;
   if (ntiles == 0) return;
-  static const int ws_wgs = getenv("CNR_WS_WGS") ? atoi(getenv("CNR_WS_WGS")) : 256;
+  const int ws_wgs = debug_flags().ws_wgs;
   long tpw = (ntiles + ws_wgs - 1) / ws_wgs;
   if (tpw < 1) tpw = 1;
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
@@ -608,7 +608,7 @@ static void launch_ws_stream(const LayerGemm& g, cnr_stream s) {
   if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_stream_kernel<VK, EK, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  static const int ws_serp = getenv("CNR_WS_SERP") ? atoi(getenv("CNR_WS_SERP")) : 1;
+  const int ws_serp = debug_flags().ws_serp;
   const int rev = ws_serp ? ws_next_rev() : 0;
   TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
   hipLaunchKernelGGL((layer_gemm_ws_stream_kernel<VK, EK, GEN>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, rev);
@@ -621,8 +621,8 @@ static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
   const size_t lds = (size_t)2 * abuf + (size_t)8 * 32 * WS_TLD * sizeof(float);
   const long ntiles = (g.P + WS_TP - 1) / WS_TP;
   if (ntiles == 0) return;
-  static const int ws_wgs = getenv("CNR_WS_WGS") ? atoi(getenv("CNR_WS_WGS")) : 256;       // tuning knobs (defaults measured on MI355X)
-  static const int ws_mintpw = getenv("CNR_WS_MINTPW") ? atoi(getenv("CNR_WS_MINTPW")) : 1;
+  const int ws_wgs = debug_flags().ws_wgs;       // tuning knobs (defaults measured on MI355X: 256 / 1)
+  const int ws_mintpw = debug_flags().ws_mintpw;
   long tpw = (ntiles + ws_wgs - 1) / ws_wgs;   // one workgroup per CU: the weights are loaded once per CU (measured best of 256 / 512 / 768 / 1024)
   if (tpw < ws_mintpw) tpw = ws_mintpw;
   const unsigned grid = (unsigned)((ntiles + tpw - 1) / tpw);
@@ -630,7 +630,7 @@ static void launch_ws_tk(const LayerGemm& g, int wrows, cnr_stream s) {
   if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_gemm_ws_kernel<VK, EK, PLAIN, K17, FULLK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  static const int ws_serp = getenv("CNR_WS_SERP") ? atoi(getenv("CNR_WS_SERP")) : 1;   // alternate walk direction: +0.35 % (A/B, the last rows of a producer are still in L2)
+  const int ws_serp = debug_flags().ws_serp;   // alternate walk direction: +0.35 % (A/B, the last rows of a producer are still in L2)
   const int rev = ws_serp ? ws_next_rev() : 0;
   TimingScope ts_("layer_gemm_ws", 0, 100 + (g.N + 31) / 32, g.P, g.N, g.K, 1, s, layer_gemm_bytes(g));
   hipLaunchKernelGGL((layer_gemm_ws_kernel<VK, EK, PLAIN, K17, FULLK>), dim3(grid), dim3(WS_THREADS), lds, s, g, (int)tpw, wrows, rev);

@@ -19,7 +19,7 @@ void launch_layer_gemm_ws(const LayerGemm& g_in, int wrows, cnr_stream s) {
     g.E.split = 1 << 30;
     g.E.o2 = nullptr;
   }
-  static const bool generic_only = getenv("CNR_WS_GENERIC") != nullptr;   // debugging aid: interpreted kernel for every combination
+  const bool generic_only = debug_flags().ws_generic;   // debugging aid: interpreted kernel for every combination
   const int vk = g.A.kind, ek = g.E.kind;
   const bool plain = g.E.tail_src == nullptr && g.E.split == (1 << 30);
   if (g.K > 256) {

@@ -74,7 +74,7 @@ namespace {
 struct Roctx {
   int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
   Roctx() {
-    if (!getenv("CNR_ROCTX")) return;
+    if (!debug_flags().roctx) return;
     for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
       void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
       if (!h) continue;

@@ -218,7 +218,7 @@ void be_strip_bwd(const StripBwd& p, cnr_stream) {
       }
   }
 }
-bool be_fdw_enabled() { return getenv("CNR_NO_FDW") == nullptr; }
+bool be_fdw_enabled() { return !debug_flags().no_fdw; }
 bool be_fdw_xrow() { return be_fdw_enabled(); }
 void be_layer_dw_gemm(const LayerGemm& g, const DwGemm& d, const DwFuse& f, cnr_stream s) {
   // xrow_mode 2: the plain weight-gradient GEMM below forms the extra row itself (d.N covers it) but zero-fills the slots first: keep what

@@ -318,13 +318,13 @@ int be_narrow_bwd_slots(long P) {
 bool be_narrow_bwd_ok(const NarrowBwd& p) {
   // debugging aid: narrow layer launch + weight-gradient launch as before.  Only the BACKWARD forms (those with a weight gradient): the
   // product-only launch that ends the forward gradient chain has its own switch below, so that this one leaves the forward pass untouched
-  static const bool off_bwd = getenv("CNR_NO_NARROW_BWD") != nullptr;
+  const bool off_bwd = debug_flags().no_narrow_bwd;
   const bool off = off_bwd && p.partial != nullptr;
   const bool dx_ok = p.Wp == nullptr || (p.wscale && p.dx && p.ldw == 256 && p.w_rows >= 1 && p.ndx >= 1 && p.ndx <= NB_YCOLS && p.ndx <= p.w_rows && (p.lddx & 3) == 0 && p.lddx >= ((p.ndx + 3) & ~3));
   const bool dw_ok = p.partial == nullptr ? (p.Wp != nullptr && p.colsum == nullptr)
                                           : (p.Y && (p.ldy & 3) == 0 && p.ky >= 1 && p.ky <= NB_YCOLS && p.ldy >= NB_YCOLS && p.ldk >= p.ky && p.ldk <= 64 &&
                                              (p.colsum == nullptr || p.ky < NB_YCOLS));
-  static const bool off_dx = getenv("CNR_NO_NARROW_DX") != nullptr;   // debugging aid: the FP32-MFMA layer kernel for the product-only launches
+  const bool off_dx = debug_flags().no_narrow_dx;   // debugging aid: the FP32-MFMA layer kernel for the product-only launches
   const bool sig_ok = p.Xb == nullptr || ((p.ldxb & 3) == 0 && p.ldxb >= 256 && p.partial == nullptr);   // (the view form: DX-only launches)
   if (p.partial == nullptr && off_dx) return false;
   return !off && p.P > 0 && p.X && (p.ldx & 3) == 0 && p.ldx >= 256 && dx_ok && dw_ok && sig_ok;

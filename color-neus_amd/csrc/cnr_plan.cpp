@@ -22,6 +22,41 @@
 
 namespace cnr {
 
+// The library's ONLY read of the environment (cnr_debug.h lists the switches): parsed once, on first use.
+const DebugFlags& debug_flags() {
+  static const DebugFlags flags = [] {
+    DebugFlags d;
+    struct B { const char* name; bool DebugFlags::*m; };
+    struct I { const char* name; int DebugFlags::*m; };
+    static const B bools[] = {
+        {"CNR_NO_FUSED", &DebugFlags::no_fused}, {"CNR_NO_CHAIN_FWD", &DebugFlags::no_chain_fwd}, {"CNR_NO_CHAIN_SDF", &DebugFlags::no_chain_sdf},
+        {"CNR_CHAIN_GRAD", &DebugFlags::chain_grad}, {"CNR_NO_FDW", &DebugFlags::no_fdw}, {"CNR_FDW_SPLIT", &DebugFlags::fdw_split},
+        {"CNR_NO_TOP_FUSE", &DebugFlags::no_top_fuse}, {"CNR_NO_HEAD_BWD", &DebugFlags::no_head_bwd}, {"CNR_NO_HEAD_FWD", &DebugFlags::no_head_fwd},
+        {"CNR_NO_STRIP_BWD", &DebugFlags::no_strip_bwd}, {"CNR_NO_SAMPLER_FUSE", &DebugFlags::no_sampler_fuse}, {"CNR_NO_SWEEP0", &DebugFlags::no_sweep0},
+        {"CNR_NO_NARROW_BWD", &DebugFlags::no_narrow_bwd}, {"CNR_NO_NARROW_DX", &DebugFlags::no_narrow_dx}, {"CNR_DISABLE_WS", &DebugFlags::disable_ws},
+        {"CNR_WS_GENERIC", &DebugFlags::ws_generic}, {"CNR_WS_NOSTREAM", &DebugFlags::ws_nostream}, {"CNR_DW_FP32", &DebugFlags::dw_fp32},
+        {"CNR_DW_BF16", &DebugFlags::dw_bf16}, {"CNR_ROCTX", &DebugFlags::roctx}};
+    static const I ints[] = {
+        {"CNR_WS_SERP", &DebugFlags::ws_serp},
+#ifdef CNR_TUNING
+        {"CNR_WS_KINDS", &DebugFlags::ws_kinds}, {"CNR_WS_MINW", &DebugFlags::ws_minw}, {"CNR_WS_WGS", &DebugFlags::ws_wgs}, {"CNR_WS_MINTPW", &DebugFlags::ws_mintpw},
+        {"CNR_CHAIN_WGS", &DebugFlags::chain_wgs}, {"CNR_CHAIN_SHAPE", &DebugFlags::chain_shape}, {"CNR_CHAIN_FWD_RT", &DebugFlags::chain_fwd_rt},
+        {"CNR_FDW_DEEP", &DebugFlags::fdw_deep}, {"CNR_FDW_NOREV", &DebugFlags::fdw_norev}, {"CNR_FDW_REVMODE", &DebugFlags::fdw_revmode},
+        {"CNR_FDW_DBG", &DebugFlags::fdw_dbg}, {"CNR_CHAIN_FWD_DBG", &DebugFlags::chain_fwd_dbg},
+#endif
+    };
+    auto env = [](const char* name) { return getenv(name); };   // <- the one call site
+    const char* v;
+    for (const B& b : bools) d.*(b.m) = env(b.name) != nullptr;
+    for (const I& i : ints) if ((v = env(i.name)) != nullptr) d.*(i.m) = *v ? atoi(v) : 1;
+#ifdef CNR_TUNING
+    if ((v = env("CNR_CHAIN_SDF_MAXP")) != nullptr) d.chain_sdf_maxp = atol(v);
+#endif
+    return d;
+  }();
+  return flags;
+}
+
 static thread_local std::string g_err;
 static int fail(const char* fmt, ...) {
   char buf[512];
@@ -263,7 +298,7 @@ static void place_lin(Lin& q, Arena& a, bool want_wtf = false) {
   q.Wps = a.f(q.wpad > 256 ? q.wpad : 256);   // (the fused kernels read 256 column scales; entries >= npad are never used)
   q.Wtps = a.f(q.kpad > 256 ? q.kpad : 256);  // (likewise)
   q.Wf = (q.ldw <= 304) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldw / 16) * 2 * 64 * 8 / 2)) : nullptr;   // (<= 19 k16 blocks: 256 + 48)
-  static const bool grad_chain = getenv("CNR_CHAIN_GRAD") != nullptr;   // (the opt-in chain-fused gradient chain: its W^T fragments are only laid out and packed for it)
+  const bool grad_chain = debug_flags().chain_grad;   // (the opt-in chain-fused gradient chain: its W^T fragments are only laid out and packed for it)
   q.Wtf = (want_wtf && grad_chain && q.ldwt <= 256 && q.kpad <= 256) ? reinterpret_cast<unsigned short*>(a.f((size_t)8 * (q.ldwt / 16) * 2 * 64 * 8 / 2)) : nullptr;
 }
 
@@ -444,7 +479,7 @@ static int region_slots(const Lin& q, const Bwd& b) {
 
 // the static part of head_bwd_ok (below): the streaming backward of a <= 4-wide head on a 256-wide ReLU layer
 static bool head_bwd_static_ok(const Lin& q, int ldaux) {
-  static const bool off = getenv("CNR_NO_HEAD_BWD") != nullptr;   // debugging aid: layer launch + strip launch as before
+  const bool off = debug_flags().no_head_bwd;   // debugging aid: layer launch + strip launch as before
   return !off && q.n <= 4 && q.k_int == 256 && q.ldw == 256 && (ldaux & 3) == 0;
 }
 
@@ -583,7 +618,7 @@ static bool sdf_save_chain_fused(const Model& m, long n, const float* E, float* 
   // Where the chain pays: it loads the layer weights once per 128-point tile from L2 instead of once per launch and workgroup, and saves
   // 17 launches' fixed costs -- decisive for small batches; at large batches its stores do not overlap its MFMA phases and the per-layer
   // launches are faster (measured: DESIGN.md section 4.5).  CNR_CHAIN_SDF_MAXP moves the switch-over (points).
-  static const long maxp = getenv("CNR_CHAIN_SDF_MAXP") ? atol(getenv("CNR_CHAIN_SDF_MAXP")) : (1L << 62);
+  const long maxp = debug_flags().chain_sdf_maxp;
   if (n > maxp) return false;
   SdfSaveChain c;
   c.v.E = E; c.v.P = n; c.v.nl = m.L; c.v.skip_mask = m.c.sdf_skip_mask; c.v.emb = m.emb;
@@ -644,7 +679,7 @@ static void run_sampler(const Model& m, const cnr_render_inputs* in, float* z, C
   sdf_chain(m, R * m.S, x.sE, Zp, x.s_sdf0, nullptr, 0, 1.0f / scale, s);
   const int mnew = m.I / m.K;
   int n = m.S;
-  static const bool unfused = getenv("CNR_NO_SAMPLER_FUSE") != nullptr;   // debugging aid: merge / up_sample / embedding as launches of their own
+  const bool unfused = debug_flags().no_sampler_fuse;   // debugging aid: merge / up_sample / embedding as launches of their own
   MergeZ prev;   // the merge of iteration i - 1 rides on the launch of iteration i
   for (int i = 0; i < m.K; ++i) {
     const bool last = i + 1 == m.K;
@@ -752,7 +787,7 @@ static View color_input_view(const Model& m, int l, const Ctx& x) {
 
 // a narrow head (rgb, relight delta) on a 256-wide hidden layer: one streaming pass instead of a 32-column tile of the FP32-MFMA layer kernel
 static bool head_fwd(const Lin& q, const LayerGemm& g, cnr_stream s) {
-  static const bool off = getenv("CNR_NO_HEAD_FWD") != nullptr;   // debugging aid: the layer kernel for the heads
+  const bool off = debug_flags().no_head_fwd;   // debugging aid: the layer kernel for the heads
   if (off || q.n > 4 || q.k_int != 256 || g.A.kind != VK_DIRECT || g.A.scale != 1.0f || (g.A.lda & 3) != 0 || (q.ldw & 3) != 0 || g.E.tail_src != nullptr) return false;
   HeadFwd h;
   h.h = g.A.a; h.ldh = g.A.lda; h.P = g.P; h.P_dev = g.P_dev; h.W = q.W; h.ldw = q.ldw; h.n = q.n; h.E = g.E;
@@ -1040,8 +1075,8 @@ static void fused_into_region(const Lin& q, const LayerGemm& g, DwGemm& d, const
   with_bias = with_bias && slot0 == 0 && !transposed;
   DwFuse f;
   if (xrow) f = *xrow;   // (the extra-row request; everything else is set below)
-  static const bool no_rev = getenv("CNR_FDW_NOREV") != nullptr;   // tuning aid: every fused launch walks its ranges upwards
-  static const int rev_mode = getenv("CNR_FDW_REVMODE") ? atoi(getenv("CNR_FDW_REVMODE")) : 0;   // tuning aid: 1 = the opposite parities, 2 = every launch downwards
+  const bool no_rev = debug_flags().fdw_norev != 0;   // tuning aid: every fused launch walks its ranges upwards
+  const int rev_mode = debug_flags().fdw_revmode;    // tuning aid: 1 = the opposite parities, 2 = every launch downwards
   f.rev = no_rev ? 0 : (rev_mode == 1 ? !rev : (rev_mode == 2 ? 1 : rev));
   f.se = se; f.partial = r.part + (size_t)slot0 * q.npad * q.ldw; f.Npad = q.npad; f.ldk = q.ldw; f.colsum = with_bias ? r.csum : nullptr;
   f.transposed = transposed; f.nslots = b.fslots;
@@ -1055,7 +1090,7 @@ static void fused_into_region(const Lin& q, const LayerGemm& g, DwGemm& d, const
 // weight-gradient strip in one streaming pass over the layer's output cotangent (be_strip_bwd) instead of a narrow layer launch + a strip
 // launch; the main launches then cover the 256 x 256 part only.
 static bool strip_bwd_ok(const Lin& q, const LayerGemm& g, const DwGemm& d) {
-  static const bool off = getenv("CNR_NO_STRIP_BWD") != nullptr;   // debugging aid: narrow layer launch + strip launch as before
+  const bool off = debug_flags().no_strip_bwd;   // debugging aid: narrow layer launch + strip launch as before
   const int nt = q.k_int - 256;
   return !off && q.n == 256 && nt >= 1 && nt <= 8 && q.ldw >= 256 + nt && g.A.kind == VK_DIRECT && (g.A.lda & 3) == 0 && g.A.scale == 1.0f &&
          (g.E.kind == EK_RELU_MASK || g.E.kind == EK_SPLIT) && g.E.split == 256 && g.E.bias == nullptr &&
@@ -1362,7 +1397,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
   const Lin& qtop = m.sdf[m.L];
   LayerGemm gtop = vback_gemm(m.L);
   gtop.K = 256; gtop.k_extra = 1;
-  static const bool no_top = getenv("CNR_NO_TOP_FUSE") != nullptr;   // debugging aid: the top layer as three launches of its own
+  const bool no_top = debug_flags().no_top_fuse;   // debugging aid: the top layer as three launches of its own
   const bool top_fused = !no_top && fdw && be_fdw_xrow() && m.L >= 2 && fuse_g[m.L - 1] && m.F == 256 && qtop.n == 257 && qtop.k_int == 256 &&
                          qtop.ldw == 256 && qtop.npad <= 288 && x.ldztop >= 260 && x.rsY[m.L] && !m.skip(m.L) && fdw_shape_ok(gtop);
   if (top_fused) fuse_v[m.L] = 1;

@@ -278,7 +278,7 @@ int be_sweep0_slots(long P) {
 }
 
 bool be_sweep0_ok(const LayerGemm& g) {
-  static const bool off = getenv("CNR_NO_SWEEP0") != nullptr || getenv("CNR_NO_FDW") != nullptr;   // debugging aids: separate launches
+  const bool off = debug_flags().no_sweep0 || debug_flags().no_fdw;   // debugging aids: separate launches
   const Epi& e = g.E;
   return !off && g.A.kind == VK_DIRECT && g.A.scale == 1.0f && (g.A.lda & 3) == 0 && g.K >= 1 && g.K <= 48 && g.A.lda >= ((g.K + 15) / 16) * 16 && g.N == 256 &&
          g.col0 == 0 && g.first_col == 0 && g.P_dev == nullptr && g.P > 0 && g.Wp != nullptr && g.wscale != nullptr && g.ldw >= ((g.K + 15) / 16) * 16 && g.k_extra == 0 &&

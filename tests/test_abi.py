@@ -60,6 +60,22 @@ def test_unsupported_configurations_are_rejected_with_a_message():
         cn.ColorNeuSRenderer(cn.RenderConfig(sdf_skip_in=[2, 4], **base), library=path)
 
 
+def test_the_library_reads_the_environment_in_one_place():
+    """Debug / fallback switches: one parsed-once struct (csrc/cnr_debug.h, debug_flags() in cnr_plan.cpp), one getenv call site; the tuning and
+    ablation words exist only in the -DCNR_TUNING build (tools), as compile-time constants in the product."""
+    csrc = os.path.join(ROOT, "color-neus_amd", "csrc")
+    sites = []
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".cpp", ".hip", ".h")):
+            for i, line in enumerate(open(os.path.join(csrc, fn)).read().split("\n")):
+                code = line.split("//")[0]
+                if re.search(r"\bgetenv\s*\(", code):
+                    sites.append((fn, i + 1))
+    assert len(sites) == 1 and sites[0][0] == "cnr_plan.cpp", sites
+    hdr = open(os.path.join(csrc, "cnr_debug.h")).read()
+    assert "static constexpr int ws_kinds" in hdr and "#ifdef CNR_TUNING" in hdr
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         _lib.RenderLibrary(str(tmp_path / "libcolorneus_hip.so"))

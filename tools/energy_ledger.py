@@ -34,10 +34,11 @@ def family(name, seconds, rays):
     import color_neus_amd as cn
     from color_neus_amd import synthetic
     dev = torch.device("cuda:0")
-    lib = cn.load_library()
+    libpath = os.environ.get("CNR_LIB") or None    # the ablation families run on the tuning build (make hip-tuning): the product has no ablation words
+    lib = cn.load_library(libpath)
     cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)
     torch.manual_seed(0)
-    r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(dev)
+    r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg, library=libpath)).to(dev)
     views = synthetic.synthetic_view(seed=1, device=dev)
     sel = torch.randperm(views[0].shape[0], generator=torch.Generator().manual_seed(7))[:rays].to(dev)
     o, d, n, f, gt, m = [x[sel] for x in views]
@@ -47,7 +48,7 @@ def family(name, seconds, rays):
 
         def setup():
             out = r(o, d, n, f, perturb_overwrite=0)
-            state["loss"], _ = cn.compute_loss_fused(out, gt, m)
+            state["loss"], _ = cn.compute_loss_fused(out, gt, m, library=lib)
 
         def body():
             for p in r.parameters():
@@ -142,8 +143,12 @@ def main():
     fams = [("idle", {}), ("copy", {}), ("sdf_value", {}), ("forward_only", {}), ("forward_saving", {}), ("backward", {}),
             ("backward_no_dw_mfma", {"CNR_FDW_DBG": "1"}), ("backward_no_product_mfma", {"CNR_FDW_DBG": "4"}), ("backward_no_mfma", {"CNR_FDW_DBG": "5"})]
     rec = {}
+    tuning = os.path.join(ROOT, "tools", "_build", "libcolorneus_hip_tuning.so")
     for fam, env in fams:
-        e = dict(os.environ, **env)
+        if env and not os.path.isfile(tuning):
+            print("# %s skipped: no tuning build (make -C color-neus_amd/csrc hip-tuning)" % fam)
+            continue
+        e = dict(os.environ, **env, **({"CNR_LIB": tuning} if env else {}))
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--family", fam, "--seconds", str(a.seconds), "--rays", str(a.rays)],
                              env=e, capture_output=True, text=True).stdout
         for line in out.splitlines():

@@ -59,7 +59,8 @@ def run_family(name, seconds, rays):
     dev = torch.device("cuda:0")
     cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)
     torch.manual_seed(0)
-    r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(dev)
+    libpath = os.environ.get("CNR_LIB") or None   # backward_nomfma: the tuning build (make hip-tuning), the product has no ablation words
+    r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg, library=libpath)).to(dev)
     views = synthetic.synthetic_view(seed=1, device=dev)
     sel = torch.randperm(views[0].shape[0], generator=torch.Generator().manual_seed(7))[:rays].to(dev)
     o, d, n, f, gt, m = [x[sel] for x in views]
@@ -67,7 +68,7 @@ def run_family(name, seconds, rays):
     if name.startswith("backward"):
         def body():
             out = r(o, d, n, f, perturb_overwrite=0)
-            loss, _ = cn.compute_loss_fused(out, gt, m)
+            loss, _ = cn.compute_loss_fused(out, gt, m, library=cn.load_library(libpath))
             # the same graph backward again and again: only cnr_render_backward (+ the loss backward launch) repeats
             for _ in range(8):
                 for p in r.parameters():
@@ -146,7 +147,7 @@ def main():
     print("# power cap: %s W" % (mcap.group(1) if mcap else "?"))
     # every family in a child process of its own (the library reads its debugging switches once per process)
     for fam, env in (("idle", {}), ("copy", {}), ("sdf_value", {}), ("forward_only", {}), ("forward_saving", {}), ("backward", {}),
-                     ("backward_nomfma", {"CNR_FDW_DBG": "5"})):
+                     ("backward_nomfma", {"CNR_FDW_DBG": "5", "CNR_LIB": os.path.join(ROOT, "tools", "_build", "libcolorneus_hip_tuning.so")})):
         e = dict(os.environ, **env)
         subprocess.run([sys.executable, os.path.abspath(__file__), "--family", fam, "--seconds", str(a.seconds), "--rays", str(a.rays)], env=e)
 
