@@ -170,43 +170,57 @@ def main():
     # get_rays_multicam + near_far_from_sphere), not a gather from a precomputed table of all 640 000 rays.
     from color_neus_amd import rays as raygen
     Hh = Ww = 800
-    cam_c2w, cam_focal, cam_image, cam_mask = synthetic.synthetic_camera(Hh, Ww, seed=1 if strong else 1 + rank, device=dev)
+    cams = {}
+
+    def camera(strong_):   # weak: every rank its own view; strong: ONE view on every rank
+        seed = 1 if strong_ else 1 + rank
+        if seed not in cams:
+            cams[seed] = synthetic.synthetic_camera(Hh, Ww, seed=seed, device=dev)
+        return cams[seed]
+
+    cam_c2w, cam_focal, cam_image, cam_mask = camera(strong)
     n_all = Hh * Ww
     perm = torch.randperm(n_all, generator=torch.Generator().manual_seed(7)).to(dev)
 
-    def batch(i, r):
-        if strong:
+    def batch(i, r, strong_=None, solo=False):
+        strong_ = strong if strong_ is None else strong_
+        c2w_, focal_, image_, mask_ = camera(strong_)
+        if strong_ and not solo:
             rg = r * world
             idx = perm[(i * rg) % (n_all - rg):(i * rg) % (n_all - rg) + rg][rank * r:(rank + 1) * r]
         else:
             idx = perm[(i * r) % (n_all - r):(i * r) % (n_all - r) + r]
-        o, d, rgb, msel, near, far = raygen._generate(lib, idx, r, cam_c2w, cam_focal, Hh, Ww, True, False, image=cam_image, mask=cam_mask,
+        o, d, rgb, msel, near, far = raygen._generate(lib, idx, r, c2w_, focal_, Hh, Ww, True, False, image=image_, mask=mask_,
                                                       origin=None, radius=1.0, want_nearfar=True)
         return o, d, near, far, rgb, msel
 
     torch.manual_seed(2)   # jitter stream (CPU generator, like the reference)
 
-    def step(i, r=None, alt=None, outputs="dict"):
+    def step(i, r=None, alt=None, outputs="dict", strong_=None, solo=False):
+        """one optimisation step of r rays on this rank.  strong_: the ranks split ONE batch of r * world rays (BASELINE C4) instead of rendering
+        r rays of their own view each; solo: this rank alone, no collective (the one-GPU reference of the strong-scaling side leg)"""
+        strong_ = strong if strong_ is None else strong_
         r = R if r is None else r
-        rg = r * world
-        o, d, near, far, gt, mask = batch(i, r)
+        nw = 1 if solo else world
+        rg = r * nw
+        o, d, near, far, gt, mask = batch(i, r, strong_, solo)
         rnd, params, opt = alt if alt is not None else (renderer, params0, opt0)
         M = rnd.rcfg.n_total
-        if strong and world > 1:   # the whole batch's jitter draw, this rank's rows (every rank consumes the CPU generator like one process would)
+        if strong_ and nw > 1:   # the whole batch's jitter draw, this rank's rows (every rank consumes the CPU generator like one process would)
             out = rnd(o, d, near, far, training_outputs=outputs, t_rand=parallel.draw_jitter(rg, rank, world, "cpu"))
         else:
             out = rnd(o, d, near, far, training_outputs=outputs)
         if args.torch_loss:    # the torch restatement of compute_loss (and its sharded counterpart)
-            if world == 1:
+            if nw == 1:
                 loss, _ = cn.compute_loss(out, gt, mask)
             else:
                 loss, _ = parallel.sharded_loss(out, gt, mask, n_rays_global=rg, n_samples=M)
         else:                  # loss kernels of the render library; ray-sharded runs all-reduce 5 floats between their two phases
-            loss, _ = cn.compute_loss_fused(out, gt, mask, n_rays_global=rg if world > 1 else None, library=lib)
+            loss, _ = cn.compute_loss_fused(out, gt, mask, n_rays_global=rg if nw > 1 else None, library=lib)
         for p in params:
             p.grad = None
         loss.backward()
-        if world > 1:
+        if nw > 1:
             parallel.allreduce_gradients(params)   # one in-place RCCL all-reduce of the flat gradient bucket
         if not args.no_optim:
             if args.torch_optim:
@@ -222,17 +236,19 @@ def main():
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
 
-    def timed(nsteps, warmup, r=None, alt=None, per_step=None, outputs="dict"):
-        for i in range(warmup):
-            step(i, r, alt, outputs)
+    def timed(nsteps, warmup, r=None, alt=None, per_step=None, outputs="dict", strong_=None, solo=False, active=True):
+        """active=False: this rank takes no step (a solo leg of another rank) but meets the others at the barriers and in the max-reduction"""
+        loss = None
+        for i in range(warmup if active else 0):
+            step(i, r, alt, outputs, strong_, solo)
         sync()
         # per-step HIP events on the stream every kernel of the step is launched on (torch's current stream): nsteps + 1 marks
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)] if (per_step is not None and dev.type == "cuda") else None
         t0 = time.perf_counter()
-        for i in range(nsteps):
+        for i in range(nsteps if active else 0):
             if marks:
                 marks[i].record()
-            loss = step(warmup + i, r, alt, outputs)
+            loss = step(warmup + i, r, alt, outputs, strong_, solo)
         if marks:
             marks[nsteps].record()
         sync()
@@ -275,6 +291,26 @@ def main():
                            (("+rccl-allreduce" if backend == "nccl" else "+%s-allreduce" % backend) if world > 1 else ""),
                    "final_loss": float(loss.detach())},
     }
+
+    # ---- N > 1: BOTH scaling figures from one invocation (the driver's command is fixed: `bench.py --gpus N`).  The timed leg above is the
+    # line's `scaling` (weak by default: --rays per GPU, every rank its own view); this side leg is the other one.  For a weak main leg: BASELINE
+    # config C4 -- ONE batch of --rays-total rays (4096) of one view and its jitter draw split over the ranks (512 rays per GPU at 8 GPUs), same
+    # protocol (barrier + synchronise on both sides, max over ranks), next to the SAME batch as one step on one GPU of this node (rank 0 alone, the
+    # other ranks wait at the barrier), so that the strong-scaling efficiency does not need a second invocation.
+    if world > 1 and not strong and args.rays_total % world == 0:
+        n_s = max(2, min(args.steps, 60))
+        w_s = max(1, min(args.warmup, 10))
+        rs = args.rays_total // world
+        dts, loss_s = timed(n_s, w_s, r=rs, strong_=True)
+        side = {"scaling": "strong", "rays_total": args.rays_total, "rays_per_gpu": rs, "steps": n_s, "warmup": w_s,
+                "value": round(args.rays_total * n_s / dts, 1), "unit": "rays/s", "ms_per_step": round(dts / n_s * 1e3, 3),
+                "final_loss": float(loss_s.detach())}
+        # the same batch on ONE GPU of this node: rank 0 alone (no collective inside the step), everybody meets at the barriers of timed()
+        dt1, _ = timed(n_s, w_s, r=args.rays_total, strong_=True, solo=True, active=rank == 0)
+        side["one_gpu_same_batch"] = {"value": round(args.rays_total * n_s / dt1, 1), "ms_per_step": round(dt1 / n_s * 1e3, 3)}
+        side["speedup_vs_one_gpu_same_batch"] = round(dt1 / dts, 3)
+        side["efficiency_vs_n1_same_batch"] = round(dt1 / dts / world, 4)
+        result["strong_scaling"] = side
 
     if step_times:
         st = sorted(step_times)

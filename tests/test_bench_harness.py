@@ -24,10 +24,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, rays_total, extra=(), launcher=True):
+def _run(world, rays_total, extra=(), launcher=True, scaling="strong", threads=2):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(CNR_BENCH_EMU_LIB=N.EMU_LIB, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
-    args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", "strong", "--rays-total", str(rays_total), *extra]
+    env.update(CNR_BENCH_EMU_LIB=N.EMU_LIB, OMP_NUM_THREADS=str(threads), MASTER_ADDR="127.0.0.1")
+    args = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--scaling", scaling, "--rays-total", str(rays_total), *extra]
     if world == 1 or not launcher:     # plain `python bench.py --gpus N`: bench.py starts its N ranks itself
         cmd = [sys.executable] + args
     else:
@@ -40,8 +40,17 @@ def _run(world, rays_total, extra=(), launcher=True):
     return json.loads(lines[0])
 
 
+_single = {}
+
+
+def _one():   # the single-process run of the 16-ray batch, once per session
+    if "d" not in _single:
+        _single["d"] = _run(1, 16)
+    return _single["d"]
+
+
 def test_bench_two_ranks_strong_scaling_line_matches_single_process():
-    one = _run(1, 16)
+    one = _one()
     two = _run(2, 16)
     for d, w in ((one, 1), (two, 2)):
         assert d["emulation"] is True and d["n_gpus"] == w and d["scaling"] == "strong" and d["steps"] == 2 and d["warmup"] == 1
@@ -59,10 +68,36 @@ def test_bench_two_ranks_strong_scaling_line_matches_single_process():
 def test_bench_four_ranks_strong_scaling_matches_single_process():
     """The same with four ranks (the slices, the jitter rows and the two reductions do not depend on the rank count being two): the C4 form at
     8 GPUs is this code with world = 8."""
-    one = _run(1, 16)
+    one = _one()
     four = _run(4, 16)
     assert four["n_gpus"] == 4 and four["config"]["rays_per_step_per_gpu"] == 4 and four["config"]["parallelism"] == "ray-sharded dp4"
     assert abs(one["config"]["final_loss"] - four["config"]["final_loss"]) <= 2e-5 * abs(one["config"]["final_loss"]), (one["config"]["final_loss"], four["config"]["final_loss"])
+
+
+def test_bench_eight_ranks_c4_shape_matches_single_process():
+    """BASELINE C4 is EIGHT ranks splitting one batch (512 rays per GPU of 4096): the same harness with world = 8 (two rays per rank here -- the
+    emulation renders ~100 rays/s -- the code path does not depend on the shard size): slices, jitter rows, the 5-float reduction before backward
+    and the gradient all-reduce after it reproduce the single-process loss after 3 optimiser steps."""
+    one = _one()
+    eight = _run(8, 16, threads=1)
+    assert eight["n_gpus"] == 8 and eight["config"]["rays_per_step_per_gpu"] == 2 and eight["config"]["parallelism"] == "ray-sharded dp8"
+    assert eight["config"]["rays_per_step_total"] == 16 and "allreduce" in eight["config"]["step"]
+    assert abs(one["config"]["final_loss"] - eight["config"]["final_loss"]) <= 2e-5 * abs(one["config"]["final_loss"]), (one["config"]["final_loss"], eight["config"]["final_loss"])
+
+
+def test_default_invocation_carries_both_scaling_figures():
+    """The driver's command is fixed (`bench.py --gpus N`, weak scaling): the same invocation must also yield the strong-scaling figure of BASELINE C4
+    -- a `strong_scaling` object: --rays-total rays of ONE view split over the ranks, the same batch on one rank alone, speed-up and efficiency."""
+    d = _run(2, 16, extra=("--rays", "8"), scaling="weak")
+    assert d["scaling"] == "weak" and d["n_gpus"] == 2 and d["config"]["rays_per_step_per_gpu"] == 8 and d["config"]["rays_per_step_total"] == 16
+    s = d["strong_scaling"]
+    assert s["scaling"] == "strong" and s["rays_total"] == 16 and s["rays_per_gpu"] == 8 and s["unit"] == "rays/s"
+    assert abs(s["value"] - 16 / (s["ms_per_step"] * 1e-3)) <= 1e-3 * s["value"] + 0.1
+    one = s["one_gpu_same_batch"]
+    assert abs(one["value"] - 16 / (one["ms_per_step"] * 1e-3)) <= 1e-3 * one["value"] + 0.1
+    assert abs(s["speedup_vs_one_gpu_same_batch"] - one["ms_per_step"] / s["ms_per_step"]) < 2e-3 * s["speedup_vs_one_gpu_same_batch"] + 1e-3
+    assert abs(s["efficiency_vs_n1_same_batch"] - s["speedup_vs_one_gpu_same_batch"] / 2) < 1e-3
+    assert "strong_scaling" not in _run(1, 16, extra=("--rays", "8"), scaling="weak")     # one rank: nothing to split
 
 
 def test_plain_gpus_2_starts_two_ranks():
