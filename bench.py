@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the contract CPU baseline (16 was the fastest of {8,16,32,64,128} on the 2x64-core bench host)")
     ap.add_argument("--torch-loss", action="store_true", help="evaluate the loss with torch ops instead of the library's fused loss kernels")
+    ap.add_argument("--graph", action="store_true", help="one GPU: replay the step as ONE HIP graph (color-neus_amd/graph.py) instead of enqueuing its ~65 launches from "
+                                                         "the host.  Bit-identical, and measured NO faster (round 6, same-box A/B: 174.4 k against 174.7 k rays/s at 4096 rays, "
+                                                         "140.1 k / 140.5 k at 512, 157.0 k / 157.6 k at 1024: the enqueued step already keeps the GPU 98 % busy), hence opt-in")
     return ap.parse_args()
 
 
@@ -152,8 +155,15 @@ def main():
     if args.torch_optim:
         opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.99), fused=True)
     else:   # config/Color_NeuS_dtu.yml: adam, LR 5e-4, GRAD_CLIP NORM 1.0 TYPE 2 per parameter tensor
-        opt = cn.ClipAdam(renderer._ordered_params(), lr=5e-4, betas=(0.9, 0.99), eps=1e-8, max_norm=1.0, library=lib)
+        opt = cn.ClipAdam(renderer._ordered_params(), lr=5e-4, betas=(0.9, 0.99), eps=1e-8, max_norm=1.0, library=lib,
+                          capturable=not emu and world == 1 and args.graph)
     opt0 = opt
+    # --graph (one GPU): the step (ray generation -> forward -> fused loss -> backward -> clip + Adam: ~65 launches on fixed addresses) is captured ONCE per
+    # batch size in a HIP graph and replayed (color-neus_amd/graph.py); per step the host refreshes the pixel indices and the jitter draw (the CPU
+    # generator is consumed exactly like the enqueued step: torch.rand([R, 1])) in static device buffers.  Same launches, same arithmetic, bit-identical
+    # parameters (tests/test_graph_step.py).  Not the default: it measured no faster than the enqueued step (see --graph's help).
+    use_graph = (not emu and world == 1 and args.graph and not args.torch_optim and not args.torch_loss and not args.no_optim)
+    graphs = {}
 
     if args.scaling == "strong":
         if args.rays_total % world:
@@ -196,11 +206,42 @@ def main():
 
     torch.manual_seed(2)   # jitter stream (CPU generator, like the reference)
 
-    def step(i, r=None, alt=None, outputs="dict", strong_=None, solo=False):
+    def graphed_step(i, r):
+        g = graphs.get(r)
+        if g is None:
+            from color_neus_amd.graph import GraphedStep, PinnedStager
+            static = {"idx": torch.empty(r, dtype=torch.int64, device=dev), "t": torch.empty(r, 1, dtype=torch.float32, device=dev)}
+            state = {"i": i, "stager": PinnedStager()}
+            c2w_, focal_, image_, mask_ = camera(False)
+
+            def refresh():   # what changes from step to step: the chosen pixels and the jitter draw of the CPU generator
+                ii = state["i"]
+                static["idx"].copy_(perm[(ii * r) % (n_all - r):(ii * r) % (n_all - r) + r])
+                static["t"].copy_(state["stager"].to_device(torch.rand([r, 1]), dev))
+
+            def fn(idx, t):
+                o, d, rgb, msel, near, far = raygen._generate(lib, idx, r, c2w_, focal_, Hh, Ww, True, False, image=image_, mask=mask_,
+                                                              origin=None, radius=1.0, want_nearfar=True)
+                out = renderer(o, d, near, far, t_rand=t)
+                loss, _ = cn.compute_loss_fused(out, rgb, msel, library=lib)
+                for p in params0:
+                    p.grad = None
+                loss.backward()
+                opt0.step()
+                return loss
+
+            g = graphs[r] = (GraphedStep(fn, static, optimizer=opt0, warmup=2, before_each=refresh), state)
+        gs, state = g
+        state["i"] = i
+        return gs.replay()
+
+    def step(i, r=None, alt=None, outputs="dict", strong_=None, solo=False, eager=False):
         """one optimisation step of r rays on this rank.  strong_: the ranks split ONE batch of r * world rays (BASELINE C4) instead of rendering
         r rays of their own view each; solo: this rank alone, no collective (the one-GPU reference of the strong-scaling side leg)"""
         strong_ = strong if strong_ is None else strong_
         r = R if r is None else r
+        if use_graph and not eager and alt is None and outputs == "dict" and not strong_:
+            return graphed_step(i, r)
         nw = 1 if solo else world
         rg = r * nw
         o, d, near, far, gt, mask = batch(i, r, strong_, solo)
@@ -225,6 +266,8 @@ def main():
         if not args.no_optim:
             if args.torch_optim:
                 clip_per_parameter_(params)
+            if getattr(opt, "capturable", False):
+                opt.prepare_step()
             opt.step()
         return loss
 
@@ -288,7 +331,8 @@ def main():
                                "view, %d rays/step/GPU x (64+64) samples, trained-like weights" % R,
                    "rays_per_step_per_gpu": R, "rays_per_step_total": Rg, "samples_per_ray": M, "parallelism": "ray-sharded dp%d" % world,
                    "step": "fwd+" + ("torch-loss" if args.torch_loss else "fused-loss") + "+bwd" + optim_name +
-                           (("+rccl-allreduce" if backend == "nccl" else "+%s-allreduce" % backend) if world > 1 else ""),
+                           (("+rccl-allreduce" if backend == "nccl" else "+%s-allreduce" % backend) if world > 1 else "") +
+                           ("; replayed as one HIP graph" if use_graph else ""),
                    "final_loss": float(loss.detach())},
     }
 
@@ -325,7 +369,7 @@ def main():
         lib.timing_enable(rank == 0)
         nrep = min(args.steps, 3)
         for i in range(nrep):
-            step(args.warmup + args.steps + i)
+            step(args.warmup + args.steps + i, eager=True)   # (per-launch events: the enqueued form of the step)
         torch.cuda.synchronize(dev)
         recs = lib.timing_collect() if rank == 0 else []
         lib.timing_enable(False)
@@ -412,7 +456,7 @@ def main():
         # launches of a 512-ray step (the fixed per-launch costs are what separates the small-batch rate from the 4096-ray rate)
         if rank == 0 and world == 1:
             lib.timing_enable(True)
-            step(0, 512)
+            step(0, 512, eager=True)
             torch.cuda.synchronize(dev)
             result["small_batch"]["launches_per_step_512"] = len(lib.timing_collect())
             lib.timing_enable(False)

@@ -68,7 +68,7 @@ class CnrLossConfig(C.Structure):
 
 class CnrAdamConfig(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_norm", C.c_float),
-                ("step", C.c_int32)]
+                ("step", C.c_int32), ("hyper_dev", C.c_void_p)]
 
 
 class CnrInGrads(C.Structure):
@@ -189,7 +189,7 @@ class RenderLibrary:
         L.cnr_composite_background_forward.argtypes = [C.POINTER(CnrBgCompositeIn), C.POINTER(CnrOutputs), _FP, C.c_size_t, _FP]
         L.cnr_composite_background_backward.argtypes = [C.POINTER(CnrBgCompositeIn), C.POINTER(CnrOutputs), C.POINTER(CnrOutGrads),
                                                         C.POINTER(CnrBgCompositeGrads), _FP, C.c_size_t, _FP]
-        if L.cnr_abi_version() != 7:
+        if L.cnr_abi_version() != 8:
             raise RuntimeError("colorneus library ABI mismatch")
 
     @property

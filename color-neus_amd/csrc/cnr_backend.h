@@ -390,6 +390,7 @@ struct AdamArgs {
   float* m; float* v;                  // flat exp_avg / exp_avg_sq
   float lr, beta1, beta2, eps, max_norm;   // max_norm <= 0: no clipping
   float bc1, bc2_sqrt;                 // 1 - beta1^step, sqrt(1 - beta2^step)
+  const float* hyper;                  // device [3] = {lr, bc1, bc2_sqrt} or null: read instead of the three members above (graph replay)
 };
 // one tensor's update; norm2 = the tensor's sum of squared gradient entries (fixed-order reduction by the caller)
 CNR_HD float adam_clip_coef(float norm2, float max_norm) {
@@ -401,8 +402,9 @@ CNR_HD void adam_update1(const AdamArgs& a, float* w, float g, float* m, float* 
   const float m1 = *m + (g - *m) * (1.0f - a.beta1);               // exp_avg.lerp_(grad, 1 - beta1)
   const float v1 = *v * a.beta2 + (1.0f - a.beta2) * g * g;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
   *m = m1; *v = v1;
-  const float denom = sqrtf(v1) / a.bc2_sqrt + a.eps;
-  *w = *w - (a.lr / a.bc1) * (m1 / denom);                         // param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
+  const float lr = a.hyper ? a.hyper[0] : a.lr, bc1 = a.hyper ? a.hyper[1] : a.bc1, bc2_sqrt = a.hyper ? a.hyper[2] : a.bc2_sqrt;
+  const float denom = sqrtf(v1) / bc2_sqrt + a.eps;
+  *w = *w - (lr / bc1) * (m1 / denom);                         // param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
 }
 void be_clip_adam(const AdamArgs& a, cnr_stream s);   // a.partial must hold a.nchunks floats
 

@@ -2141,13 +2141,15 @@ int cnr_clip_adam_step(const cnr_adam_config* cfg, int32_t n_tensors, const int6
                        float* exp_avg, float* exp_avg_sq, void* scratch, size_t scratch_bytes, void* stream) {
   if (!cfg || !sizes || !params || !grads || !exp_avg || !exp_avg_sq || !scratch) return fail("null argument");
   if (n_tensors <= 0) return fail("n_tensors must be positive");
-  if (cfg->step < 1) return fail("step is 1-based");
+  if (cfg->step < 1 && !cfg->hyper_dev) return fail("step is 1-based");
   if (scratch_bytes < cnr_clip_adam_scratch_bytes(n_tensors, sizes)) return fail("clip_adam scratch too small");
   AdamArgs a;
   a.m = exp_avg; a.v = exp_avg_sq;
   a.lr = cfg->lr; a.beta1 = cfg->beta1; a.beta2 = cfg->beta2; a.eps = cfg->eps; a.max_norm = cfg->max_norm;
-  a.bc1 = (float)(1.0 - pow((double)cfg->beta1, (double)cfg->step));
-  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)cfg->beta2, (double)cfg->step));
+  a.hyper = cfg->hyper_dev;
+  const int step = cfg->step < 1 ? 1 : cfg->step;
+  a.bc1 = (float)(1.0 - pow((double)cfg->beta1, (double)step));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)cfg->beta2, (double)step));
   long off = 0;
   float* part = static_cast<float*>(scratch);
   a.count = 0; a.nchunks = 0; a.partial = part;

@@ -38,12 +38,22 @@ def flat_view_of_grads(params):
 
 
 class ClipAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=5e-4, betas=(0.9, 0.99), eps=1e-8, max_norm=None, library=None):
+    """clip_gradient (per parameter tensor, lib/utils/net_utils.py:174-184) + Adam (net_utils.py:88) as one library call per step.
+
+    ``capturable=True``: the step-dependent scalars (lr, 1 - beta1^t, sqrt(1 - beta2^t)) are read by the kernel from three floats in device
+    memory instead of being passed by value, so that ``step()`` can be captured ONCE in a HIP graph (graph.GraphedStep) and replayed for every
+    step: call ``prepare_step()`` before each step / replay -- it advances the step count and refreshes the three floats (pinned staging, no
+    host stall); ``step()`` itself then only enqueues the launches.  Results are identical to the default mode (same float32 values)."""
+
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.99), eps=1e-8, max_norm=None, library=None, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, max_norm=max_norm)
         super().__init__(params, defaults)
         self._library = library
         self._lib_obj = None
         self._scratch = {}
+        self.capturable = bool(capturable)
+        self._hyper = {}      # group index -> (device float[3], PinnedStager)
+        self._prepared = False
 
     @property
     def _lib(self):
@@ -51,6 +61,39 @@ class ClipAdam(torch.optim.Optimizer):
             lib = self._library
             self._lib_obj = lib if isinstance(lib, _lib.RenderLibrary) else _lib.load_library(lib)
         return self._lib_obj
+
+    def _group_state(self, gi, group):
+        allp = list(group["params"])
+        st = self.state.setdefault(allp[0], {})
+        total = sum(p.numel() for p in allp)
+        dev = allp[0].device
+        if "exp_avg" not in st:
+            st["exp_avg"] = torch.zeros(total, dtype=torch.float32, device=dev)
+            st["exp_avg_sq"] = torch.zeros(total, dtype=torch.float32, device=dev)
+            st["steps"] = [0] * len(allp)
+        return allp, st, dev
+
+    @torch.no_grad()
+    def prepare_step(self):
+        """capturable mode: advance every group's step count and refresh its device-side {lr, 1 - beta1^t, sqrt(1 - beta2^t)} (enqueued on the current
+        stream, before the step / graph replay that reads them).  All parameters of a group step together in this mode."""
+        if not self.capturable:
+            raise RuntimeError("prepare_step() belongs to ClipAdam(capturable=True)")
+        from .graph import PinnedStager
+        for gi, group in enumerate(self.param_groups):
+            allp, st, dev = self._group_state(gi, group)
+            if len(set(st["steps"])) != 1:
+                raise RuntimeError("ClipAdam(capturable=True): the parameters of a group must share one step count")
+            t = st["steps"][0] + 1
+            st["steps"] = [t] * len(allp)
+            # exactly what cnr_clip_adam_step forms from its by-value arguments: the betas as float32 values, the powers in double, the results as float32
+            b1, b2 = (float(torch.tensor(b, dtype=torch.float32)) for b in group["betas"])
+            vals = torch.tensor([float(group["lr"]), 1.0 - b1 ** t, (1.0 - b2 ** t) ** 0.5], dtype=torch.float64).float()
+            if gi not in self._hyper:
+                self._hyper[gi] = (torch.empty(3, dtype=torch.float32, device=dev), PinnedStager())
+            buf, stager = self._hyper[gi]
+            buf.copy_(stager.to_device(vals, dev))
+        self._prepared = True
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -68,14 +111,11 @@ class ClipAdam(torch.optim.Optimizer):
             # The moments of a group live in two flat buffers laid out over ALL its parameters in group order (offsets fixed for the life
             # of the optimiser), so a parameter that receives a gradient only on some steps keeps its moments and its own step count --
             # like torch.optim.Adam's per-parameter state.  The state hangs off the group's first parameter (state_dict-compatible).
-            st = self.state.setdefault(allp[0], {})
+            _, st, dev = self._group_state(gi, group)
             sizes_all = [p.numel() for p in allp]
             total = sum(sizes_all)
-            dev = allp[0].device
-            if "exp_avg" not in st:
-                st["exp_avg"] = torch.zeros(total, dtype=torch.float32, device=dev)
-                st["exp_avg_sq"] = torch.zeros(total, dtype=torch.float32, device=dev)
-                st["steps"] = [0] * len(allp)
+            if self.capturable and gi not in self._hyper:
+                raise RuntimeError("ClipAdam(capturable=True): call prepare_step() before step()")
             if "steps" not in st and "step" in st:
                 # state saved by an earlier build: one step count for the group, moments laid out over the parameters that had gradients.
                 # Loadable when that was every parameter of the group (the renderer's case); otherwise the offsets are not recoverable.
@@ -101,10 +141,12 @@ class ClipAdam(torch.optim.Optimizer):
                 while j + 1 < len(allp) and allp[j + 1].grad is not None and st["steps"][j + 1] == st["steps"][i]:
                     j += 1
                 ps = allp[i:j + 1]
-                for k in range(i, j + 1):
-                    st["steps"][k] += 1
+                if not self.capturable:
+                    for k in range(i, j + 1):
+                        st["steps"][k] += 1
                 cfg = _lib.CnrAdamConfig(lr=float(group["lr"]), beta1=float(b1), beta2=float(b2), eps=float(group["eps"]),
-                                         max_norm=float(mn) if mn else 0.0, step=int(st["steps"][i]))
+                                         max_norm=float(mn) if mn else 0.0, step=max(1, int(st["steps"][i])),
+                                         hyper_dev=self._hyper[gi][0].data_ptr() if self.capturable else None)
                 grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
                 n = len(ps)
                 sz = (C.c_int64 * n)(*sizes_all[i:j + 1])

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CNR_ABI_VERSION 7
+#define CNR_ABI_VERSION 8
 
 typedef struct cnr_config {
   int32_t type;              /* 0 = NeuS (NeuS.py:68), 1 = Color_NeuS (Color_NeuS.py:10) */
@@ -219,6 +219,10 @@ int cnr_gen_rays_backward(const int64_t* pix_idx, int64_t n, const float* c2w, i
 typedef struct cnr_adam_config {
   float lr, beta1, beta2, eps, max_norm;
   int32_t step;
+  const float* hyper_dev;   /* ABI 8; NULL, or DEVICE [3] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)}: the step-dependent scalars read from device memory
+                               instead of lr / step above, so that a launch sequence captured ONCE in a HIP graph (hipStreamBeginCapture; every entry point
+                               only enqueues on the caller's stream and allocates nothing) can be replayed for every step -- the caller refreshes the three
+                               floats before each replay (optim.ClipAdam(capturable=True).prepare_step) */
 } cnr_adam_config;
 size_t cnr_clip_adam_scratch_bytes(int32_t n_tensors, const int64_t* sizes);
 int cnr_clip_adam_step(const cnr_adam_config* cfg, int32_t n_tensors, const int64_t* sizes, float* const* params, const float* const* grads,

@@ -152,3 +152,35 @@ def test_clip_adam_loads_state_of_the_previous_layout():
         q.grad = torch.zeros_like(q)
     with pytest.raises(RuntimeError, match="earlier layout"):
         c.step()
+
+
+@pytest.mark.skipif(not os.path.isfile(N.EMU_LIB), reason="emulation library not built")
+def test_capturable_mode_reads_the_step_scalars_from_device_memory_emu():
+    """ClipAdam(capturable=True) -- cnr_adam_config.hyper_dev (ABI 8): lr and the two bias corrections read from three device floats that
+    prepare_step() refreshes, so that step() can sit in a captured HIP graph -- must produce the same bits as the by-value form, with a
+    scheduler changing lr every step; step() without prepare_step() is an error."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(33, 7), (5,), (4100,)]
+    w0 = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) * sc for s in shapes] for sc in (1e-3, 1.0, 30.0, 0.2, 1e-6, 2.0)]
+
+    def run(cap):
+        ps = [w.clone().requires_grad_(True) for w in w0]
+        opt = cn.ClipAdam(ps, lr=5e-4, betas=(0.9, 0.99), eps=1e-8, max_norm=0.05, library=N.EMU_LIB, capturable=cap)
+        for it, gs in enumerate(grads):
+            opt.param_groups[0]["lr"] = 5e-4 * (0.9 ** it)
+            for p, gr in zip(ps, gs):
+                p.grad = gr.clone()
+            if cap:
+                opt.prepare_step()
+            opt.step()
+        return [p.detach() for p in ps], opt.state[ps[0]]
+
+    (a, sa), (b, sb) = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]) and sa["steps"] == sb["steps"]
+    p = torch.zeros(3, requires_grad=True)
+    p.grad = torch.ones(3)
+    with pytest.raises(RuntimeError, match="prepare_step"):
+        cn.ClipAdam([p], library=N.EMU_LIB, capturable=True).step()

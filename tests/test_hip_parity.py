@@ -34,10 +34,8 @@ def _g2(name, tag):
     noimp = "noimp" in name   # no importance sampling (BASELINE C2): z is a closed form of near / far, which then carry gradients
     res = N.run_native(name, tag, None, DEV, fixed_z=not noimp, nearfar_grad=noimp)
     fx, r, out, loss, grads, o, d = res[:7]
-    for k in G.OUTPUT_KEYS:
-        if f"{tag}:out_{k}" in fx:
-            ref = fx[f"{tag}:out_{k}"]
-            assert G.relerr(out[k].detach().cpu().reshape(ref.shape), ref) < TOL, k
+    bad = G.check_outputs(fx, tag, out, TOL)
+    assert not bad, bad
     assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
     checks = [("grad_rays_o", o.grad), ("grad_rays_d", d.grad)] + ([("grad_near", res[7].grad), ("grad_far", res[8].grad)] if noimp else [])
     return fx, grads, checks

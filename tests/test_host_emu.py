@@ -26,9 +26,8 @@ def test_g2_render_core_forward_backward(name):
     noimp = "noimp" in name   # no importance sampling: z is a closed form of near / far, which then carry gradients (NeuS.py:311-313)
     res = N.run_native(name, tag, N.EMU_LIB, "cpu", fixed_z=not noimp, nearfar_grad=noimp)
     fx, r, out, loss, grads, o, d = res[:7]
-    for k in G.OUTPUT_KEYS:
-        if f"{tag}:out_{k}" in fx:
-            assert G.relerr(out[k].detach().reshape(fx[f"{tag}:out_{k}"].shape), fx[f"{tag}:out_{k}"]) < TOL, k
+    bad = G.check_outputs(fx, tag, out, TOL)
+    assert not bad, bad
     assert abs(float(loss.detach()) - float(fx[f"{tag}:loss"])) < TOL * abs(float(fx[f"{tag}:loss"]))
     bad = G.check_param_grads(fx, tag, grads)
     assert not bad, bad
