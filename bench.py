@@ -519,6 +519,7 @@ def main():
             vn, vf = raygen.near_far_from_sphere(vo, vd)
             # (chunks of 65536 rays: 113 GB of scratch -- what 288 GB of HBM are for: fewer, larger launches, +8 % over 8192-ray chunks)
             big = 65536 if torch.cuda.mem_get_info(dev)[0] > 170e9 else Ri
+            imgs = {}
             for tag, ch, kw in ((("view_800x800_s", Ri, dict()), ("view_800x800_pruned_s", Ri, dict(prune_eps=1e-4)),
                                  ("view_800x800_chunk%d_s" % big, big, dict()), ("view_800x800_chunk%d_pruned_s" % big, big, dict(prune_eps=1e-4)))
                                 if world == 1 else ()):   # (the chunk loop gathers over the process group)
@@ -528,6 +529,13 @@ def main():
                 img = parallel.sharded_render_image(renderer, vo, vd, vn, vf, chunk=ch, perturb_overwrite=0, **kw)
                 torch.cuda.synchronize(dev)
                 inf[tag] = round(time.perf_counter() - t1, 3)
+                # the 65536-ray chunks (P x 256 = 2^31 elements per tensor) must render the image of the 8192-ray chunks: per-ray arithmetic does not
+                # depend on the chunking (no jitter here), so any difference would be an addressing fault at that size, not round-off
+                imgs[tag] = {k: v.detach().clone() for k, v in img.items()}
+            if "view_800x800_s" in imgs and "view_800x800_chunk%d_s" % big in imgs and big != Ri:
+                inf["chunk%d_image_equals_chunk%d_image" % (big, Ri)] = all(torch.equal(v, imgs["view_800x800_chunk%d_s" % big][k]) for k, v in imgs["view_800x800_s"].items())
+                assert inf["chunk%d_image_equals_chunk%d_image" % (big, Ri)], "the 65536-ray chunks render a different image than the 8192-ray chunks"
+            imgs.clear()
             torch.cuda.empty_cache()
             del vo, vd, vn, vf
             inf["scratch_GB"] = {"forward_only": round(lib.lib.cnr_infer_scratch_bytes(__import__("ctypes").byref(renderer._ccfg), Ri) / 1e9, 2),

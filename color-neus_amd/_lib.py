@@ -162,7 +162,7 @@ class RenderLibrary:
         L.cnr_clip_adam_scratch_bytes.restype = C.c_size_t
         L.cnr_clip_adam_scratch_bytes.argtypes = [C.c_int32, C.POINTER(C.c_int64)]
         L.cnr_gen_rays.argtypes = [_FP, C.c_int64, _FP, C.c_int32, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, C.c_float,
-                                   _FP, _FP, _FP, _FP, _FP, _FP, _FP]
+                                   _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]
         L.cnr_gen_rays_backward.argtypes = [_FP, C.c_int64, _FP, C.c_int32, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP, C.c_float,
                                             _FP, _FP, _FP, _FP, _FP, _FP, _FP, C.c_size_t, _FP]
         L.cnr_sample_z.argtypes = [C.POINTER(CnrConfig), C.POINTER(_FP), C.POINTER(CnrInputs), _FP, _FP, C.c_size_t, _FP]

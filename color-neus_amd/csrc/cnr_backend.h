@@ -419,6 +419,7 @@ struct GenRays {
   const float* image; const float* mask;    // [n_cams][H][W][3] / [n_cams][H][W] or null
   const float* origin; float radius;        // rays_o = (rays_o - origin) / radius when origin != null
   float* rays_o; float* rays_d; float* rgb; float* mask_sel; float* near_; float* far_;   // any of rgb / mask_sel / near_ / far_ may be null
+  int* bad_count = nullptr;             // device counter or null: +1 per pixel index outside [0, n_cams * H * W) (an error flag, not arithmetic)
 };
 struct GenRaysBwd {
   GenRays f;                            // the forward arguments (outputs unused)

@@ -171,6 +171,16 @@ CNR_HD void body_gen_rays(const GenRays& p, long i) {
     for (int k = 0; k < 3; ++k) { p.rays_o[i * 3 + k] = nan_; p.rays_d[i * 3 + k] = nan_; if (p.rgb) p.rgb[i * 3 + k] = nan_; }
     if (p.mask_sel) p.mask_sel[i] = nan_;
     if (p.near_ && p.far_) { p.near_[i] = nan_; p.far_[i] = nan_; }
+    // the reference's torch indexing raises here; the device cannot: the ray is NaN (loud in the loss) AND counted, so that the host can raise at
+    // its next synchronisation point (rays.raise_if_bad_indices) before the NaN gradients reach the optimiser state
+    if (p.bad_count) {
+#if defined(CNR_CPU_EMU)
+#pragma omp atomic
+      *p.bad_count += 1;
+#else
+      atomicAdd(p.bad_count, 1);
+#endif
+    }
     return;
   }
   const int cam = (int)(idx / hw);

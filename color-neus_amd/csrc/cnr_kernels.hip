@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeFwd p
       carry = carry * __shfl(incl, 63);
       if (q.ok) {
         wsum += w; wmax = fmaxf(wmax, w); dep += w * q.z;
-        for (int k = 0; k < 3; ++k) col[k] += w * p.color[pt * p.ldcolor + k];
+        if (p.color) for (int k = 0; k < 3; ++k) col[k] += w * p.color[pt * p.ldcolor + k];   // (null: the weights-only pass in front of the compaction)
         if (p.gcolor) for (int k = 0; k < 3; ++k) gcl[k] += w * p.gcolor[pt * p.ldg + k];
         e0 += q.relax * (q.gn - 1.0f) * (q.gn - 1.0f);
         e1 += q.relax;
@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompositeFwd p
           p.cdf_fine[pt] = q.a.pc;
           p.inside_sphere[pt] = q.inside;
           if (p.sdf_s) p.sdf_s[pt] = p.sdf[pt];
-          if (p.color_s) for (int k = 0; k < 3; ++k) p.color_s[pt * 3 + k] = p.color[pt * p.ldcolor + k];
+          if (p.color_s && p.color) for (int k = 0; k < 3; ++k) p.color_s[pt * 3 + k] = p.color[pt * p.ldcolor + k];
           if (p.gcolor_s && p.gcolor) for (int k = 0; k < 3; ++k) p.gcolor_s[pt * 3 + k] = p.gcolor[pt * p.ldg + k];
         }
       }

@@ -521,12 +521,12 @@ void be_composite_fwd(const CompositeFwd& p, cnr_stream) {
       float w = q.a.alpha * T;
       T = T * (1.0f - q.a.alpha + 1e-7f);
       wsum += w; wmax = std::max(wmax, w); dep += w * q.z;
-      for (int k = 0; k < 3; ++k) col[k] += w * p.color[pt * p.ldcolor + k];
+      if (p.color) for (int k = 0; k < 3; ++k) col[k] += w * p.color[pt * p.ldcolor + k];
       if (p.gcolor) for (int k = 0; k < 3; ++k) gcl[k] += w * p.gcolor[pt * p.ldg + k];
       e0 += q.relax * (q.gn - 1.0f) * (q.gn - 1.0f); e1 += q.relax;
       p.weights[pt] = w; p.cdf_fine[pt] = q.a.pc; p.inside_sphere[pt] = q.inside;
       if (p.sdf_s) p.sdf_s[pt] = p.sdf[pt];
-      if (p.color_s) for (int k = 0; k < 3; ++k) p.color_s[pt * 3 + k] = p.color[pt * p.ldcolor + k];
+      if (p.color_s && p.color) for (int k = 0; k < 3; ++k) p.color_s[pt * 3 + k] = p.color[pt * p.ldcolor + k];
       if (p.gcolor_s && p.gcolor) for (int k = 0; k < 3; ++k) p.gcolor_s[pt * 3 + k] = p.gcolor[pt * p.ldg + k];
     }
     for (int k = 0; k < 3; ++k) {

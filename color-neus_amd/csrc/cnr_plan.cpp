@@ -309,7 +309,8 @@ static void layout_weights(Model& m, Arena& a) {
   for (auto& q : m.rel) place(q);
 }
 
-// shapes the chain-fused forward of the ReLU stacks takes (cnr_chain_fwd.hip; relu_chains_fused below repeats these checks on the real buffers)
+// shapes the chain-fused forward of the ReLU stacks takes (cnr_chain_fwd.hip).  THE definition: relu_chains_fused below starts with this test (what it
+// checks after that are buffer pointers), and layout_ctx_infer decides by it that the forward-only layout needs no hidden-layer buffers.
 static bool relu_fused_shapes(const Model& m) {
   if (m.Hc != 256 || m.F != 256 || m.NC < 2 || m.NC - 1 + (m.has_relight ? m.NR : 0) > kChainSteps) return false;
   const int ldfx = round_up(m.F + kAux, 16);
@@ -850,7 +851,7 @@ static void relight_chain(const Model& m, long P, const Ctx& x, float* delta_out
 // Colour chain + relight chain as ONE chain-fused launch (cnr_chain_fwd.hip) where the shapes allow: 256-wide hidden layers, a 256-wide
 // feature vector, heads of <= 3 outputs.  Returns false (nothing launched) otherwise: the per-layer chains above then run.
 static bool relu_chains_fused(const Model& m, long P, const Ctx& x, float* delta_out, cnr_stream s, const int* P_dev = nullptr, const int* row_idx = nullptr) {
-  if (m.Hc != 256 || m.F != 256 || m.NC < 2 || m.NC - 1 + (m.has_relight ? m.NR : 0) > kChainSteps) return false;
+  if (!relu_fused_shapes(m)) return false;   // (one definition of the shapes: the forward-only layout relies on the same answer)
   ReluChainFwd c;
   c.P = P; c.P_dev = P_dev; c.row_idx = row_idx;
   auto hidden_ok = [](const Lin& q, int k_lo, int k_hi) { return q.n == 256 && q.Wf && q.wpad >= 256 && q.k_int >= k_lo && q.k_int <= k_hi; };
@@ -982,7 +983,8 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
     // early termination on the forward-only path: weights first (they need only sdf and its gradient), a ballot / popcount pass per ray builds
     // the list of samples with weight >= eps (and zeroes the colour outputs of the others), and the chain-fused colour + relight launch reads
     // its rows through that list and writes the kept samples' outputs in place -- no compact copies, no scatter
-    be_composite_fwd(cf, s);
+    { CompositeFwd cw = cf; cw.color = nullptr; cw.gcolor = nullptr; cw.delta = nullptr; cw.delta_ray_sum = nullptr;   // weights only: the colour
+      be_composite_fwd(cw, s); }                                                                                       // buffers hold nothing yet
     PruneCount pc; pc.weights = out->weights; pc.R = R; pc.M = m.M; pc.eps = in->prune_eps; pc.counts = x.p_counts;
     be_prune_count(pc, s);
     PruneScan ps; ps.counts = x.p_counts; ps.R = R; ps.offsets = x.p_offsets;
@@ -998,7 +1000,7 @@ static int render_forward(const cnr_config* cfg, const float* const* params, con
     be_memset_zero(x.gcol, (size_t)P * 4 * sizeof(float), s);
     be_memset_zero(x.relit, (size_t)P * 4 * sizeof(float), s);
     if (m.has_relight) be_memset_zero(out->delta_relight, (size_t)P * 3 * sizeof(float), s);
-    be_composite_fwd(cf, s);
+    { CompositeFwd cw = cf; cw.color = nullptr; cw.gcolor = nullptr; cw.delta = nullptr; cw.delta_ray_sum = nullptr; be_composite_fwd(cw, s); }   // weights only
     PruneCount pc; pc.weights = out->weights; pc.R = R; pc.M = m.M; pc.eps = in->prune_eps; pc.counts = x.p_counts;
     be_prune_count(pc, s);
     PruneScan ps; ps.counts = x.p_counts; ps.R = R; ps.offsets = x.p_offsets;
@@ -2105,13 +2107,13 @@ static int gen_rays_args(const int64_t* pix_idx, int64_t n, const float* c2w, in
 
 int cnr_gen_rays(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
                  int32_t normalize, int32_t opengl, const float* image, const float* mask, const float* origin, float radius,
-                 float* rays_o, float* rays_d, float* rgb, float* mask_sel, float* near_, float* far_, void* stream) {
+                 float* rays_o, float* rays_d, float* rgb, float* mask_sel, float* near_, float* far_, int32_t* bad_index_count, void* stream) {
   GenRays g;
   if (gen_rays_args(pix_idx, n, c2w, n_cams, focal, H, W, normalize, opengl, origin, radius, g)) return -1;
   if (!rays_o || !rays_d) return fail("null argument");
   if ((rgb && !image) || (mask_sel && !mask)) return fail("gen_rays: rgb / mask_sel need image / mask");
   if ((near_ != nullptr) != (far_ != nullptr)) return fail("gen_rays: near and far must be given together");
-  g.image = image; g.mask = mask; g.rays_o = rays_o; g.rays_d = rays_d; g.rgb = rgb; g.mask_sel = mask_sel; g.near_ = near_; g.far_ = far_;
+  g.image = image; g.mask = mask; g.rays_o = rays_o; g.rays_d = rays_d; g.rgb = rgb; g.mask_sel = mask_sel; g.near_ = near_; g.far_ = far_; g.bad_count = bad_index_count;
   be_gen_rays(g, (cnr_stream)stream);
   return check_backend("gen_rays");
 }

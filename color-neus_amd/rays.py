@@ -51,6 +51,34 @@ def choose_pixels(n_rays, pixels_per_image, device, mask=None, mask_rate=0.9):
 
 
 _CHECK_INDICES = os.environ.get("CNR_CHECK_INDICES", "0") not in ("", "0")
+_BAD = {}   # device -> int32 counter written by the ray kernel: pixel indices outside [0, n_cams * H * W) since the last check
+
+
+def _bad_counter(dev):
+    t = _BAD.get(dev)
+    if t is None:
+        t = _BAD[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
+def bad_index_count(device=None):
+    """Out-of-range pixel indices the ray kernel has met on ``device`` (default: every device used) since the last call; resets the counter.
+    Reads device memory, i.e. synchronises -- call it where the step synchronises anyway (next to the loss' .item())."""
+    n = 0
+    for dev, t in _BAD.items():
+        if device is None or torch.device(device) == dev:
+            n += int(t.item())
+            t.zero_()
+    return n
+
+
+def raise_if_bad_indices(device=None):
+    """The reference's torch indexing raises IndexError on an out-of-range pixel index (ray_utils.py:63-76); the ray kernel cannot raise -- it
+    makes that ray NaN and counts it.  Call this at the step's synchronisation point (before the optimiser step, if NaN gradients must not
+    reach the optimiser state): raises IndexError like the reference, one step late at most."""
+    n = bad_index_count(device)
+    if n:
+        raise IndexError(f"{n} pixel index/indices outside [0, n_cams * H * W) reached cnr_gen_rays since the last check (their rays are NaN)")
 
 
 class _GenRays(torch.autograd.Function):
@@ -90,7 +118,8 @@ class _GenRays(torch.autograd.Function):
         near = torch.empty(n, **f32) if want_nearfar else None
         far = torch.empty(n, **f32) if want_nearfar else None
         rc = lib.lib.cnr_gen_rays(_ptr(idx), n, _ptr(c2w_c), c2w_c.shape[0], _ptr(focal_c), H, W, int(normalize), int(opengl), _ptr(img), _ptr(msk),
-                                  _ptr(org), float(radius), _ptr(rays_o), _ptr(rays_d), _ptr(rgb), _ptr(msel), _ptr(near), _ptr(far), _stream_of(c2w_c))
+                                  _ptr(org), float(radius), _ptr(rays_o), _ptr(rays_d), _ptr(rgb), _ptr(msel), _ptr(near), _ptr(far),
+                                  _ptr(_bad_counter(dev)) if idx is not None else C.c_void_p(0), _stream_of(c2w_c))
         lib.check(rc, "cnr_gen_rays")
         ctx.lib, ctx.meta = lib, (n, H, W, int(normalize), int(opengl), float(radius), c2w.shape, focal.shape)
         ctx.save_for_backward(idx if idx is not None else torch.empty(0, dtype=torch.int64, device=dev), c2w_c, focal_c,

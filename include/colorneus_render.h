@@ -205,7 +205,10 @@ int cnr_loss_shard_combine(const cnr_loss_config* cfg, const float* stats /* dev
  * poses / focal (config/Color_NeuS_iho.yml:18-20); scratch: n_cams * 2 floats. */
 int cnr_gen_rays(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
                  int32_t normalize, int32_t opengl, const float* image, const float* mask, const float* origin, float radius,
-                 float* rays_o, float* rays_d, float* rgb, float* mask_sel, float* near_, float* far_, void* stream);
+                 float* rays_o, float* rays_d, float* rgb, float* mask_sel, float* near_, float* far_,
+                 int32_t* bad_index_count /* ABI 8; device or NULL: incremented once per index outside [0, n_cams*H*W) -- such a ray's outputs are NaN (the
+                                             reference's torch indexing raises; the caller reads the counter at its next synchronisation point and raises) */,
+                 void* stream);
 int cnr_gen_rays_backward(const int64_t* pix_idx, int64_t n, const float* c2w, int32_t n_cams, const float* focal, int32_t H, int32_t W,
                           int32_t normalize, int32_t opengl, const float* origin, float radius, const float* d_rays_o, const float* d_rays_d,
                           const float* d_near, const float* d_far, float* d_c2w, float* d_focal, void* scratch, size_t scratch_bytes, void* stream);
@@ -247,8 +250,8 @@ int cnr_render_forward(const cnr_config* cfg, const float* const* params, const 
 /* Forward-only render -- the inference use of the path: NeuS_Trainer.validate_image (NeuS_Trainer.py:236-245 consumes color_fine and depth of every
  * chunk) and evaluation.py.  Same inputs, same outputs, BIT-IDENTICAL values to cnr_render_forward (every value-producing launch is the same
  * kernel on the same operands), but nothing is written for cnr_render_backward: no row scales, no hidden activations of the colour / relight
- * stacks, two reused buffers instead of the saved V_l of the gradient chain.  `scratch` (cnr_infer_scratch_bytes, about 60 % of
- * cnr_ctx_bytes) holds no state after the call.  prune_eps > 0 (cnr_render_inputs): the colour / relight stacks run only on the samples
+ * stacks, two reused buffers instead of the saved V_l of the gradient chain.  `scratch` (cnr_infer_scratch_bytes, about half of
+ * cnr_ctx_bytes: 14.1 GB against 29.7 GB for 8192 rays) holds no state after the call.  prune_eps > 0 (cnr_render_inputs): the colour / relight stacks run only on the samples
  * whose compositing weight is >= prune_eps -- per ray a wavefront ballot + popcount builds the index list, the chain-fused launch reads its
  * rows through it; the pixel error per skipped sample is < prune_eps, the per-sample colour outputs of skipped samples are zero. */
 size_t cnr_infer_scratch_bytes(const cnr_config* cfg, int64_t n_rays);

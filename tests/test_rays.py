@@ -101,7 +101,12 @@ def _bad_indices(library, dev):
     bad = torch.tensor([0, -1, H * W + 3, n_cams * H * W, 5, 1 << 40], dtype=torch.int64)
     lib = rays._library(library)
     og, dg, rg, mg, ng, fg = rays._generate(lib, good.to(dev), 4, c2w, focal, H, W, True, False, image=image, mask=mask, want_nearfar=True)
+    assert rays.bad_index_count(dev) == 0
+    rays.raise_if_bad_indices(dev)
     ob, db, rb, mb, nb, fb = rays._generate(lib, bad.to(dev), 6, c2w, focal, H, W, True, False, image=image, mask=mask, want_nearfar=True)
+    with pytest.raises(IndexError, match="3 pixel"):    # the device-side error counter: raised at the caller's next synchronisation point
+        rays.raise_if_bad_indices(dev)
+    assert rays.bad_index_count(dev) == 0                # (reset by the check)
     for t in (ob, db, rb, mb, nb, fb):
         t = t.detach().cpu().reshape(6, -1)
         assert bool(torch.isnan(t[[1, 3, 5]]).all()) and bool(torch.isfinite(t[[0, 2, 4]]).all())
