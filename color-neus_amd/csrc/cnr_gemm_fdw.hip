@@ -11,11 +11,11 @@
 // input tile is an L2 hit.  Inside a workgroup the waves are specialised (one of each kind per SIMD):
 //   waves 0..3 "P"  weight-stationary layer product of their 32 columns (3 x v_mfma_f32_32x32x16_f16 per k16 block, as cnr_gemm_ws.h),
 //                   fused epilogue with 16-byte global accesses, and -- from the side inputs the epilogue fetched anyway -- the tile of the
-//                   epilogue-side operand Ep, scaled and split hi / lo, written TRANSPOSED ([column][point]) into LDS;
+//                   epilogue-side operand Ep, scaled and split hi / lo, written row-major ([point][column], one 8-byte store per plane and 4 columns) into LDS;
 //   waves 4..7 "D"  stage the input tile S (HBM -> registers -> exact power-of-two row scale -> f16 hi / lo planes in LDS, the operand of
 //                   the P waves), and accumulate C[s][e] += sum_pt S'[pt][s] * Ep'[pt][e] for the tile the P waves finished one
-//                   iteration earlier: S' fragments are gathered from the row-major planes (8 two-byte reads per fragment), Ep' fragments
-//                   are 16-byte reads of the transposed tile; 64 x 128 outputs per wave = 128 accumulator registers.
+//                   iteration earlier: both fragments come out of the row-major planes by the LDS transpose read (ds_read_b64_tr_b16, two per
+//                   fragment: fd_tr8 below); 64 x 128 outputs per wave = 128 accumulator registers.
 // Per 32-point tile and SIMD: 48 + 48 MFMAs.  One workgroup barrier per tile; three input-tile buffers (stage t + 1 | product t | dW t - 1).
 //
 // Scaling of the split-f16 weight gradient (same scheme as dw_gemm_hx_kernel): S' = S * ss[pt] are the planes the layer product uses
@@ -30,8 +30,8 @@ constexpr int FD_TP = 32;                        // points per tile
 constexpr int FD_ALD = 256 * 2 + 16;             // bytes per LDS row of one S plane (+16: conflict-free ds_read_b128 of the product fragments)
 constexpr int FD_APLANE = FD_TP * FD_ALD;
 constexpr int FD_ABUF = 2 * FD_APLANE + 256;     // two planes + rs[32] (1 / row scale) + ss[32] (row scale; 0 / NaN: zero / non-finite row)
-constexpr int FD_YLD = 80;                       // bytes per column of one Ep' plane: 32 points x 2 B + 16 (conflict-free ds_read_b128)
-constexpr int FD_YPLANE = 128 * FD_YLD;
+constexpr int FD_YLD = 128 * 2 + 16;             // bytes per POINT row of one Ep' plane (round 6: row-major [point][column], see fd_tr8): 128 columns x 2 B + 16
+constexpr int FD_YPLANE = FD_TP * FD_YLD;
 constexpr int FD_YBUF = 2 * FD_YPLANE;
 constexpr int FD_TLD = 36;
 constexpr int FD_TBYTES = 32 * FD_TLD * 4;       // accumulator transposition buffer of one P wave
@@ -42,24 +42,24 @@ constexpr int FD_LDS = FD_OFF_INFO + 64;
 static_assert(FD_LDS <= 160 * 1024, "LDS budget of one CU");
 constexpr int FD_GBIG = 0x3f000000;              // "no point with two non-zero rows yet"
 
-// Round 6: the weight-gradient waves take their S' fragments with the LDS transpose read (ds_read_b64_tr_b16: a 16-lane group reads a
-// [4 points][16 columns] block of the row-major plane, 8 contiguous bytes per lane, and every lane receives one column of it) instead of
-// 8 two-byte reads per fragment: 16 LDS instructions per wave and tile instead of 64.  The four rows of a block are points 4 apart
-// (row stride 528 B = 4 banks mod 64: rows 4 points apart sit 16 banks apart, so the 2 x 4 x 4 eight-byte pieces of a 32-lane half cover
-// the 64 banks exactly once), i.e. position q = 4 h + r of k group kg in k16 block kb holds point 16 kb + 4 r + 2 kg + h; the Ep' tile is
-// written in the same point order (fd_slot), the order of the k index being free as long as both operands agree.  CNR_FDW_TR=0: the
-// two-byte gathers in natural point order (A/B builds).
-#ifndef CNR_FDW_TR
-#define CNR_FDW_TR 1
-#endif
-__device__ __forceinline__ int fd_slot(int pt) {   // position of point pt (0..31) in the k order of the weight-gradient MFMAs
-#if CNR_FDW_TR
-  return (pt & 16) | ((pt & 2) << 2) | ((pt & 1) << 2) | ((pt >> 2) & 3);
-#else
-  return pt;
-#endif
-}
+// Round 6: BOTH operands of the weight-gradient MFMAs come out of row-major [point][column] f16 planes by the LDS transpose read
+// (ds_read_b64_tr_b16: a 16-lane group reads a [4 points][16 columns] block, 8 contiguous bytes per lane, and every lane receives one column of
+// it) -- S' from the planes the product uses anyway (16 LDS reads per wave and tile instead of 64 two-byte reads), Ep' from planes the product
+// waves now write with ONE 8-byte store per plane and 4 columns (8 LDS stores per lane and tile instead of 32 two-byte transposed ones, no
+// rotation of the column order against bank conflicts: same-box ablation before the change, backward pass 14.65 ms -> 14.14 ms with those
+// stores removed).  The four rows of a block are points 4 apart: both row strides (528 B, 272 B) are 4 banks mod 64, so rows 4 points apart
+// sit 16 banks apart and the 2 x 4 x 4 eight-byte pieces of a 32-lane half cover the 64 banks exactly once.  Position q = 4 h + r of k group
+// kg in k16 block kb therefore holds point 16 kb + 4 r + 2 kg + h -- in both operands, which is all the MFMA needs.
 typedef short fd_s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 fd_f16x4 __attribute__((ext_vector_type(4)));
+// one MFMA fragment (8 k positions of this lane's row / column) out of a row-major plane: `src` = the lane's 8-byte piece of the block's row r
+// = (lane & 15) >> 2 for h = 0; the piece for h = 1 lies one point row (ld bytes) below
+__device__ __forceinline__ f16x8 fd_tr8(const unsigned char* src, int ld) {
+  typedef __attribute__((address_space(3))) fd_s16x4* lds_s16x4;
+  const fd_s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src));
+  const fd_s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + ld));
+  return __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
 // 2^G / sx for a power-of-two sx > 0 by exponent arithmetic (0 stays 0, NaN stays NaN, underflow flushes to 0)
 __device__ __forceinline__ float fd_yscale(float sx, int G) {
@@ -84,10 +84,6 @@ __device__ __forceinline__ f4 fd_ep4(const Epi& e, const EpiRaw4& raw) {
   return r;
 }
 
-__device__ __forceinline__ float fd_sel4(const f4& v, int j) {   // v[j] for a per-lane j without scratch memory
-  const float lo = (j & 1) ? v.y : v.x, hi = (j & 1) ? v.w : v.z;
-  return (j & 2) ? hi : lo;
-}
 
 // DP: the P waves keep the epilogue side inputs of TWO tiles in flight (tile i + 2 is requested while tile i is finished);
 // DD: the D waves keep two input tiles in flight (tile i + 3 is requested when tile i + 1 has been converted).
@@ -154,7 +150,6 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     const f4 wsc = *reinterpret_cast<const f4*>(g.wscale + ecol);
     const f4 bias4 = epi_bias4(g.E, ecol);
     float* T = reinterpret_cast<float*>(smem + FD_OFF_T + wave * FD_TBYTES);
-    const int jrot = (lane & 7) >> 1;                    // rotation of the 2-byte Ep' stores over a lane's 4 columns (LDS banks)
     int G = FD_GBIG;
     f4 wr1 = {0.f, 0.f, 0.f, 0.f}, xacc = {0.f, 0.f, 0.f, 0.f};   // XR: column 256 of this lane's 4 weight rows; the extra row's sums
     float xb = 0.0f;
@@ -227,16 +222,14 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         ern[q] = fetch_side(tn * FD_TP + rr, ecol);
         const float ys = fd_yscale(ssr[rr], G);
         ep.x *= ys; ep.y *= ys; ep.z *= ys; ep.w *= ys;
-        unsigned char* yrow = Yb + (wave * 32 + cc) * FD_YLD + fd_slot(rr) * 2;
-        if (!(dbg & 2))
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int j = (jj + jrot) & 3;
-          const float x = fd_sel4(ep, j);
-          const _Float16 h1 = (_Float16)x;
-          const _Float16 h2 = (_Float16)(x - (float)h1);
-          *reinterpret_cast<_Float16*>(yrow + j * FD_YLD) = h1;
-          *reinterpret_cast<_Float16*>(yrow + j * FD_YLD + FD_YPLANE) = h2;
+        unsigned char* yrow = Yb + rr * FD_YLD + (wave * 32 + cc) * 2;
+        if (!(dbg & 2)) {
+          fd_f16x4 h1, h2;
+          h1[0] = (_Float16)ep.x; h1[1] = (_Float16)ep.y; h1[2] = (_Float16)ep.z; h1[3] = (_Float16)ep.w;
+          h2[0] = (_Float16)(ep.x - (float)h1[0]); h2[1] = (_Float16)(ep.y - (float)h1[1]);
+          h2[2] = (_Float16)(ep.z - (float)h1[2]); h2[3] = (_Float16)(ep.w - (float)h1[3]);
+          *reinterpret_cast<fd_f16x4*>(yrow) = h1;
+          *reinterpret_cast<fd_f16x4*>(yrow + FD_YPLANE) = h2;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -366,28 +359,20 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
       const unsigned char* Yb = smem + FD_OFF_Y + (i & 1) * FD_YBUF;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
+        // this lane's 8-byte piece of a [4 points][16 columns] block: point row kb * 16 + 2 kg + 4 r (h = 1: one row below), 4 columns at pcol
+        const int prow = kb * 16 + kg * 2 + 4 * ((lane & 15) >> 2), pcol = (m & 16) + (lane & 3) * 4;
         f16x8 a[2][2];
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
-#if CNR_FDW_TR
-            const unsigned char* src = B + pl * FD_APLANE + (kb * 16 + kg * 2 + 4 * ((lane & 15) >> 2)) * FD_ALD + (wd * 64 + it * 32 + (m & 16) + (lane & 3) * 4) * 2;
-            typedef __attribute__((address_space(3))) fd_s16x4* lds_s16x4;
-            const fd_s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src));
-            const fd_s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + FD_ALD));
-            a[it][pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-#else
-            const unsigned char* src = B + pl * FD_APLANE + (kb * 16 + kg * 8) * FD_ALD + (wd * 64 + it * 32 + m) * 2;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) a[it][pl][q] = *reinterpret_cast<const _Float16*>(src + q * FD_ALD);
-#endif
+            a[it][pl] = fd_tr8(B + pl * FD_APLANE + prow * FD_ALD + (wd * 64 + it * 32 + pcol) * 2, FD_ALD);
           }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-          const unsigned char* ysrc = Yb + (jt * 32 + m) * FD_YLD + kb * 32 + kg * 16;
-          const f16x8 b1 = *reinterpret_cast<const f16x8*>(ysrc);
-          const f16x8 b2 = *reinterpret_cast<const f16x8*>(ysrc + FD_YPLANE);
+          const unsigned char* ysrc = Yb + prow * FD_YLD + (jt * 32 + pcol) * 2;
+          const f16x8 b1 = fd_tr8(ysrc, FD_YLD);
+          const f16x8 b2 = fd_tr8(ysrc + FD_YPLANE, FD_YLD);
           f32x16 c0 = acc[0][jt], c1 = acc[1][jt];
           c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b2, c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b2, c1, 0, 0, 0);
