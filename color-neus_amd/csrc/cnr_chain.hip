@@ -137,8 +137,7 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
       const f4 z4 = {0.f, 0.f, 0.f, 0.f};
       const f4 v = sc4 < kEmb ? erows[pass] : z4;
       float mx = ws_absmax4(v);
-#pragma unroll
-      for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+      mx = cnr_max16(mx);
       const float sc = chain_row_scale(mx);
       if (sc4 < kEmb) {
         f16x4 h1, h2;

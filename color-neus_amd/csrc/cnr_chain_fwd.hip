@@ -113,8 +113,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
         for (int pass = 0; pass < RT; ++pass) {
           const int row_l = pass * 32 + (tid >> 4);
           float mx = fmaxf(fmaxf(fmaxf(ws_absmax4(v0[pass]), ws_absmax4(v1[pass])), fmaxf(ws_absmax4(v2[pass]), ws_absmax4(v3[pass]))), ws_absmax4(vx[pass]));
-#pragma unroll
-          for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+          mx = cnr_max16(mx);
           const float sc = chain_row_scale(mx);
           unsigned char* dst = smem + row_l * CH_ALD + sc4 * 2;
           if (sc4 < ncol) chain_put4(v0[pass], sc, dst, APLANE);
@@ -415,8 +414,7 @@ __global__ __launch_bounds__(512, 1) void sdf_save_chain_kernel(const SdfSaveCha
       for (int pass = 0; pass < RT; ++pass) {
         const int row_l = pass * 32 + (tid >> 4);
         float mx = ws_absmax4(x[pass]);
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+        mx = cnr_max16(mx);
         const float sc = chain_row_scale(mx);
         if (sc4 < kEmb) chain_put4(x[pass], sc, smem + row_l * CH_ALD + sc4 * 2, APLANE);
         if ((tid & 15) == 0) rs[row_l] = 1.0f / sc;
@@ -685,8 +683,7 @@ __global__ __launch_bounds__(512, 1) void sdf_grad_chain_kernel(const SdfGradCha
           u.z = softplus100_d1(u.z) * w4[j].z * c.vscale; u.w = softplus100_d1(u.w) * w4[j].w * c.vscale;
           mx = fmaxf(mx, ws_absmax4(u));
         }
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+        mx = cnr_max16(mx);
         const float sc = chain_row_scale(mx);
         unsigned char* dst = smem + row_l * CH_ALD + sc4 * 2;
 #pragma unroll

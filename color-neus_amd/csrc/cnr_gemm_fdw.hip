@@ -325,8 +325,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
           if (ascale != 1.0f) { v[q].x *= ascale; v[q].y *= ascale; v[q].z *= ascale; v[q].w *= ascale; }
         }
         float mx = fmaxf(fmaxf(ws_absmax4(v[0]), ws_absmax4(v[1])), fmaxf(ws_absmax4(v[2]), ws_absmax4(v[3])));
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+        mx = cnr_max16(mx);
         const bool valid = mx > 0.0f && mx < 3.0e38f;
         float sc = 1.0f;
         if (valid) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); }

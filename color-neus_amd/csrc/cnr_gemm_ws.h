@@ -133,7 +133,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     const f4 v3 = pv3 ? view_finish4(g.A, r3##S_, 192 + scol) : z4;               \
     const f4 v4 = (K17 && pv4) ? view_finish4(g.A, r4##S_, 256 + scol) : z4;      \
     float mx = fmaxf(fmaxf(fmaxf(ws_absmax4(v0), ws_absmax4(v1)), fmaxf(ws_absmax4(v2), ws_absmax4(v3))), ws_absmax4(v4)); \
-    _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16)); \
+    mx = cnr_max16(mx); \
     float sc = 1.0f;                                                              \
     if (mx > 0.0f && mx < 3.0e38f) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); } /* 2^e_ clamp: subnormal rows must not overflow the scale */ \
     unsigned char* dst = smem_b + (buf_) * abuf + srow * ald + scol * 2;          \
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
     const f4 v2 = view_finish4(g.A, r2##S_, 128 + scol);                          \
     const f4 v3 = view_finish4(g.A, r3##S_, 192 + scol);                          \
     float mx = fmaxf(fmaxf(ws_absmax4(v0), ws_absmax4(v1)), fmaxf(ws_absmax4(v2), ws_absmax4(v3))); \
-    _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16)); \
+    mx = cnr_max16(mx); \
     float sc = 1.0f;                                                              \
     if (mx > 0.0f && mx < 3.0e38f) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); } \
     unsigned char* dst = smem_b + (buf_) * abuf + srow * ald + scol * 2;          \

@@ -36,6 +36,19 @@ __device__ __forceinline__ void cnr_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
+// max over the 16 lanes of a DPP row (every lane gets it) by four data-parallel-primitive moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
+// instead of four __shfl_xor(.., 16), which hipcc lowers to ds_bpermute_b32: an LDS-crossbar round trip each, on the path between a tile's
+// arrival and its f16 planes.  max is associative and commutative: bit-identical to the shuffle form.
+__device__ __forceinline__ float cnr_max16(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int v = __float_as_int(x);
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false))); v = __float_as_int(x);
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false))); v = __float_as_int(x);
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false))); v = __float_as_int(x);
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false)));
+#endif
+  return x;
+}
 #define CNR_LAUNCH_CHECK(where)                                   \
   do {                                                            \
     hipError_t e_ = hipGetLastError();                            \

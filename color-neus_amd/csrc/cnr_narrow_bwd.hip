@@ -120,8 +120,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
     if (!ylive) y = z4;
     float mx = fmaxf(fmaxf(ws_absmax4(v[0]), ws_absmax4(v[1])), fmaxf(ws_absmax4(v[2]), ws_absmax4(v[3])));
     float my = ws_absmax4(y);
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, d, 16)); my = fmaxf(my, __shfl_xor(my, d, 16)); }
+    mx = cnr_max16(mx); my = cnr_max16(my);
     const bool vx = mx > 0.0f && mx < 3.0e38f, vy = my > 0.0f && my < 3.0e38f;
     float sx = 1.0f, sy = 1.0f;
     if (vx) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sx = ldexpf(1.0f, 14 - e_); }

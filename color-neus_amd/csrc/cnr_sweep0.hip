@@ -82,8 +82,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
     const long prow = (t0 + i) * WS_TP + srow;
     const f4 v = (pv && prow < Pn) ? sraw : z4;
     float mx = ws_absmax4(v);
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+    mx = cnr_max16(mx);
     const bool valid = mx > 0.0f && mx < 3.0e38f;
     float sc = 1.0f;
     if (valid) { int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100; sc = ldexpf(1.0f, 14 - e_); }
