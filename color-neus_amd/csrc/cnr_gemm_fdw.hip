@@ -50,17 +50,6 @@ constexpr int FD_GBIG = 0x3f000000;              // "no point with two non-zero 
 // stores removed).  The four rows of a block are points 4 apart: both row strides (528 B, 272 B) are 4 banks mod 64, so rows 4 points apart
 // sit 16 banks apart and the 2 x 4 x 4 eight-byte pieces of a 32-lane half cover the 64 banks exactly once.  Position q = 4 h + r of k group
 // kg in k16 block kb therefore holds point 16 kb + 4 r + 2 kg + h -- in both operands, which is all the MFMA needs.
-typedef short fd_s16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 fd_f16x4 __attribute__((ext_vector_type(4)));
-// one MFMA fragment (8 k positions of this lane's row / column) out of a row-major plane: `src` = the lane's 8-byte piece of the block's row r
-// = (lane & 15) >> 2 for h = 0; the piece for h = 1 lies one point row (ld bytes) below
-__device__ __forceinline__ f16x8 fd_tr8(const unsigned char* src, int ld) {
-  typedef __attribute__((address_space(3))) fd_s16x4* lds_s16x4;
-  const fd_s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src));
-  const fd_s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + ld));
-  return __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-
 // 2^G / sx for a power-of-two sx > 0 by exponent arithmetic (0 stays 0, NaN stays NaN, underflow flushes to 0)
 __device__ __forceinline__ float fd_yscale(float sx, int G) {
   const unsigned bits = __float_as_uint(sx);
@@ -224,12 +213,12 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         ep.x *= ys; ep.y *= ys; ep.z *= ys; ep.w *= ys;
         unsigned char* yrow = Yb + rr * FD_YLD + (wave * 32 + cc) * 2;
         if (!(dbg & 2)) {
-          fd_f16x4 h1, h2;
+          ws_f16x4 h1, h2;
           h1[0] = (_Float16)ep.x; h1[1] = (_Float16)ep.y; h1[2] = (_Float16)ep.z; h1[3] = (_Float16)ep.w;
           h2[0] = (_Float16)(ep.x - (float)h1[0]); h2[1] = (_Float16)(ep.y - (float)h1[1]);
           h2[2] = (_Float16)(ep.z - (float)h1[2]); h2[3] = (_Float16)(ep.w - (float)h1[3]);
-          *reinterpret_cast<fd_f16x4*>(yrow) = h1;
-          *reinterpret_cast<fd_f16x4*>(yrow + FD_YPLANE) = h2;
+          *reinterpret_cast<ws_f16x4*>(yrow) = h1;
+          *reinterpret_cast<ws_f16x4*>(yrow + FD_YPLANE) = h2;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -365,13 +354,13 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         for (int it = 0; it < 2; ++it)
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
-            a[it][pl] = fd_tr8(B + pl * FD_APLANE + prow * FD_ALD + (wd * 64 + it * 32 + pcol) * 2, FD_ALD);
+            a[it][pl] = ws_tr8(B + pl * FD_APLANE + prow * FD_ALD + (wd * 64 + it * 32 + pcol) * 2, FD_ALD);
           }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
           const unsigned char* ysrc = Yb + prow * FD_YLD + (jt * 32 + pcol) * 2;
-          const f16x8 b1 = fd_tr8(ysrc, FD_YLD);
-          const f16x8 b2 = fd_tr8(ysrc + FD_YPLANE, FD_YLD);
+          const f16x8 b1 = ws_tr8(ysrc, FD_YLD);
+          const f16x8 b2 = ws_tr8(ysrc + FD_YPLANE, FD_YLD);
           f32x16 c0 = acc[0][jt], c1 = acc[1][jt];
           c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b2, c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b2, c1, 0, 0, 0);

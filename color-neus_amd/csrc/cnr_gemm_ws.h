@@ -582,6 +582,25 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
 #undef WSS_TILE
 }
 
+// ---- MFMA fragments out of ROW-MAJOR [point][column] f16 planes by the LDS transpose read (gfx950 ds_read_b64_tr_b16): a 16-lane group reads a
+// [4 points][16 columns] block, 8 contiguous bytes per lane (lane i: block row i >> 2, columns 4 (i & 3) ..), and lane i receives column i of it.
+// Two reads make one fragment (8 k positions of the lane's row / column).  The four rows of a block are taken 4 POINTS APART: with a row stride of
+// 4 banks mod 64 (528 B, 272 B, 144 B) they sit 16 banks apart and the 2 x 4 x 4 eight-byte pieces of a 32-lane half cover the 64 banks exactly
+// once.  So position q = 4 h + r of k group kg in k16 block kb holds point 16 kb + 4 r + 2 kg + h (ws_kslot is the inverse) -- for both operands of
+// a product over points, which is all the MFMA needs.  `src`: the lane's piece for h = 0 (point row kb * 16 + 2 kg + 4 ((lane & 15) >> 2), columns
+// base + (lane & 16) + 4 (lane & 3)); the piece for h = 1 lies one point row (ld bytes) below.
+typedef short ws_s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ws_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8 ws_tr8(const unsigned char* src, int ld) {
+  typedef __attribute__((address_space(3))) ws_s16x4* lds_s16x4;
+  const ws_s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src));
+  const ws_s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(src + ld));
+  return __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ int ws_kslot(int pt) {   // k position (within a 32-point tile) at which the fragments above hold point pt
+  return (pt & 16) | ((pt & 2) << 2) | ((pt & 1) << 2) | ((pt >> 2) & 3);
+}
+
 // host-side test for the stream form: every wave has weights and a live 32-column epilogue block, every lane the 16-byte epilogue path
 inline bool ws_stream_ok(const LayerGemm& g, int wrows) {
   const bool off = debug_flags().ws_nostream;   // debugging aid: the general kernel for every launch

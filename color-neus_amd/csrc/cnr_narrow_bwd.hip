@@ -8,10 +8,10 @@
 //
 // Layout: one workgroup per point range (= partial-sum slot), 8 waves, 32-point tiles, double buffered.  A tile of X is staged like a layer
 // input (cnr_gemm_ws.h: exact power-of-two row scale ss, f16 hi / lo planes, row-major); the tile of Y gets its own row scale sy and is stored
-// TRANSPOSED ([column][point]) with a column of ones behind its ky columns: that column of dW is the bias gradient.  dX: waves 0 / 1 take the
+// row-major as well (one 8-byte store per plane and thread) with a column of ones behind its ky columns: that column of dW is the bias gradient.  dX: waves 0 / 1 take the
 // 2 x 32 columns; the f16 planes of W^T (48 rows) sit in LDS for the whole launch (K = 256: 16 k16 blocks x 3 MFMAs per tile and wave).
-// dW: wave w owns rows j in [32 w, 32 w + 32): A fragments are gathered from the X planes (two-byte reads), B fragments are 16-byte reads of
-// the transposed Y planes.  The planes carry ss[pt] sy[pt] X Y; every A element is multiplied by the exact power of two 2^(Gt - e[pt]) <= 1,
+// dW: wave w owns rows j in [32 w, 32 w + 32): both fragments come out of the row-major planes by the LDS transpose read (ws_tr8, cnr_gemm_ws.h;
+// round 6: 8 + 8 reads per tile and wave instead of 32 two-byte reads + 8 sixteen-byte reads of a transposed Y tile written with two-byte stores).  The planes carry ss[pt] sy[pt] X Y; every A element is multiplied by the exact power of two 2^(Gt - e[pt]) <= 1,
 // e = log2(ss sy), Gt = min of e over the tile (an f16 multiply by a power of two down to the subnormal 2^-24: the product keeps the f16 subnormal
 // grid, i.e. an absolute error of 2^-25 per element like any other split operand), so a tile's MFMAs form 2^Gt sum X Y; the tile result is folded
 // into the fp32 totals with 2^-Gt.  Two staging register sets keep two tiles in flight; fixed order: bitwise deterministic.
@@ -23,9 +23,9 @@ namespace cnr {
 constexpr int NB_ALD = 256 * 2 + 16;
 constexpr int NB_APLANE = WS_TP * NB_ALD;
 constexpr int NB_ABUF = 2 * NB_APLANE + 256;      // two planes + rs[32] (1 / ss) + e[32] (int: log2(ss sy); NB_EBIG: the row contributes nothing)
-constexpr int NB_YLD = 80;                        // bytes per column of one Y plane: 32 points x 2 B + 16
 constexpr int NB_YCOLS = 48;
-constexpr int NB_YPLANE = NB_YCOLS * NB_YLD;
+constexpr int NB_YLD = 144;                       // bytes per POINT row of one Y plane (row-major [point][column], round 6): 48 columns x 2 B + 48 -- 36 dwords = 4 banks mod 16 (ws_tr8)
+constexpr int NB_YPLANE = WS_TP * NB_YLD;
 constexpr int NB_YBUF = 2 * NB_YPLANE;
 constexpr int NB_OFF_Y = 2 * NB_ABUF;
 constexpr int NB_OFF_T = NB_OFF_Y + 2 * NB_YBUF;
@@ -130,15 +130,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
 #pragma unroll
     for (int q = 0; q < 4; ++q) ws_put4(v[q], sx, dst + 128 * q, NB_APLANE);
     if (DW && ylive) {
-      unsigned char* yb = smem_n + NB_OFF_Y + buf * NB_YBUF + scol * NB_YLD + srow * 2;
+      unsigned char* yb = smem_n + NB_OFF_Y + buf * NB_YBUF + srow * NB_YLD + scol * 2;
       const float ya[4] = {y.x * sy, y.y * sy, y.z * sy, y.w * sy};
+      ws_f16x4 h1, h2;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const _Float16 h1 = (_Float16)ya[j];
-        const _Float16 h2 = (_Float16)(ya[j] - (float)h1);
-        *reinterpret_cast<_Float16*>(yb + j * NB_YLD) = h1;
-        *reinterpret_cast<_Float16*>(yb + j * NB_YLD + NB_YPLANE) = h2;
-      }
+      for (int j = 0; j < 4; ++j) { h1[j] = (_Float16)ya[j]; h2[j] = (_Float16)(ya[j] - (float)h1[j]); }
+      *reinterpret_cast<ws_f16x4*>(yb) = h1;
+      *reinterpret_cast<ws_f16x4*>(yb + NB_YPLANE) = h2;
     }
     if ((tid & 15) == 0) {
       float* rs = reinterpret_cast<float*>(B + 2 * NB_APLANE);
@@ -238,29 +236,23 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
         const int d = Gt - e_l;                          // <= 0 for live rows
         unsigned short bits = (e_l == NB_EBIG || d < -24) ? (unsigned short)0 : d < -14 ? (unsigned short)(1 << (d + 24)) : (unsigned short)((15 + d) << 10);
         if (e_l == -NB_EBIG) bits = (unsigned short)(15 << 10);
-        if (lane < 32) fb[lane] = bits;
+        if (lane < 32) fb[ws_kslot(lane)] = bits;   // (in the k order of the transpose-read fragments)
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const f16x8 fv = *reinterpret_cast<const f16x8*>(fb + kb * 16 + kg * 8);
-        f16x8 a1, a2;
-        {
-          const unsigned char* src = B + (kb * 16 + kg * 8) * NB_ALD + (c0 + m) * 2;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            a1[q] = *reinterpret_cast<const _Float16*>(src + q * NB_ALD);
-            a2[q] = *reinterpret_cast<const _Float16*>(src + q * NB_ALD + NB_APLANE);
-          }
-        }
+        const int prow = kb * 16 + kg * 2 + 4 * ((lane & 15) >> 2), pcol = (m & 16) + (lane & 3) * 4;   // this lane's piece of a [4 points][16 columns] block
+        f16x8 a1 = ws_tr8(B + prow * NB_ALD + (c0 + pcol) * 2, NB_ALD);
+        f16x8 a2 = ws_tr8(B + NB_APLANE + prow * NB_ALD + (c0 + pcol) * 2, NB_ALD);
         a1 = a1 * fv; a2 = a2 * fv;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
           const int c = cb * 32 + m;
-          const unsigned char* ysrc = Yb + (c < NB_YCOLS ? c : 0) * NB_YLD + kb * 32 + kg * 16;
-          f16x8 b1 = *reinterpret_cast<const f16x8*>(ysrc);
-          f16x8 b2 = *reinterpret_cast<const f16x8*>(ysrc + NB_YPLANE);
+          const unsigned char* ysrc = Yb + prow * NB_YLD + (cb * 32 + pcol) * 2;   // (columns 48 .. 63 of the second block: the pad behind a row, masked below)
+          f16x8 b1 = ws_tr8(ysrc, NB_YLD);
+          f16x8 b2 = ws_tr8(ysrc + NB_YPLANE, NB_YLD);
           if (c >= NB_YCOLS) {
             const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
             b1 = z8; b2 = z8;

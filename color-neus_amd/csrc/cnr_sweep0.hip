@@ -7,9 +7,10 @@
 //
 // Layout: one workgroup per point range, 8 waves x 32 output columns, weights of the 3 k16 blocks resident in registers (cnr_gemm_ws.h),
 // 32-point tiles.  A wave OWNS its 32 rows of dW (dW[j][c] = sum_pt u[pt][j] cbar[pt][c], j = its output columns), so everything about the
-// weight gradient is wave-private: after the epilogue of a tile the wave writes u', scaled and split hi / lo, TRANSPOSED into its own LDS
-// strip, reads it back as MFMA A fragments (16-byte reads), gathers the B fragments from the row-major cbar planes the product used
-// (two-byte reads), and issues 2 x 2 x 3 MFMAs into a [32 x 64] accumulator block.
+// weight gradient is wave-private: after the epilogue of a tile the wave writes u', scaled and split hi / lo, row-major into its own LDS
+// strip (one 8-byte store per plane and lane), and takes both MFMA fragments -- u' from the strip, cbar' from the row-major planes the product
+// used -- by the LDS transpose read (ws_tr8, cnr_gemm_ws.h; round 6: 8 + 16 reads per tile and wave instead of 32 two-byte stores, 4 sixteen-byte
+// reads and 64 two-byte reads), and issues 2 x 2 x 3 MFMAs into a [32 x 64] accumulator block.
 // Scaling as in cnr_gemm_fdw.hip: cbar' = cbar * ss[pt] are the product's planes; u' = u * 2^G / ss[pt]; G = 1 + the running minimum of
 // log2(ss * se), se = the scale that lifts the wave's 32 values of a row into the top f16 binade -- per WAVE here (no saved row scales of u_0
 // exist, and none are needed: the rows of dW never mix waves); lowering G rescales the accumulators by the exact power of two.
@@ -22,7 +23,7 @@ constexpr int S0_NKB = 3;                          // k16 blocks (K <= 48)
 constexpr int S0_ALD = S0_NKB * 32 + 16;           // bytes per LDS row of one cbar plane
 constexpr int S0_APLANE = WS_TP * S0_ALD;
 constexpr int S0_ABUF = 2 * S0_APLANE + 256;       // two planes + rs[32] (1 / row scale) + ss[32] (row scale)
-constexpr int S0_YLD = 80;                         // bytes per column of one u' plane: 32 points x 2 B + 16
+constexpr int S0_YLD = 80;                         // bytes per POINT row of one u' plane (row-major [point][32 columns of the wave], round 6): 64 B + 16 -- 20 dwords = 4 banks mod 16 (ws_tr8)
 constexpr int S0_YPLANE = 32 * S0_YLD;
 constexpr int S0_YBUF = 2 * S0_YPLANE;             // per wave
 constexpr int S0_OFF_T = 2 * S0_ABUF;
@@ -34,10 +35,6 @@ __device__ __forceinline__ float s0_yscale(float sx, int G) {   // 2^G / sx for 
   const unsigned bits = __float_as_uint(sx);
   const int field = G - (int)((bits >> 23) & 0xff) + 254;
   return field < 1 ? 0.0f : __uint_as_float((unsigned)(field > 254 ? 254 : field) << 23);
-}
-__device__ __forceinline__ float s0_sel4(const f4& v, int j) {
-  const float lo = (j & 1) ? v.y : v.x, hi = (j & 1) ? v.w : v.z;
-  return (j & 2) ? hi : lo;
 }
 
 __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGemm g, float* partial, int ldk, int tiles_per_wg) {
@@ -66,7 +63,6 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
   const f4 wsc = *reinterpret_cast<const f4*>(g.wscale + ecol);
   float* T = reinterpret_cast<float*>(smem_s + S0_OFF_T) + wave * (32 * WS_TLD);
   unsigned char* Yw = smem_s + S0_OFF_Y + wave * S0_YBUF;
-  const int jrot = (lane & 7) >> 1;
 
   // staging map: 16 threads per row, 4 columns each (K <= 48: 12 of them hold data)
   const int srow = tid >> 4, scol = (tid & 15) * 4;
@@ -201,7 +197,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
       }
       G = qmin + 1;
     }
-    // ---- u' = u * 2^G / ss, split hi / lo, transposed ([column][point]) into this wave's strip
+    // ---- u' = u * 2^G / ss, split hi / lo, row-major ([point][column], one 8-byte store per plane) into this wave's strip
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int rr = (lane >> 3) + 8 * q, cc = (lane & 7) * 4;
@@ -209,16 +205,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
       const float ys = ss > 0.0f ? s0_yscale(ss, G) : ss;   // (0 for an all-zero cbar row, NaN for a non-finite one)
       f4 e = u[q];
       e.x *= ys; e.y *= ys; e.z *= ys; e.w *= ys;
-      unsigned char* yrow = Yw + cc * S0_YLD + rr * 2;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int j = (jj + jrot) & 3;
-        const float x = s0_sel4(e, j);
-        const _Float16 h1 = (_Float16)x;
-        const _Float16 h2 = (_Float16)(x - (float)h1);
-        *reinterpret_cast<_Float16*>(yrow + j * S0_YLD) = h1;
-        *reinterpret_cast<_Float16*>(yrow + j * S0_YLD + S0_YPLANE) = h2;
-      }
+      unsigned char* yrow = Yw + rr * S0_YLD + cc * 2;
+      ws_f16x4 h1, h2;
+      h1[0] = (_Float16)e.x; h1[1] = (_Float16)e.y; h1[2] = (_Float16)e.z; h1[3] = (_Float16)e.w;
+      h2[0] = (_Float16)(e.x - (float)h1[0]); h2[1] = (_Float16)(e.y - (float)h1[1]);
+      h2[2] = (_Float16)(e.z - (float)h1[2]); h2[3] = (_Float16)(e.w - (float)h1[3]);
+      *reinterpret_cast<ws_f16x4*>(yrow) = h1;
+      *reinterpret_cast<ws_f16x4*>(yrow + S0_YPLANE) = h2;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -227,20 +220,21 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
       const int m = lane & 31, kg = lane >> 5;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const unsigned char* ysrc = Yw + m * S0_YLD + kb * 32 + kg * 16;
-        const f16x8 a1 = *reinterpret_cast<const f16x8*>(ysrc);
-        const f16x8 a2 = *reinterpret_cast<const f16x8*>(ysrc + S0_YPLANE);
+        // both fragments out of row-major planes by the LDS transpose read (ws_tr8, cnr_gemm_ws.h: block rows 4 points apart; the cbar planes'
+        // row stride of 112 B puts them 48 banks apart, as good as 16)
+        const int prow = kb * 16 + kg * 2 + 4 * ((lane & 15) >> 2), pcol = (m & 16) + (lane & 3) * 4;
+        const unsigned char* ysrc = Yw + prow * S0_YLD + pcol * 2;
+        const f16x8 a1 = ws_tr8(ysrc, S0_YLD);
+        const f16x8 a2 = ws_tr8(ysrc + S0_YPLANE, S0_YLD);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
           const int c = cb * 32 + m;
-          f16x8 b1, b2;
-          const unsigned char* src = B + (kb * 16 + kg * 8) * S0_ALD + (c < kpad ? c : 0) * 2;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const _Float16 x1 = *reinterpret_cast<const _Float16*>(src + q * S0_ALD);
-            const _Float16 x2 = *reinterpret_cast<const _Float16*>(src + q * S0_ALD + S0_APLANE);
-            b1[q] = c < kpad ? x1 : (_Float16)0.0f;
-            b2[q] = c < kpad ? x2 : (_Float16)0.0f;
+          const unsigned char* src = B + prow * S0_ALD + (cb * 32 + pcol) * 2;   // (columns >= kpad: whatever lies behind the row, masked below)
+          f16x8 b1 = ws_tr8(src, S0_ALD);
+          f16x8 b2 = ws_tr8(src + S0_APLANE, S0_ALD);
+          if (c >= kpad) {
+            const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            b1 = z8; b2 = z8;
           }
           f32x16 cacc = dacc[cb];
           cacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, cacc, 0, 0, 0);
