@@ -533,8 +533,16 @@ def main():
                 # depend on the chunking (no jitter here), so any difference would be an addressing fault at that size, not round-off
                 imgs[tag] = {k: v.detach().clone() for k, v in img.items()}
             if "view_800x800_s" in imgs and "view_800x800_chunk%d_s" % big in imgs and big != Ri:
-                inf["chunk%d_image_equals_chunk%d_image" % (big, Ri)] = all(torch.equal(v, imgs["view_800x800_chunk%d_s" % big][k]) for k, v in imgs["view_800x800_s"].items())
-                assert inf["chunk%d_image_equals_chunk%d_image" % (big, Ri)], "the 65536-ray chunks render a different image than the 8192-ray chunks"
+                # (bit patterns: a NaN pixel compares equal to the same NaN pixel)
+                same = {k: bool(torch.equal(v.contiguous().view(torch.int32), imgs["view_800x800_chunk%d_s" % big][k].contiguous().view(torch.int32)))
+                        for k, v in imgs["view_800x800_s"].items()}
+                inf["chunk%d_image_equals_chunk%d_image" % (big, Ri)] = all(same.values())
+                inf["view_nonfinite_pixels"] = int(sum((~torch.isfinite(v)).reshape(v.shape[0], -1).any(dim=1).sum() for v in imgs["view_800x800_s"].values()))
+                if not all(same.values()):
+                    a_, b_ = imgs["view_800x800_s"]["color_fine"], imgs["view_800x800_chunk%d_s" % big]["color_fine"]
+                    bad = torch.nonzero((a_ != b_).reshape(a_.shape[0], -1).any(dim=1)).reshape(-1)
+                    raise AssertionError("the %d-ray chunks render a different image than the %d-ray chunks: %s; %d rays differ, first %s last %s, max abs %.3e"
+                                         % (big, Ri, same, len(bad), bad[:4].tolist(), bad[-4:].tolist(), float((a_ - b_).abs().max())))
             imgs.clear()
             torch.cuda.empty_cache()
             del vo, vd, vn, vf

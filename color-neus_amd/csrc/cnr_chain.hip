@@ -182,9 +182,13 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
       const bool next_skip = !last && ((c.skip_mask >> (l + 1)) & 1);
       const float oscale = next_skip ? kInvSqrt2 : 1.0f;
       const bool ragged = L.N < 256;   // wave-uniform: only the layer in front of a skip connection (217 columns + 39 of e)
-      float red[RT];
+      float red[RT], dotj[CB][RT];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) red[rt] = 0.0f;
+      for (int rt = 0; rt < RT; ++rt) {
+        red[rt] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CB; ++j) dotj[j][rt] = 0.0f;
+      }
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
         const int c0 = cbase + 32 * j;
@@ -235,13 +239,25 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(fabsf(acc[j][rt][r]), fabsf(acc[j][rt][r + 1])), mx);
           }
-          red[rt] = last ? red[rt] + dot : fmaxf(red[rt], mx);
+          if (last) dotj[j][rt] = dot; else red[rt] = fmaxf(red[rt], mx);
         }
       }
+      // partial results per row: the row maximum per wave; the sdf dot product per 32-COLUMN BLOCK (its two 16-column halves added first), slot =
+      // block index -- the same 8 partial sums in the same order for every tile shape, so that the sdf of a point does not depend on how many points
+      // the call holds (round 6: a 1024-ray chunk of a view used to differ from the same rays inside a 65536-ray chunk by one ulp of sdf, because
+      // <2, 2> added the halves of two blocks first; bench.py now asserts that the two chunkings render the same image)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const float other = __shfl_xor(red[rt], 32);
-        if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = last ? red[rt] + other : fmaxf(red[rt], other);
+        if (last) {
+#pragma unroll
+          for (int j = 0; j < CB; ++j) {
+            const float other = __shfl_xor(dotj[j][rt], 32);
+            if (half == 0) pm[(rt * 32 + pt) * 8 + wave * CB + j] = dotj[j][rt] + other;
+          }
+        } else {
+          const float other = __shfl_xor(red[rt], 32);
+          if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = fmaxf(red[rt], other);
+        }
       }
       lds_barrier();   // partial maxima visible; every wave is done reading the planes of this layer's input
       if (!last) {
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
         for (int row = tid; row < T; row += THREADS) {
           float sum = pm[row * 8];
 #pragma unroll
-          for (int w = 1; w < WAVES; ++w) sum += pm[row * 8 + w];
+          for (int w = 1; w < 8; ++w) sum += pm[row * 8 + w];   // (8 column blocks, whatever the number of waves)
           const long grow = tile * T + row;
           if (grow < c.P) c.sdf_out[grow] = (sum + c.btop[0]) * c.top_scale;
         }

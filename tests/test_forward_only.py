@@ -239,3 +239,30 @@ def test_forward_only_full_size_matches_saving_forward_hip():
     keep = b["weights"] >= 1e-4
     assert bool(((b["color_fine"] - c["color_fine"]).abs() <= (~keep).sum(-1, keepdim=True).float() * 1e-4 + 1e-6).all())
     assert torch.equal(c["delta_relight"][keep], b["delta_relight"][keep])
+
+
+@pytest.mark.gpu
+def test_a_ray_renders_the_same_in_every_chunk_size_hip():
+    """validate_image renders a view in EVAL_RAY_SIZE chunks (NeuS_Trainer.py:233-245): the pixel of a ray must not depend on how many rays share
+    its chunk.  The library picks tile shapes by point count -- the sampler's value chain runs <1, 2>, <2, 2> or <4, 1> tiles below / above 8192 and
+    32768 points per launch -- and every shape must form every point's values in the same order (round 6: <2, 2> used to add the halves of the sdf dot
+    product in another order than <4, 1>: one ulp of sdf, a 1.5e-7 colour difference on 215 of 640 000 pixels between 8192- and 65536-ray chunks).
+    4096 rays in one call against the same rays in chunks of 1024, 256 and 96 (ragged): every output of every ray bit-identical."""
+    import color_neus_amd as cn
+    from color_neus_amd import synthetic
+    dev = torch.device("cuda:0")
+    cfg = cn.RenderConfig(type="Color_NeuS", col_mode="no_view_dir", col_d_in=6, col_multires_view=0)
+    torch.manual_seed(0)
+    r = synthetic.make_trained_like_(cn.ColorNeuSRenderer(cfg)).to(dev)
+    views = synthetic.synthetic_view(seed=1, device=dev)
+    sel = torch.randperm(views[0].shape[0], generator=torch.Generator().manual_seed(3))[:4096].to(dev)
+    o, d, n, f = [x[sel] for x in views[:4]]
+    per_ray = ["color_fine", "depth", "weight_sum", "weight_max", "weights", "cdf_fine", "gradients", "z_vals", "global_color", "delta_relight", "inside_sphere"]
+    with torch.no_grad():
+        whole = r(o, d, n, f, perturb_overwrite=0)
+        for chunk in (1024, 256, 96):
+            parts = [r(o[a:a + chunk], d[a:a + chunk], n[a:a + chunk], f[a:a + chunk], perturb_overwrite=0) for a in range(0, 4096, chunk)]
+            for k in per_ray:
+                got = torch.cat([p[k].reshape(p[k].shape[0], -1) for p in parts], 0)
+                ref = whole[k].reshape(4096, -1)
+                assert torch.equal(got, ref), (chunk, k, int((got != ref).any(dim=1).sum()), float((got - ref).abs().max()))
