@@ -420,7 +420,7 @@ def main():
         # HBM bytes per launch from the PMC counters cannot be collected inside this process; they come from the committed summary
         # of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py)
         traffic, tfile = None, None
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             cand = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic_%drays.json" % (rnd, R))
             if os.path.exists(cand):
                 t = json.load(open(cand))["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
