@@ -69,9 +69,6 @@ class RenderConfig:
             raise ValueError("N_OUTSIDE must be >= 0 and N_SAMPLES + N_IMPORTANCE + N_OUTSIDE <= 256")
         if self.sdf_d_in != 3 or self.col_d_out != 3 or self.rel_d_out != 3:
             raise NotImplementedError("only 3-D points / RGB outputs are supported")
-        if len([l for l in self.sdf_skip_in if 0 < int(l) < self.sdf_n_layers]) > 1:
-            # the library keeps ONE embedding-cotangent buffer for the skip connection (cnr_param_count rejects it as well): every shipped YAML has SKIP_IN [4]
-            raise NotImplementedError("at most one SDF skip connection is supported (SKIP_IN = %r)" % (list(self.sdf_skip_in),))
         if self.col_mode not in ("idr", "no_view_dir", "no_normal"):
             raise ValueError(f"no such mode: {self.col_mode}")
 

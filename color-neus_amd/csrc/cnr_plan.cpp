@@ -151,11 +151,9 @@ static int build_model(const cnr_config* cfg, Model& m) {
   if (m.F < 1 || m.F > 256 || m.F != c.col_d_feature) return fail("sdf d_out - 1 must equal colour d_feature (<= 256)");
   if (c.sdf_skip_mask & 1) return fail("skip connection at layer 0 is not supported");
   if ((c.sdf_skip_mask >> m.L) & 1) return fail("skip connection at the top layer is not supported");
-  // ONE skip connection (every shipped YAML: SKIP_IN [4], fields.py:23): the embedding cotangents of the gradient chain and of the backward
-  // pass have one buffer each (Ctx::CES, ebars).  A two-skip network used to be accepted and rendered WRONG normals (round 6: found by
-  // capturing a SKIP_IN [2, 4] fixture from the reference); it is rejected here until those buffers accumulate over the skips.
-  { int nskip = 0; for (int l = 1; l < m.L; ++l) nskip += (c.sdf_skip_mask >> l) & 1;
-    if (nskip > 1) return fail("at most one SDF skip connection is supported (SKIP_IN has %d entries)", nskip); }
+  // Several skip connections (fields.py:45-48 allows any SKIP_IN; every shipped YAML has [4]): the embedding cotangents of the gradient chain and of
+  // the backward pass have one buffer each (Ctx::CES, ebars); the launch of the FIRST skip layer a sweep meets stores into it, the later ones add
+  // (Epi::o2_acc).  Round 6: a [2, 4] fixture captured from the reference showed that such a network used to be accepted and rendered wrong normals.
   m.has_relight = c.type == 1;
   m.Hc = c.col_d_hidden; m.NC = c.col_n_layers + 1;
   if (m.Hc < 16 || m.Hc > 256 || m.Hc % 16 || c.col_n_layers < 1 || c.col_n_layers >= kMaxLayers) return fail("colour d_hidden must be a multiple of 16 in [16,256]");
@@ -720,6 +718,7 @@ static int skip_off(const Model& m) {
 // the whole gradient chain as one chain-fused launch (cnr_chain_fwd.hip); false: not handled
 static bool sdf_grad_chain_fused(const Model& m, long P, const float* const* Z, float* const* V, float* CE0, float* CES, cnr_stream s, float* const* rs) {
   if (m.Hs != 256 || m.L < 2 || m.F != 256 || m.skip(m.L) || m.sdf[m.L].ldw < 256) return false;
+  { int nskip = 0; for (int l = 1; l < m.L; ++l) nskip += m.skip(l) ? 1 : 0; if (nskip > 1) return false; }   // (this opt-in kernel stores its one skip cotangent)
   SdfGradChain c;
   c.P = P; c.nl = m.L; c.ldz = m.Hs; c.skip_mask = m.c.sdf_skip_mask; c.emb = m.emb;
   c.vrow = m.sdf[m.L].W + (long)m.F * m.sdf[m.L].ldw; c.vscale = 1.0f / m.c.sdf_scale;
@@ -745,6 +744,7 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
   // next GEMM of this chain: its pad columns must hold finite values whatever the caller's scratch contained (every user of the
   // chain -- render, vertex colour -- gets this here rather than at the call site)
   // (zeroed right in front of the launch that leaves them unwritten: the forward-only layout reuses two V buffers for all layers)
+  bool ces_written = false;
   for (int l = m.L - 1; l >= 0; --l) {
     const Lin& q = m.sdf[l];
     if (l >= 1 && m.skip(l) && V[l - 1] && round_up(m.sdf[l - 1].n, 16) > m.sdf[l - 1].n)
@@ -766,6 +766,7 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
     } else if (m.skip(l)) {
       g.E.kind = EK_SPLIT; g.E.n_out = q.k_int; g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n;
       g.E.o1 = V[l - 1]; g.E.ld1 = m.Hs; g.E.o2 = CES; g.E.ld2 = kEmb; g.E.o2_off = skip_off(m);
+      g.E.o2_acc = ces_written; ces_written = true;   // (the sweep runs from the top layer down: the first skip layer it meets stores, the others add)
     } else {
       g.E.kind = EK_STORE; g.E.n_out = q.k_int; g.E.o1 = V[l - 1]; g.E.ld1 = m.Hs;
     }
@@ -773,6 +774,10 @@ static void sdf_grad_chain(const Model& m, long P, const float* E, const float* 
   }
 }
 
+static int top_skip(const Model& m) {   // the highest layer fed by a skip connection (-1: none)
+  for (int l = m.L - 1; l >= 1; --l) if (m.skip(l)) return l;
+  return -1;
+}
 static bool has_skip(const Model& m) {
   for (int l = 1; l < m.L; ++l) if (m.skip(l)) return true;
   return false;
@@ -1342,6 +1347,7 @@ static int render_backward(const cnr_config* cfg, const float* const* params, co
     g.W = q.Wt; g.ldw = q.ldwt; g.Wp = q.Wtp; g.wp_stride = (long)q.kpad * q.ldwt; g.wscale = q.Wtps; g.N = q.k_int; g.K = q.n; g.P = P;
     g.E.kind = EK_VBACK; g.E.n_out = q.k_int; g.E.z = x.Z[l - 1]; g.E.ldz = m.Hs; g.E.o1 = b.Z2[l - 1]; g.E.ld1 = m.Hs;
     if (m.skip(l)) { g.E.scale = kInvSqrt2; g.E.split = m.sdf[l - 1].n; g.E.o2 = rays_grad ? b.ebars : nullptr; g.E.ld2 = kEmb; g.E.o2_off = skip_off(m);
+                     g.E.o2_acc = l != top_skip(m);   // (the value backward runs from the top layer down: the highest skip layer stores, the others add)
                      g.E.vscale = kInvSqrt2; }   // (vscale: the scale of the layer's input view, for the fused launch's epilogue-side operand)
     return g;
   };

@@ -97,6 +97,7 @@ struct Epi {
   float scale = 1.0f;
   float* o1 = nullptr; int ld1 = 0; int o1_off = 0;
   float* o2 = nullptr; int ld2 = 0; int o2_off = 0;
+  bool o2_acc = false;   // EK_SPLIT / EK_VBACK: ADD the beyond-split columns to o2 instead of storing them (the embedding cotangent of the 2nd, 3rd .. skip connection)
   int split = 1 << 30;
   const float* z = nullptr; int ldz = 0;      // pre-activations (EK_SWEEP / EK_VBACK)
   const float* v = nullptr; int ldv = 0;      // grad-chain cotangent v_l (EK_SWEEP); ldv == 0 -> broadcast row
@@ -138,7 +139,7 @@ CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
       float b = e.bias ? e.bias[col] : 0.0f;
       float v = (acc + b) * e.scale;
       if (col < e.split) e.o1[row * e.ld1 + e.o1_off + col] = v;
-      else if (e.o2) e.o2[row * e.ld2 + (col - e.split) + e.o2_off] = v;
+      else if (e.o2) { float* q = e.o2 + row * e.ld2 + (col - e.split) + e.o2_off; *q = e.o2_acc ? *q + v : v; }
     } break;
     case EK_SDF_TOP: {
       float v = acc + e.bias[col];
@@ -173,7 +174,8 @@ CNR_HD void epi_apply(const Epi& e, long row, int col, float acc) {
         float* p = e.o1 + row * e.ld1 + col;
         *p = softplus100_d1(e.z[row * e.ldz + col]) * h + *p;
       } else if (e.o2) {
-        e.o2[row * e.ld2 + (col - e.split) + e.o2_off] = h;
+        float* q = e.o2 + row * e.ld2 + (col - e.split) + e.o2_off;
+        *q = e.o2_acc ? *q + h : h;
       }
     } break;
     default: {  // EK_RELU_MASK
@@ -262,7 +264,11 @@ CNR_HD void epi_finish4(const Epi& e, long row, int col, const f4& acc, const f4
       f4 o;
       o.x = (acc.x + b.x) * e.scale; o.y = (acc.y + b.y) * e.scale; o.z = (acc.z + b.z) * e.scale; o.w = (acc.w + b.w) * e.scale;
       if (col < e.split) *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + e.o1_off + col) = o;
-      if (col + 4 > e.split && e.o2) *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + (col - e.split) + e.o2_off) = o;
+      if (col + 4 > e.split && e.o2) {
+        f4* q = reinterpret_cast<f4*>(e.o2 + row * e.ld2 + (col - e.split) + e.o2_off);
+        if (e.o2_acc) { const f4 old = *q; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }   // (a straddling group also touches the pad columns in front of o2_off: never read)
+        *q = o;
+      }
     } break;
     case EK_STORE: {
       f4 o;
@@ -308,7 +314,11 @@ CNR_HD void epi_finish4(const Epi& e, long row, int col, const f4& acc, const f4
         if (col + 3 < e.split) o.w = softplus100_d1(zz.w) * h.w + o.w;
         *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o;
       }
-      if (col + 4 > e.split && e.o2) *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + (col - e.split) + e.o2_off) = h;
+      if (col + 4 > e.split && e.o2) {
+        f4* q = reinterpret_cast<f4*>(e.o2 + row * e.ld2 + (col - e.split) + e.o2_off);
+        if (e.o2_acc) { const f4 old = *q; h.x += old.x; h.y += old.y; h.z += old.z; h.w += old.w; }
+        *q = h;
+      }
     } break;
     case EK_RELU_MASK: {
       const f4 m = raw.a;

@@ -29,7 +29,7 @@ CONFIGS = {
 
 # Round 6: the network-configuration branches the ABI accepts but no shipped YAML takes (fields.py:72-73 WEIGHT_NORM, :170-171 MODE no_normal,
 # :186-187 SQUEEZE_OUT, :302-306 / :342-343 INCLUDE_GRAD, :311-314 / :346-349 Y_IN_LAYER incl. the rgb-into-the-last-layer form, :354-359 INV_SIGMOID,
-# :45-48 SKIP_IN at another layer -- more than one skip connection is REJECTED by cnr_param_count, tests/test_abi.py), each at the tiny size (per-layer kernels) and at the DTU widths (chain-fused kernels).  tools/gen_golden.py captures
+# :45-48 SKIP_IN at another layer and TWO skip connections), each at the tiny size (per-layer kernels) and at the DTU widths (chain-fused kernels).  tools/gen_golden.py captures
 # them from the reference with these very configurations.  The tiny ones also move the remaining cnr_config fields off their defaults:
 # UP_SAMPLE_STEPS 2, SDF MULTIRES 4 and SCALE 2, MULTIRES_VIEW 2 (relight; colour in no_normal mode).
 def _tiny(**kw):
@@ -46,6 +46,7 @@ VARIANTS = {
         sdf=O.SDFConfig(d_out=65, d_hidden=64, n_layers=5, skip_in=[2], weight_norm=False, multires=4, scale=2.0),
         color=O.ColorConfig(d_feature=64, mode="no_view_dir", d_in=6, d_hidden=64, n_layers=2, multires_view=0, weight_norm=False),
         relight=O.RelightConfig(d_hidden=64, n_layers=3, y_in_layer=2)),
+    "tiny_twoskip": lambda: _tiny(sdf=O.SDFConfig(d_out=65, d_hidden=64, n_layers=5, skip_in=[2, 4])),
     "tiny_nosq": lambda: _tiny(color=O.ColorConfig(d_feature=64, mode="no_view_dir", d_in=6, d_hidden=64, n_layers=2, multires_view=0, squeeze_out=False)),
     "tiny_neus_nonormal": lambda: O.RenderConfig(
         type="NeuS", n_samples=16, n_importance=16,
@@ -58,6 +59,7 @@ VARIANTS = {
         type="Color_NeuS", sdf=O.SDFConfig(skip_in=[6], weight_norm=False),
         color=O.ColorConfig(mode="no_view_dir", d_in=6, multires_view=0, weight_norm=False),
         relight=O.RelightConfig(y_in_layer=4)),
+    "dtu_twoskip": lambda: O.RenderConfig(type="Color_NeuS", sdf=O.SDFConfig(skip_in=[3, 6]), color=O.ColorConfig(mode="no_view_dir", d_in=6, multires_view=0)),
     "neus_dtu_nonormal": lambda: O.RenderConfig(type="NeuS", color=O.ColorConfig(mode="no_normal", d_in=6, squeeze_out=False), relight=None),
 }
 CONFIGS.update(VARIANTS)
@@ -130,15 +132,23 @@ def relerr(a, b):
 
 
 def check_g1(z, fx, tag):
-    """Gate G1 (sampler): every sample position within 1e-3 of the reference's -- except on at most one ray per 512 (at least one), where a
-    sample may sit up to 4e-3 (an eighth of a coarse section at 64 samples) away: the up-sampling steps amplify float32 round-off (the
-    reference's own float32 and float64 runs place samples up to 6.7e-4 apart; on `dtu_rel_alt` / `neus_dtu_nonormal` [jit] the oracle's float32
-    restatement -- bit-identical to the reference where no weight-norm quotient is involved -- moves 2 samples of one ray by 1.4e-3).  None when fine."""
-    df = (torch.as_tensor(z).double().cpu() - torch.from_numpy(np.asarray(fx[f"{tag}:z_vals"])).double()).abs()
-    bad_rays = int((df > 1e-3).any(dim=1).sum())
+    """Gate G1 (sampler): every sample position within 1e-3 of the reference's.  The up-sampling steps amplify float32 round-off (the
+    reference's own float32 and float64 runs place samples up to 6.7e-4 apart on one draw, 3e-3 on another), so a ray on which THE REFERENCE'S OWN
+    float32 and float64 samplers disagree by more than 2e-4 is a ray on which any float32 implementation may land elsewhere: where the fixture holds
+    that float64 run (round-6 fixtures: `f64:z_vals_own`) those rays may sit up to HALF A COARSE SECTION at 64 samples (1 / 64: a new sample that falls into
+    the neighbouring section of the piecewise-linear cdf; the full-size test uses the same bound) away, every other ray must be within 1e-3; the older fixtures keep the flat rule with one ray per 512 (at least one) allowed up to 4e-3.  None when fine."""
+    ref = torch.from_numpy(np.asarray(fx[f"{tag}:z_vals"])).double()
+    df = (torch.as_tensor(z).double().cpu() - ref).abs()
+    bad = (df > 1e-3).any(dim=1)
+    if f"{tag}:f64:z_vals_own" in fx:
+        own = (torch.from_numpy(np.asarray(fx[f"{tag}:f64:z_vals_own"])).double() - ref).abs().amax(dim=1) > 2e-4
+        stray = int((bad & ~own).sum())
+        if float(df.max()) >= 1.0 / 64 or stray > 0:
+            return "z_vals: max |dz| %.2e; %d ray(s) beyond 1e-3 that the reference's own float32 / float64 samplers agree on (%d sensitive rays)" % (float(df.max()), stray, int(own.sum()))
+        return None
     allowed = max(1, df.shape[0] // 512)
-    if float(df.max()) >= 4e-3 or bad_rays > allowed:
-        return "z_vals: max |dz| %.2e, %d ray(s) beyond 1e-3 (allowed %d below 4e-3)" % (float(df.max()), bad_rays, allowed)
+    if float(df.max()) >= 4e-3 or int(bad.sum()) > allowed:
+        return "z_vals: max |dz| %.2e, %d ray(s) beyond 1e-3 (allowed %d below 4e-3)" % (float(df.max()), int(bad.sum()), allowed)
     return None
 
 

@@ -44,20 +44,20 @@ def test_hip_library_identifies_itself():
 
 def test_unsupported_configurations_are_rejected_with_a_message():
     """What the kernels do not implement must fail in cnr_param_count (every entry point builds its model through the same check), never
-    render something else: more than one SDF skip connection (fields.py:45-48 allows any SKIP_IN; round 6: a [2, 4] network rendered wrong
-    normals before this check), a skip at layer 0 or at the top layer, widths the tiles do not cover."""
+    render something else: a skip connection at layer 0 or at the top layer, widths the tiles do not cover.  (Several skip connections,
+    fields.py:45-48, are supported since round 6 -- a [2, 4] network used to be accepted and rendered wrong normals; now pinned by the
+    `*_twoskip` reference goldens.)"""
     path = os.path.join(ROOT, "tests", "_build", "libcolorneus_emu.so")
     if not os.path.isfile(path):
         pytest.skip("emulation library not built")
     lib = cn.load_library(path)
     base = dict(col_mode="no_view_dir", col_d_in=6, col_multires_view=0)
     assert len(lib.param_inventory(_lib.c_config(cn.RenderConfig(sdf_skip_in=[6], **base)))) == 53
-    for kw, msg in ((dict(sdf_skip_in=[2, 4]), "at most one SDF skip"), (dict(sdf_skip_in=[0]), "layer 0"), (dict(sdf_skip_in=[8]), "top layer"),
+    assert len(lib.param_inventory(_lib.c_config(cn.RenderConfig(sdf_skip_in=[2, 5], **base)))) == 53
+    for kw, msg in ((dict(sdf_skip_in=[0]), "layer 0"), (dict(sdf_skip_in=[8]), "top layer"),
                     (dict(sdf_d_hidden=40), "d_hidden"), (dict(sdf_multires=7), "multires"), (dict(rel_y_in_layer=5), "y_in_layer")):
         with pytest.raises(RuntimeError, match=msg):
             lib.param_inventory(_lib.c_config(cn.RenderConfig(**base, **kw)))
-    with pytest.raises(NotImplementedError, match="at most one SDF skip"):   # ... and already when the module is built (RenderConfig.validate)
-        cn.ColorNeuSRenderer(cn.RenderConfig(sdf_skip_in=[2, 4], **base), library=path)
 
 
 def test_the_library_reads_the_environment_in_one_place():

@@ -173,6 +173,11 @@ def e2e_fixture(name, cfg, cls, CN, mods, R, weight_seed, trained_like, store_we
         for k in ("loss", "grad_rays_o", "grad_rays_d", "grad_near", "grad_far"):
             if k in res64:
                 fx[f"{tag}:f64:{k}"] = res64[k]
+        if store_f64_outputs and cfg.n_importance > 0:
+            # ... and where the reference's OWN float64 run puts its samples (sampler included, same jitter draw): the rays on which its float32 and
+            # float64 samplers disagree are the rays on which any float32 implementation may (gate G1, tests/_golden.py check_g1)
+            own64, _ = run_reference(cls, node, P, o, d, gt, mask, js, mods, dtype=torch.float64, t_rand=res.get("t_rand"), z_override=None, call_kw=call_kw)
+            fx[f"{tag}:f64:z_vals_own"] = own64["z_vals"]
         if store_f64_outputs:   # round 6: the outputs of the float64 run as well (the per-sample outputs of a sharp surface sit 1e-4 from float64
             for k, v in res64.items():   # in the reference's OWN float32 run: the output gate is then stated against float64, tests/_golden.py check_outputs)
                 if k.startswith("out_"):
