@@ -71,6 +71,8 @@ class ClipAdam(torch.optim.Optimizer):
             st["exp_avg"] = torch.zeros(total, dtype=torch.float32, device=dev)
             st["exp_avg_sq"] = torch.zeros(total, dtype=torch.float32, device=dev)
             st["steps"] = [0] * len(allp)
+        if "steps" not in st and "step" in st and st["exp_avg"].numel() == total:   # state of an earlier build: one step count for the whole group
+            st["steps"] = [int(st.pop("step"))] * len(allp)
         return allp, st, dev
 
     @torch.no_grad()
