@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
         *reinterpret_cast<f16x4*>(dst) = h1;
         *reinterpret_cast<f16x4*>(dst + APLANE) = h2;
       }
-      if ((tid & 15) == 0) rs[row_l] = 1.0f / sc;
+      if ((tid & 15) == 0) rs[row_l] = cnr_pow2_rcp(sc);
     }
     }
     lds_barrier();
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
           const float sc = chain_row_scale(mx);
 #pragma unroll
           for (int j = 0; j < CB; ++j) chain_put16(acc[j][rt], sc, smem + row_l * CH_ALD + (cbase + 32 * j) * 2, APLANE);
-          if (wave == 0 && half == 0) rs[row_l] = 1.0f / sc;
+          if (wave == 0 && half == 0) rs[row_l] = cnr_pow2_rcp(sc);
         }
       } else {
         // sdf = (softplus(z_top-1) . w_sdf + b_sdf) * top_scale: the per-wave partial sums in a fixed order

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
           if (128 + sc4 < ncol) chain_put4(v2[pass], sc, dst + 256, APLANE);
           if (192 + sc4 < ncol) chain_put4(v3[pass], sc, dst + 384, APLANE);
           if ((tid & 15) == 0) {
-            rs[row_l] = 1.0f / sc; rsf[row_l] = sc;
+            rs[row_l] = cnr_pow2_rcp(sc); rsf[row_l] = sc;
             if (S.rs_in != nullptr && row_l < rows_left) S.rs_in[tile0 + row_l] = chain_rs_value(mx, sc);
           }
         }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
           const float sc = chain_row_scale(mx);
           chain_put16(acc[rt], sc, smem + row_l * CH_ALD + cbase * 2, APLANE);
           if (wave == 0 && half == 0) {
-            rs[row_l] = 1.0f / sc; rsf[row_l] = sc;
+            rs[row_l] = cnr_pow2_rcp(sc); rsf[row_l] = sc;
             const long grow = tile * T + row_l;
             if (Sn.rs_in != nullptr && grow < P) Sn.rs_in[grow] = chain_rs_value(mx, sc);
           }
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void sdf_save_chain_kernel(const SdfSaveCha
         mx = cnr_max16(mx);
         const float sc = chain_row_scale(mx);
         if (sc4 < kEmb) chain_put4(x[pass], sc, smem + row_l * CH_ALD + sc4 * 2, APLANE);
-        if ((tid & 15) == 0) rs[row_l] = 1.0f / sc;
+        if ((tid & 15) == 0) rs[row_l] = cnr_pow2_rcp(sc);
       }
       lds_barrier();
     }
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512, 1) void sdf_save_chain_kernel(const SdfSaveCha
           const float sc = chain_row_scale(mx);
           chain_put16(acc[rt], sc, smem + row_l * CH_ALD + cbase * 2, APLANE);
           if (wave == 0 && half == 0) {
-            rs[row_l] = 1.0f / sc;
+            rs[row_l] = cnr_pow2_rcp(sc);
             if (rso != nullptr && row_l < rows_left) rso[tile0 + row_l] = chain_rs_value(mx, sc);
           }
         }
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(512, 1) void sdf_grad_chain_kernel(const SdfGradCha
 #pragma unroll
         for (int j = 0; j < 4; ++j) chain_put4(zv[pass][j], sc, dst + 128 * j, APLANE);
         if ((tid & 15) == 0) {
-          rs[row_l] = 1.0f / sc;
+          rs[row_l] = cnr_pow2_rcp(sc);
           if (c.rs[L - 1] != nullptr && row_l < rows_left) c.rs[L - 1][tile0 + row_l] = chain_rs_value(mx, sc);
         }
       }
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(512, 1) void sdf_grad_chain_kernel(const SdfGradCha
           const float sc = chain_row_scale(mx);
           chain_put16(acc[rt], sc, smem + row_l * CH_ALD + cbase * 2, APLANE);
           if (wave == 0 && half == 0) {
-            rs[row_l] = 1.0f / sc;
+            rs[row_l] = cnr_pow2_rcp(sc);
             if (rso != nullptr && row_l < rows_left) rso[tile0 + row_l] = chain_rs_value(mx, sc);
           }
         }

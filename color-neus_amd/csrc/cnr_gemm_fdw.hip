@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         }
         const float ssv = valid ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf(""));
         if ((dt & 15) == 0) {
-          rs[row_l] = 1.0f / sc;
+          rs[row_l] = cnr_pow2_rcp(sc);
           rs[32 + row_l] = ssv;
           if (g.rs_out && half == 0) g.rs_out[FD_TILE(i) * FD_TP + row_l] = ssv;
         }

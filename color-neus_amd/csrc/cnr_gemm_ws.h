@@ -148,7 +148,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) dsum_ += __shfl_xor(dsum_, d, 16); \
     }                                                                             \
     if ((tid & 15) == 0) {                                                        \
-      reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
+      reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = cnr_pow2_rcp(sc); \
       const long prow_ = WS_TILE(tile_) * WS_TP + srow;                                  \
       if (WS_DOT && g.dot_w && prow_ < Pn) g.dot_out[prow_] = (dsum_ + dot_b) * g.dot_scale; \
       if (g.rs_out && prow_ < Pn) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); /* 0: all-zero row, NaN: non-finite row (must keep poisoning the weight gradient) */ \
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
       _Pragma("unroll") for (int d = 8; d >= 1; d >>= 1) dsum_ += __shfl_xor(dsum_, d, 16); \
     }                                                                             \
     if ((tid & 15) == 0) {                                                        \
-      reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = 1.0f / sc; \
+      reinterpret_cast<float*>(smem_b + (buf_) * abuf + 2 * aplane)[srow] = cnr_pow2_rcp(sc); \
       const long prow_ = WSS_TILE((tile_) < tlast ? (tile_) : tlast) * WS_TP + srow; \
       if (EK == EK_SDF_TOP && g.dot_w) g.dot_out[prow_] = (dsum_ + dot_b) * g.dot_scale; \
       if (g.rs_out) g.rs_out[prow_] = (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); \

@@ -36,6 +36,9 @@ __device__ __forceinline__ void cnr_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
+// 1 / s for a power of two s (every row / operand scale of the split-f16 arithmetic is one, 2^-114 .. 2^114): exponent arithmetic, exact -- the IEEE
+// division the compiler emits for `1.0f / s` is ~10 VALU instructions (v_div_scale x 2, v_rcp, 4 fma, v_div_fmas, v_div_fixup) per row and tile
+__device__ __forceinline__ float cnr_pow2_rcp(float s) { return __uint_as_float(0x7f000000u - __float_as_uint(s)); }
 // max over the 16 lanes of a DPP row (every lane gets it) by four data-parallel-primitive moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
 // instead of four __shfl_xor(.., 16), which hipcc lowers to ds_bpermute_b32: an LDS-crossbar round trip each, on the path between a tile's
 // arrival and its f16 planes.  max is associative and commutative: bit-identical to the shuffle form.

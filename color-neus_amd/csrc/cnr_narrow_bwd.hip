@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
     }
     if ((tid & 15) == 0) {
       float* rs = reinterpret_cast<float*>(B + 2 * NB_APLANE);
-      rs[srow] = 1.0f / sx;
+      rs[srow] = cnr_pow2_rcp(sx);
       // a row with a zero operand contributes nothing (its planes are zero); a non-finite row keeps factor 1 so that it poisons the sums
       const bool nonfin = !(mx < 3.0e38f) || !(my < 3.0e38f);
       int e = NB_EBIG;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
     if ((tid & 15) == 0) {
       float* rs = reinterpret_cast<float*>(B + 2 * S0_APLANE);
       const float ssv = valid ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf(""));
-      rs[srow] = 1.0f / sc;
+      rs[srow] = cnr_pow2_rcp(sc);
       rs[32 + srow] = ssv;
       if (g.rs_out && prow < Pn) g.rs_out[prow] = ssv;
     }
