@@ -16,13 +16,13 @@ def sampler():
     while not stop:
         samples.append((time.time(),) + smi()); time.sleep(0.25)
 th = threading.Thread(target=sampler, daemon=True); th.start()
-p = subprocess.Popen([exe, "4"], stdout=subprocess.PIPE, text=True)
+p = subprocess.Popen([exe, "4"] + (["256", "shapes"] if "--shapes" in sys.argv else []), stdout=subprocess.PIPE, text=True)
 marks = []
 for line in p.stdout:
     line = line.strip(); marks.append((time.time(), line)); print(line, flush=True)
 p.wait(); stop = True; th.join(timeout=3)
 starts = [(t, l) for t, l in marks if " start" in l]; ends = [(t, l) for t, l in marks if " end" in l]
-names = {"mode3": "constant operands", "mode0": "shipped order (a1 w2, a2 w1, a1 w1)", "mode1": "Gray order (a1 w2, a1 w1, a2 w1)", "mode2": "both operands change every MFMA"}
+names = {"mode3": "constant operands", "mode0": "shipped order (a1 w2, a2 w1, a1 w1)", "mode1": "Gray order (a1 w2, a1 w1, a2 w1)", "mode2": "both operands change every MFMA", "mode4": "v_mfma_f32_16x16x32_f16, shipped order, two accumulators", "mode5": "v_mfma_f32_32x32x16_f16, shipped order, two accumulators"}
 for (t0, l0), (t1, l1) in zip(starts, ends):
     ws = [w for t, w, c in samples if t0 + 1.0 <= t <= t1 and w]; cs = [c for t, w, c in samples if t0 + 1.0 <= t <= t1 and c]
     tf = float(re.search(r"([0-9.]+) TFLOP/s", l1).group(1))
