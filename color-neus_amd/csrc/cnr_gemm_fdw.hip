@@ -26,6 +26,14 @@
 
 namespace cnr {
 
+// Round 6: the MFMA SHAPE.  v_mfma_f32_16x16x32_f16 is 12 % cheaper per FLOP than v_mfma_f32_32x32x16_f16 on random operands and holds the clock 15 % higher
+// (profiles/r06_mfma_shapes.txt: 1950 against 1705 TFLOP/s with the matrix pipe alone at the board's power limit) -- and this kernel's time is its joules.
+// FD_MFMA16 = 1: product and weight gradient on 16 x 16 x 32 blocks (same LDS planes, same register budget: 128 weight registers, 16 / 128 accumulators);
+// 0: the 32 x 32 x 16 form (A/B builds).
+#ifndef FD_MFMA16
+#define FD_MFMA16 1
+#endif
+typedef float fd_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int FD_TP = 32;                        // points per tile
 constexpr int FD_ALD = 256 * 2 + 16;             // bytes per LDS row of one S plane (+16: conflict-free ds_read_b128 of the product fragments)
 constexpr int FD_APLANE = FD_TP * FD_ALD;
@@ -126,6 +134,20 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
   if (isP) {
     // ================================================================ P waves
     const int c0 = half * 128 + wave * 32;               // first output column of this wave
+#if FD_MFMA16
+    // weights of this wave's 2 x 16 output columns as B fragments of the 16 x 16 x 32 MFMA: lane (n = lane & 15, kg = lane >> 4) holds W[c0 + 16 cb + n][32 kb + 8 kg ..]
+    constexpr int NKB2 = NKB / 2;
+    f16x8 w1[NKB2][2], w2[NKB2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const unsigned short* wp = g.Wp + (long)(c0 + 16 * cb + (lane & 15)) * g.ldw + (lane >> 4) * 8;
+#pragma unroll
+      for (int kb = 0; kb < NKB2; ++kb) {
+        w1[kb][cb] = *reinterpret_cast<const f16x8*>(wp + kb * 32);
+        w2[kb][cb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 32);
+      }
+    }
+#else
     f16x8 w1[NKB], w2[NKB];
     {
       const unsigned short* wp = g.Wp + (long)(c0 + (lane & 31)) * g.ldw + (lane >> 5) * 8;
@@ -135,6 +157,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         w2[kb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 16);
       }
     }
+#endif
     const int ecol = c0 + (lane & 7) * 4;
     const f4 wsc = *reinterpret_cast<const f4*>(g.wscale + ecol);
     const f4 bias4 = epi_bias4(g.E, ecol);
@@ -160,6 +183,45 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) zq[q] = g.A.a[(t * FD_TP + (lane >> 3) + 8 * q) * g.A.lda + 256];
       }
+#if FD_MFMA16
+      fd_f32x4 acc[2][2];   // [row block of 16 points][column block of 16 columns]
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[rb][cb][j] = 0.0f;
+      const unsigned char* Ab = B + (lane & 15) * FD_ALD + (lane >> 4) * 16;   // A fragment: S'[16 rb + (lane & 15)][32 kb + 8 (lane >> 4) ..]
+      if (!(dbg & 4))
+#pragma unroll
+      for (int kb = 0; kb < NKB2; ++kb) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * FD_ALD + kb * 64);
+          const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * FD_ALD + FD_APLANE + kb * 64);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            fd_f32x4 c = acc[rb][cb];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w2[kb][cb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, w1[kb][cb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w1[kb][cb], c, 0, 0, 0);
+            acc[rb][cb] = c;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float* rs = reinterpret_cast<const float*>(B + 2 * FD_APLANE);
+      const float* ssr = rs + 32;
+      {
+        const int q4 = lane >> 4, cl = lane & 15;   // result block: rows 4 q4 + r, column cl
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(16 * rb + 4 * q4 + r) * FD_TLD + 16 * cb + cl] = acc[rb][cb][r];
+      }
+#else
       f32x16 acc;
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -179,6 +241,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
       const int hi = lane >> 5, cl = lane & 31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * FD_TLD + cl] = acc[r];
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const long tn = FD_TILE(i + ahead < nlast ? i + ahead : nlast);
@@ -274,6 +337,16 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     if (dbg & 8) __builtin_amdgcn_s_setprio(0); else if (dbg & 16) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
     const int wd = wave - 4, dt = tid - 256;
     const int srow = dt >> 4, scol = (dt & 15) * 4;
+#if FD_MFMA16
+    const int m = lane & 15, kg = lane >> 4;   // result blocks: column m, rows 4 kg + r
+    fd_f32x4 acc[4][8];                        // [block of 16 S columns (rows of dW)][block of 16 Ep columns]: 128 registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+#else
     const int m = lane & 31, kg = lane >> 5;
     f32x16 acc[2][4];
 #pragma unroll
@@ -282,6 +355,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#endif
     struct RawTile { f4 r[2][4]; float se[2]; };
     f4 cs[4];
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -345,6 +419,32 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     auto d_dw = [&](int i, int ab) {
       const unsigned char* B = smem + ab * FD_ABUF;
       const unsigned char* Yb = smem + FD_OFF_Y + (i & 1) * FD_YBUF;
+#if FD_MFMA16
+      {
+        // ONE k32 step covers the tile's 32 points.  This lane's 8-byte piece of a [4 points][16 columns] block: k group kg = lane >> 4 holds points
+        // 16 (kg >> 1) + 2 (kg & 1) + 4 r + h (the two 16-lane groups of a 32-lane half are then 8 banks apart, the four rows 16 banks: conflict-free)
+        const int prow = 16 * (kg >> 1) + 2 * (kg & 1) + 4 * ((lane & 15) >> 2), pcol = (lane & 3) * 4;
+        f16x8 a[4][2];
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) a[sb][pl] = ws_tr8(B + pl * FD_APLANE + prow * FD_ALD + (wd * 64 + sb * 16 + pcol) * 2, FD_ALD);
+#pragma unroll
+        for (int eb = 0; eb < 8; ++eb) {
+          const unsigned char* ysrc = Yb + prow * FD_YLD + (eb * 16 + pcol) * 2;
+          const f16x8 b1 = ws_tr8(ysrc, FD_YLD);
+          const f16x8 b2 = ws_tr8(ysrc + FD_YPLANE, FD_YLD);
+#pragma unroll
+          for (int sb = 0; sb < 4; ++sb) {
+            fd_f32x4 c = acc[sb][eb];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[sb][0], b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[sb][1], b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[sb][0], b1, c, 0, 0, 0);
+            acc[sb][eb] = c;
+          }
+        }
+      }
+#else
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         // this lane's 8-byte piece of a [4 points][16 columns] block: point row kb * 16 + 2 kg + 4 r (h = 1: one row below), 4 columns at pcol
@@ -371,6 +471,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
           acc[0][jt] = c0; acc[1][jt] = c1;
         }
       }
+#endif
     };
     int Gd = FD_GBIG;
     // weight-gradient contribution of tile i (buffer abp): fold the tile's exponent into the running one first
@@ -382,12 +483,21 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
         if (Gd < FD_GBIG) {   // exact power-of-two rescale of what has been accumulated under the old exponent
           const int dlt = mq + 1 - Gd;
           const float u1 = ldexpf(1.0f, dlt / 2), u2 = ldexpf(1.0f, dlt - dlt / 2);
+#if FD_MFMA16
+#pragma unroll
+          for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+            for (int eb = 0; eb < 8; ++eb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[sb][eb][r] = acc[sb][eb][r] * u1 * u2;
+#else
 #pragma unroll
           for (int it = 0; it < 2; ++it)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[it][jt][r] = acc[it][jt][r] * u1 * u2;
+#endif
         }
         Gd = mq + 1;
       }
@@ -445,6 +555,46 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
     if (Gd >= FD_GBIG) Gd = 0;
     const float u1 = ldexpf(1.0f, -(Gd / 2)), u2 = ldexpf(1.0f, -(Gd - Gd / 2));
     float* X = reinterpret_cast<float*>(smem + wd * (32 * 33 * 4));
+#if FD_MFMA16
+    // a lane holds dW[s = 16 sb + 4 kg + r][e = 16 eb + m] of each block.  Natural form: 64-byte row pieces; transposed form: 32 x 32 regions (2 x 2 blocks)
+    // through the per-wave LDS tile so that both forms store whole 128-byte row pieces where they can
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int s0 = wd * 64 + it * 32, e0 = half * 128 + jt * 32;
+        if (!f.transposed) {
+#pragma unroll
+          for (int sbl = 0; sbl < 2; ++sbl)
+#pragma unroll
+            for (int ebl = 0; ebl < 2; ++ebl)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int sidx = s0 + 16 * sbl + 4 * kg + r;
+                if (sidx < f.Npad) out[(long)sidx * f.ldk + e0 + 16 * ebl + m] = acc[2 * it + sbl][2 * jt + ebl][r] * u1 * u2;
+              }
+        } else {
+#pragma unroll
+          for (int sbl = 0; sbl < 2; ++sbl)
+#pragma unroll
+            for (int ebl = 0; ebl < 2; ++ebl)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) X[(16 * sbl + 4 * kg + r) * 33 + 16 * ebl + m] = acc[2 * it + sbl][2 * jt + ebl][r] * u1 * u2;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          {
+            const int m32 = lane & 31, k2 = lane >> 5;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int e = 2 * r + k2;
+              if (e0 + e < f.Npad) out[(long)(e0 + e) * f.ldk + s0 + m32] = X[m32 * 33 + e];
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+#else
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -470,6 +620,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
           __builtin_amdgcn_wave_barrier();
         }
       }
+#endif
     if (want_cs) {   // bias gradient: the 16 row owners of a column group are folded in a fixed order below
       float* C = reinterpret_cast<float*>(smem + 4 * (32 * 33 * 4));
 #pragma unroll
