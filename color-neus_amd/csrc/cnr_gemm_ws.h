@@ -23,6 +23,10 @@ namespace cnr {
 // 1.1e-6 -- also with rows spanning 12 orders of magnitude -- at 3 x 32 = 96 MFMA cycles per k16 block instead of 8 x 64 = 512.
 // No weight traffic after the prologue, 16 accumulator registers, one barrier per 32 points.
 // ================================================================================================
+#ifndef WS_MFMA16
+#define WS_MFMA16 1   // the stream form of the layer kernel on v_mfma_f32_16x16x32_f16 (0: 32 x 32 x 16, A/B builds)
+#endif
+typedef float ws_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WS_TP = 32;
 constexpr int WS_THREADS = 512;
 constexpr int WS_TLD = 36;
@@ -369,6 +373,21 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
   float* T = reinterpret_cast<float*>(smem_b + 2 * abuf) + wave * (32 * WS_TLD);
   const int c0 = g.col0 + wave * 32;
 
+#if WS_MFMA16
+  // (round 6) the stream form on v_mfma_f32_16x16x32_f16 -- 12 % cheaper per FLOP than the 32 x 32 x 16 shape and a 15 % higher clock under the board's power
+  // limit (profiles/r06_mfma_shapes.txt): B fragments of this wave's 2 x 16 output columns, lane (n = lane & 15, kg = lane >> 4) holds W[c0 + 16 cb + n][32 kb + 8 kg ..]
+  constexpr int NKB2 = NKB / 2;
+  f16x8 w1[NKB2][2], w2[NKB2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const unsigned short* wp = g.Wp + (long)(c0 + 16 * cb + (lane & 15)) * g.ldw + (lane >> 4) * 8;
+#pragma unroll
+    for (int kb = 0; kb < NKB2; ++kb) {
+      w1[kb][cb] = *reinterpret_cast<const f16x8*>(wp + kb * 32);
+      w2[kb][cb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 32);
+    }
+  }
+#else
   f16x8 w1[NKB], w2[NKB];
   {
     const unsigned short* wp = g.Wp + (long)(c0 + (lane & 31)) * g.ldw + (lane >> 5) * 8;
@@ -378,6 +397,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
       w2[kb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 16);
     }
   }
+#endif
   const f4 wsc = *reinterpret_cast<const f4*>(g.wscale + c0 + (lane & 7) * 4);
   const int ecol = c0 + (lane & 7) * 4;
   const f4 bias4 = epi_bias4(g.E, ecol);
@@ -447,6 +467,45 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
   }
   auto compute = [&](const long tc, const int buf) {
     const long t = WSS_TILE(tc < tlast ? tc : tlast);
+#if WS_MFMA16
+    ws_f32x4 acc[2][2];   // [row block of 16 points][column block of 16 columns]
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[rb][cb][j] = 0.0f;
+    const unsigned char* Ab = smem_b + buf * abuf + (lane & 15) * ald + (lane >> 4) * 16;   // A fragment: tile[16 rb + (lane & 15)][32 kb + 8 (lane >> 4) ..]
+#pragma unroll
+    for (int kb = 0; kb < NKB2; ++kb) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * ald + kb * 64);
+        const f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * ald + aplane + kb * 64);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          ws_f32x4 c = acc[rb][cb];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w2[kb][cb], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, w1[kb][cb], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w1[kb][cb], c, 0, 0, 0);
+          acc[rb][cb] = c;
+        }
+      }
+    }
+    // (scheduling fences between the phases: the blocks are branch-free now, and an unconstrained scheduler hoists the next phase's loads
+    // across the MFMA block until the register file spills)
+    __builtin_amdgcn_sched_barrier(0);
+    const float* rs = reinterpret_cast<const float*>(smem_b + buf * abuf + 2 * aplane);
+    {
+      const int q4 = lane >> 4, cl = lane & 15;   // result block: rows 4 q4 + r, column cl
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[(16 * rb + 4 * q4 + r) * WS_TLD + 16 * cb + cl] = acc[rb][cb][r];
+    }
+#else
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -466,6 +525,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_stream_kernel(con
     const int hi = lane >> 5, cl = lane & 31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * WS_TLD + cl] = acc[r];
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if constexpr (EPRE) {
