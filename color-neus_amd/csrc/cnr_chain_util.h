@@ -134,6 +134,29 @@ __device__ __forceinline__ void chain_mfma_blocks(f32x16 (&acc)[CB][RT], f16x8 (
         a2[cur ^ 1][rt] = *reinterpret_cast<const f16x8*>(Ab + rt * 32 * CH_ALD + aplane + (gk + 1) * 32);
       }
     }
+#ifdef CNR_CHAIN_MFMA16_PROBE
+    // TIMING PROBE ONLY (wrong results): the same FLOP, fragment registers and accumulator registers issued as v_mfma_f32_16x16x32_f16
+#define PROBE16(W, A)                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < CB; ++j) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                      \
+      typedef float pf4 __attribute__((ext_vector_type(4)));                                                                 \
+      f32x16& c = acc[j][rt];                                                                                                \
+      if (gk & 1) {                                                                                                          \
+        pf4 s0 = {c[8], c[9], c[10], c[11]}, s1 = {c[12], c[13], c[14], c[15]};                                              \
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[gk & 3][j], A[cur][rt], s0, 0, 0, 0);                                  \
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[gk & 3][j], A[cur][(rt + 1) % RT], s1, 0, 0, 0);                       \
+        c[8] = s0[0]; c[9] = s0[1]; c[10] = s0[2]; c[11] = s0[3]; c[12] = s1[0]; c[13] = s1[1]; c[14] = s1[2]; c[15] = s1[3]; \
+      } else {                                                                                                               \
+        pf4 s0 = {c[0], c[1], c[2], c[3]}, s1 = {c[4], c[5], c[6], c[7]};                                                    \
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[gk & 3][j], A[cur][rt], s0, 0, 0, 0);                                  \
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[gk & 3][j], A[cur][(rt + 1) % RT], s1, 0, 0, 0);                       \
+        c[0] = s0[0]; c[1] = s0[1]; c[2] = s0[2]; c[3] = s0[3]; c[4] = s1[0]; c[5] = s1[1]; c[6] = s1[2]; c[7] = s1[3];       \
+      }                                                                                                                      \
+    }
+    PROBE16(wr2, a1)
+    PROBE16(wr1, a2)
+    PROBE16(wr1, a1)
+#undef PROBE16
+#else
 #pragma unroll
     for (int j = 0; j < CB; ++j)
 #pragma unroll
@@ -146,6 +169,7 @@ __device__ __forceinline__ void chain_mfma_blocks(f32x16 (&acc)[CB][RT], f16x8 (
     for (int j = 0; j < CB; ++j)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[j][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr1[gk & 3][j], a1[cur][rt], acc[j][rt], 0, 0, 0);
+#endif
     if (gk + 4 < NTOT) chain_wload<CB>(wr1, wr2, gk & 3, wlane, nkb_w, kb0 + gk + 4);
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -80,6 +80,28 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   const int ncols_live = g.E.n_out + (g.E.tail_src ? g.E.tail_n : 0);
 
   // ---- resident weights (two f16 planes of this wave's 32 rows of W)
+#if WS_MFMA16
+  // v_mfma_f32_16x16x32_f16 like the stream form below (one arithmetic for every split-f16 layer product of the library): k32 blocks; when the
+  // number of live k16 blocks is odd, the lanes that hold the upper 16 k of the last block (lane >> 4 >= 2) carry zeros in both operands
+  constexpr int NKB2 = (NKB + 1) / 2;
+  f16x8 w1[NKB2][2], w2[NKB2][2];
+  const bool khi = (lane >> 4) >= 2;
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const unsigned short* wp = g.Wp + (long)(has_w ? c0 + 16 * cb + (lane & 15) : 0) * g.ldw + (lane >> 4) * 8;
+#pragma unroll
+    for (int kb = 0; kb < NKB2; ++kb) {
+      if (2 * kb < nkb) {
+        w1[kb][cb] = zero8; w2[kb][cb] = zero8;
+        if (!(khi && 2 * kb + 1 == nkb)) {
+          w1[kb][cb] = *reinterpret_cast<const f16x8*>(wp + kb * 32);
+          w2[kb][cb] = *reinterpret_cast<const f16x8*>(wp + g.wp_stride + kb * 32);
+        }
+      }
+    }
+  }
+#else
   f16x8 w1[NKB], w2[NKB];
   {
     const unsigned short* wp = g.Wp + (long)(has_w ? c0 + (lane & 31) : 0) * g.ldw + (lane >> 5) * 8;
@@ -91,6 +113,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       }
     }
   }
+#endif
   f4 wsc = {1.f, 1.f, 1.f, 1.f};               // inverse column scales of the 4 columns this lane finishes in the epilogue
   if (has_w) wsc = *reinterpret_cast<const f4*>(g.wscale + c0 + (lane & 7) * 4);
   const int ecol = c0 + (lane & 7) * 4;         // ... and their epilogue path / bias (fixed per lane for the whole launch)
@@ -159,6 +182,24 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     }                                                                             \
   }
 #define WS_PUT_TILE(buf_, tile_) WS_PUT_SET(buf_, tile_, a)
+#if WS_MFMA16
+#define WS_MFMA(kb_)                                                                               \
+  if (2 * (kb_) < nkb) {                                                                           \
+    const bool dead_ = khi && 2 * (kb_) + 1 == nkb;                                                \
+    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                             \
+      f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * ald + (kb_) * 64);                 \
+      f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * ald + aplane + (kb_) * 64);        \
+      if (dead_) { a1 = zero8; a2 = zero8; }                                                       \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                                           \
+        ws_f32x4 c = acc[rb][cb];                                                                  \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w2[kb_][cb], c, 0, 0, 0);                   \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, w1[kb_][cb], c, 0, 0, 0);                   \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w1[kb_][cb], c, 0, 0, 0);                   \
+        acc[rb][cb] = c;                                                                           \
+      }                                                                                            \
+    }                                                                                              \
+  }
+#else
 #define WS_MFMA(kb_)                                                                               \
   if ((kb_) < nkb) {                                                                               \
     const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + (kb_) * 32);                             \
@@ -167,6 +208,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, w1[kb_], acc, 0, 0, 0);                       \
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, w1[kb_], acc, 0, 0, 0);                       \
   }
+#endif
 
   // Waves 0..3 (rows 0..15 of a tile) and waves 4..7 (rows 16..31) share the SIMDs pairwise and run half an iteration out of
   // phase: the late group converts + stores its half of tile t+1 (fetched one iteration earlier) and fetches tile t+2 BEFORE
@@ -176,6 +218,20 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   // MFMAs + epilogue of tile t from LDS buffer buf
   auto compute = [&](const long tc, const int buf) {
     const long t = WS_TILE(tc);
+#if WS_MFMA16
+    ws_f32x4 acc[2][2];   // [row block of 16 points][column block of 16 columns]
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[rb][cb][j] = 0.0f;
+    const unsigned char* Ab = smem_b + buf * abuf + (lane & 15) * ald + (lane >> 4) * 16;
+    if (has_w) {
+      WS_MFMA(0) WS_MFMA(1) WS_MFMA(2) WS_MFMA(3) WS_MFMA(4) WS_MFMA(5) WS_MFMA(6) WS_MFMA(7)
+      if (K17) { WS_MFMA(NKB2 - 1) }
+    }
+#else
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -185,14 +241,27 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
       WS_MFMA(8) WS_MFMA(9) WS_MFMA(10) WS_MFMA(11) WS_MFMA(12) WS_MFMA(13) WS_MFMA(14) WS_MFMA(15)
       if (K17) { WS_MFMA(NKB - 1) }
     }
+#endif
     // epilogue of this 32 x 32 tile: undo the exact row / column scales, then the fused epilogue on 4 columns per lane.
     // The side inputs of all four row groups are requested first: one memory round trip per tile, and no load has to
     // wait behind the stores of the previous row group.
     if (c0 < ncols_live) {
       const float* rs = reinterpret_cast<const float*>(smem_b + buf * abuf + 2 * aplane);
+#if WS_MFMA16
+      {
+        const int q4 = lane >> 4, cl = lane & 15;   // result block: rows 4 q4 + r, column cl
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(16 * rb + 4 * q4 + r) * WS_TLD + 16 * cb + cl] = acc[rb][cb][r];
+      }
+#else
       const int hi = lane >> 5, cl = lane & 31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * WS_TLD + cl] = acc[r];
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       constexpr int EG = (EK == EK_SWEEP || EK == EK_VBACK) ? 2 : 4;   // row groups whose side inputs are in flight together (register budget)
