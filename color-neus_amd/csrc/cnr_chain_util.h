@@ -135,7 +135,11 @@ __device__ __forceinline__ void chain_mfma_blocks(f32x16 (&acc)[CB][RT], f16x8 (
       }
     }
 #ifdef CNR_CHAIN_MFMA16_PROBE
-    // TIMING PROBE ONLY (wrong results): the same FLOP, fragment registers and accumulator registers issued as v_mfma_f32_16x16x32_f16
+    // TIMING PROBE ONLY (wrong results): the same FLOP, fragment registers and accumulator registers issued as v_mfma_f32_16x16x32_f16.  It measured the chain
+    // kernels 15-27 % faster (profiles/r06_probe_chain_mfma16.txt) and MISLED: the real conversion (tools/ab/exp_chain_mfma16.patch: k32 fragment layout, a lane
+    // owning two points x 8 columns, parity-green on the GPU) is 5-8 % SLOWER than this 32 x 32 x 16 form (profiles/r06_ab_chain_mfma16.txt) -- the probe's wrong
+    // activations change what the matrix pipe is fed (zero-heavy operands draw far less power: tools/mfma_power.py), these kernels run below the board's power
+    // limit (so cheaper MFMAs do not buy time as they do in layer_dw), and the 16 x 16 lane ownership costs the epilogue two cross-lane steps per row maximum.
 #define PROBE16(W, A)                                                                                                        \
     _Pragma("unroll") for (int j = 0; j < CB; ++j) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                      \
       typedef float pf4 __attribute__((ext_vector_type(4)));                                                                 \

@@ -158,7 +158,7 @@ def check_outputs(fx, tag, out, tol=1e-4, factor=1.5):
     -- in the sharp regime the reference's float32 `weights` sit 1.1e-4 from its float64 run (neus_dtu_nonormal; SURVEY 8c measured 3.8e-5 on
     another draw), so a flat 1e-4 against the float32 vector would gate an implementation on the reference's round-off, not on its own.
     Otherwise: within tol of the float32 vector.  Returns the offending (key, error, limit) rows."""
-    bad = []
+    bad, lims = [], {}
     for k in OUTPUT_KEYS:
         if f"{tag}:out_{k}" not in fx:
             continue
@@ -169,12 +169,17 @@ def check_outputs(fx, tag, out, tol=1e-4, factor=1.5):
             e, lim = relerr(got, ref64), max(tol, factor * relerr(torch.from_numpy(np.asarray(ref32)), ref64))
         else:
             e, lim = relerr(got, ref32), tol
+        lims[k] = lim
+        if k == "weight_max":
+            # max_j w_j of a ray: |max w - max w'| <= max |w - w'| on the same scale (the largest weight), so `weights` passing its limit already
+            # bounds this output by that limit; a tighter one would gate the same quantity twice with two different numbers
+            lim = max(lim, lims.get("weights", 0.0))
         if not e < lim:
             bad.append((k, e, lim))
     return bad
 
 
-OUTPUT_KEYS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",
+OUTPUT_KEYS = ["color_fine", "s_val", "cdf_fine", "weight_sum", "weights", "weight_max", "gradients",   # (weights in front of weight_max: see check_outputs)
                "gradient_error", "inside_sphere", "depth", "global_color", "delta_relight"]
 
 
