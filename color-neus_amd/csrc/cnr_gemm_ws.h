@@ -26,6 +26,13 @@ namespace cnr {
 #ifndef WS_MFMA16
 #define WS_MFMA16 1   // the stream form of the layer kernel on v_mfma_f32_16x16x32_f16 (0: 32 x 32 x 16, A/B builds)
 #endif
+#ifndef WS_GEN_MFMA16
+// ... and the general form.  Built and parity-green on 16 x 16 x 32 too (then bit-identical to the stream form), but SLOWER there: 478 against 358 us for the
+// one general launch of a step (the 217-wide layer of the forward gradient chain; profiles/r06_ab_general_mfma16.txt) -- its k blocks sit behind run-time
+// guards, so nothing is scheduled across them.  It stays on 32 x 32 x 16: the two forms then agree to fp32 round-off, not to the bit
+// (tests/test_hip_parity.py::test_stream_form_of_the_layer_kernel_matches_the_general_form).
+#define WS_GEN_MFMA16 0
+#endif
 typedef float ws_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WS_TP = 32;
 constexpr int WS_THREADS = 512;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   const int ncols_live = g.E.n_out + (g.E.tail_src ? g.E.tail_n : 0);
 
   // ---- resident weights (two f16 planes of this wave's 32 rows of W)
-#if WS_MFMA16
+#if WS_GEN_MFMA16
   // v_mfma_f32_16x16x32_f16 like the stream form below (one arithmetic for every split-f16 layer product of the library): k32 blocks; when the
   // number of live k16 blocks is odd, the lanes that hold the upper 16 k of the last block (lane >> 4 >= 2) carry zeros in both operands
   constexpr int NKB2 = (NKB + 1) / 2;
@@ -182,19 +189,23 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     }                                                                             \
   }
 #define WS_PUT_TILE(buf_, tile_) WS_PUT_SET(buf_, tile_, a)
-#if WS_MFMA16
+#if WS_GEN_MFMA16
 #define WS_MFMA(kb_)                                                                               \
   if (2 * (kb_) < nkb) {                                                                           \
-    const bool dead_ = khi && 2 * (kb_) + 1 == nkb;                                                \
+    /* all four fragments of the block first: one exposed LDS round trip per k32 block, not one per row block */ \
+    f16x8 a1_[2], a2_[2];                                                                          \
     _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                             \
-      f16x8 a1 = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * ald + (kb_) * 64);                 \
-      f16x8 a2 = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * ald + aplane + (kb_) * 64);        \
-      if (dead_) { a1 = zero8; a2 = zero8; }                                                       \
+      a1_[rb] = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * ald + (kb_) * 64);                  \
+      a2_[rb] = *reinterpret_cast<const f16x8*>(Ab + rb * 16 * ald + aplane + (kb_) * 64);         \
+    }                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                             \
+      if (2 * (kb_) + 1 == nkb) { if (khi) { a1_[rb] = zero8; a2_[rb] = zero8; } }   /* (uniform test first: the lane select only runs in an odd last block) */ \
       _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                                           \
         ws_f32x4 c = acc[rb][cb];                                                                  \
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w2[kb_][cb], c, 0, 0, 0);                   \
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, w1[kb_][cb], c, 0, 0, 0);                   \
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w1[kb_][cb], c, 0, 0, 0);                   \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1_[rb], w2[kb_][cb], c, 0, 0, 0);              \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2_[rb], w1[kb_][cb], c, 0, 0, 0);              \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1_[rb], w1[kb_][cb], c, 0, 0, 0);              \
         acc[rb][cb] = c;                                                                           \
       }                                                                                            \
     }                                                                                              \
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
   // MFMAs + epilogue of tile t from LDS buffer buf
   auto compute = [&](const long tc, const int buf) {
     const long t = WS_TILE(tc);
-#if WS_MFMA16
+#if WS_GEN_MFMA16
     ws_f32x4 acc[2][2];   // [row block of 16 points][column block of 16 columns]
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void layer_gemm_ws_kernel(const Laye
     // wait behind the stores of the previous row group.
     if (c0 < ncols_live) {
       const float* rs = reinterpret_cast<const float*>(smem_b + buf * abuf + 2 * aplane);
-#if WS_MFMA16
+#if WS_GEN_MFMA16
       {
         const int q4 = lane >> 4, cl = lane & 15;   // result block: rows 4 q4 + r, column cl
 #pragma unroll

@@ -549,10 +549,13 @@ np.savez(out, **res)
 """
 
 
-def test_stream_form_of_the_layer_kernel_is_bit_identical(tmp_path):
+def test_stream_form_of_the_layer_kernel_matches_the_general_form(tmp_path):
     """layer_gemm_ws_stream_kernel (per-wave-group loops, prefetched epilogue inputs; most layer launches of a step) against the general
-    kernel (CNR_WS_NOSTREAM=1, child processes): same tiles, same MFMA order, same epilogue arithmetic -> every output and every gradient
-    of a forward + backward pass must agree to the bit."""
+    kernel (CNR_WS_NOSTREAM=1, child processes): same tiles, same split, same epilogue arithmetic.  Since round 6 the stream form issues its
+    products as v_mfma_f32_16x16x32_f16 and the general form stays on 32x32x16 (cnr_gemm_ws.h, WS_GEN_MFMA16: the general form is 30 % slower on the
+    other shape), so the fp32 accumulation order inside a product differs: every output and every gradient of a forward + backward pass must
+    agree to fp32 round-off -- 1e-5 of the tensor's largest entry for the outputs, the fixture's own per-tensor float32 tolerance for the gradients
+    (a build with -DWS_GEN_MFMA16=1 is bit-identical: that was this test until then)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for tag, extra in (("stream", {}), ("general", {"CNR_WS_NOSTREAM": "1"})):
@@ -561,8 +564,34 @@ def test_stream_form_of_the_layer_kernel_is_bit_identical(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         res[tag] = dict(np.load(path))
     assert set(res["stream"]) == set(res["general"])
+    fx = G.load("dtu_sharp")
+    bad, worst = [], {}
+    frac, floor, cap = G._gate(True)
     for k in sorted(res["stream"]):
-        assert np.array_equal(res["stream"][k], res["general"][k], equal_nan=True), k
+        a, b = res["stream"][k].astype(np.float64).reshape(-1), res["general"][k].astype(np.float64).reshape(-1)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        if a.size == 0:
+            continue
+        e = np.nan_to_num(np.abs(a - b)) / max(float(np.nanmax(np.abs(b))), 1e-300)
+        grad = k.startswith("g:") or k in ("d_o", "d_d")
+        if not grad:
+            lim, emax, bulk = 1e-5, float(e.max()), float(e.max())
+        else:
+            # Two float32 evaluations of the same gradient under the HIP gate's own rule (G.check_param_grads, strict): the bulk of a tensor's entries
+            # within the fixture's per-tensor float32 tolerance (`gspread`; 5e-5 for the ray gradients), a handful -- a ReLU unit of the colour / relight
+            # stacks that sits within round-off of its kink at one sample and flips with the last bit of the normals -- up to the hard cap
+            sp = fx.get("det:gspread:" + k[2:]) if k.startswith("g:") else None
+            lim = 5e-5 if sp is None else min(cap, G.grad_tolerance(sp, strict=True) if a.size > 1 else G.scalar_tolerance(sp))
+            allowed = max(floor, int(frac * a.size)) if a.size > 1 else 0
+            emax = float(e.max())
+            bulk = float(np.sort(e)[-(allowed + 1)]) if a.size > allowed else 0.0
+            if emax > cap:
+                bad.append((k, "cap", emax, cap))
+        worst["grad" if grad else "out"] = max(worst.get("grad" if grad else "out", 0.0), bulk / lim)
+        if not bulk < lim:
+            bad.append((k, bulk, lim, emax))
+    print("stream vs general form, largest difference as a fraction of the limit:", worst)
+    assert not bad, bad
 
 
 def test_fused_layer_dw_matches_separate_launches(tmp_path):
