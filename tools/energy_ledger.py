@@ -130,6 +130,25 @@ def mfma_unit_cost():
     return (float(tf.group(1)), float(w.group(1)), t) if tf and w else None
 
 
+def mfma_shape_costs():
+    """(TFLOP/s, W) of the matrix pipe alone per MFMA shape (tools/mfma_order.py --shapes): {"16x16x32": .., "32x32x16": ..}; {} if the probe cannot run here"""
+    try:
+        t = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_order.py"), "--shapes"], capture_output=True, text=True, timeout=180).stdout
+    except Exception:
+        return {}, ""
+    out = {}
+    for shape in ("16x16x32", "32x32x16"):
+        m = re.search(r"v_mfma_f32_%s_f16[^\n]*?([0-9.]+) TFLOP/s\s+W mean\s+([0-9.]+)" % shape, t)
+        if m:
+            out[shape] = (float(m.group(1)), float(m.group(2)))
+    return out, t
+
+
+# kernels whose split-f16 products are issued as v_mfma_f32_16x16x32_f16 (round 6): the fused layer + weight-gradient kernel and the stream form of the
+# layer kernel (6 of the 7 launches of the layer_gemm_ws family in a step; the family is priced at that shape).  Everything else is on 32x32x16.
+MFMA16_KERNELS = ("layer_dw", "layer_gemm_ws")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=4.0)
@@ -164,9 +183,25 @@ def main():
     else:
         tflop_per_j = 1603.0 / (1236.0 - 297.0)
         src = "profiles/r05_mfma_power.txt: 1603 TFLOP/s at 1236 W over 297 W idle"
+    shapes, shapes_txt = ({}, "") if a.no_mfma_probe else mfma_shape_costs()
+    price = {"32x32x16": tflop_per_j, "16x16x32": tflop_per_j}
+    for sh, (tf, w) in shapes.items():
+        price[sh] = tf / (w - idle_w)
+    def kprice(name):
+        return price["16x16x32"] if name in MFMA16_KERNELS else price["32x32x16"]
+    def fam_mfma_j(r, drop=None):
+        """MFMA joules of a family = sum over its kernels at each kernel's shape price; drop = (kernel, TFLOP) switched off in an ablation run"""
+        j = 0.0
+        for k, v in r["kernels"].items():
+            tf = v[2] - (drop[1] if drop and drop[0] == k else 0.0)
+            j += max(tf, 0.0) / kprice(k)
+        return j
     print("# energy ledger, %d rays (%d points) per pass; rocm-smi every 0.25 s while one family loops for %.0f s (first second dropped)" % (a.rays, a.rays * 128, a.seconds))
     print("# unit costs above the idle draw (%.0f W): memory %.1f pJ/B (device copy: %.2f TB/s of traffic at %.0f W); matrix pipe %.2f TFLOP/J (%s)" %
           (idle_w, j_per_gb * 1e3, cp["gbytes"] / cp["ms_per_pass"], cp["W"], tflop_per_j, src))
+    if shapes:
+        print("# matrix pipe by MFMA shape (tools/mfma_order.py --shapes, same run): " + "; ".join("%s %.0f TFLOP/s at %.0f W = %.2f TFLOP/J" % (sh, tf, w, price[sh]) for sh, (tf, w) in sorted(shapes.items())) +
+              " -- layer_dw and the layer_gemm_ws family are priced at 16x16x32, every other kernel at 32x32x16")
     print("# rest = J - MFMA - memory - idle: LDS, registers, VALU, issue, L2 weight streams (the fused launches' second read of their input tile is an L2 hit and not in 'GB')")
     print("%-26s %8s %7s %6s %7s | %7s %7s %7s %7s | %6s %6s  %s" % ("family", "ms/pass", "W", "MHz", "J/pass", "MFMA J", "mem J", "idle J", "rest J", "TFLOP", "GB", "rest/J"))
     for fam, _ in fams:
@@ -174,14 +209,14 @@ def main():
         if not r:
             continue
         J = r["W"] * r["ms_per_pass"] * 1e-3
-        jm = r["f16_mfma_tflop"] / tflop_per_j
+        jm = fam_mfma_j(r)
         if fam == "backward_no_dw_mfma" or fam == "backward_no_product_mfma":
             # half of the fused launches' MFMAs are switched off: take them out of the FLOP count
             k = rec["backward"]["kernels"].get("layer_dw", [0, 0, 0, 0])
-            jm = (r["f16_mfma_tflop"] - 0.5 * k[2]) / tflop_per_j
+            jm = fam_mfma_j(r, ("layer_dw", 0.5 * k[2]))
         if fam == "backward_no_mfma":
             k = rec["backward"]["kernels"].get("layer_dw", [0, 0, 0, 0])
-            jm = (r["f16_mfma_tflop"] - k[2]) / tflop_per_j
+            jm = fam_mfma_j(r, ("layer_dw", k[2]))
         jb = r["gbytes"] * j_per_gb
         ji = idle_w * r["ms_per_pass"] * 1e-3
         rest = J - jm - jb - ji
@@ -198,7 +233,7 @@ def main():
         for k, v in sorted(r["kernels"].items(), key=lambda kv: -kv[1][1]):
             share = v[1] / r["kernel_ms"] if r["kernel_ms"] else 0
             jk = J * share
-            jmk = v[2] / tflop_per_j
+            jmk = v[2] / kprice(k)
             jbk = v[3] * j_per_gb
             jik = idle_w * r["ms_per_pass"] * 1e-3 * share
             print("   %-22s x%-3d %7.3f ms  %6.3f TFLOP %6.2f GB | J/launch %.4f = MFMA %.4f + mem %.4f + idle %.4f + rest %.4f" %
@@ -207,6 +242,10 @@ def main():
         print()
         print("# matrix pipe alone (tools/mfma_power.py):")
         for line in mf[2].splitlines():
+            print("#   " + line)
+    if shapes_txt:
+        print("# matrix pipe by shape (tools/mfma_order.py --shapes):")
+        for line in shapes_txt.splitlines():
             print("#   " + line)
 
 
