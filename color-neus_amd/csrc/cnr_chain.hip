@@ -251,12 +251,12 @@ __global__ __launch_bounds__(512 / CB, 2 / (3 - CB) + 0) void sdf_value_chain_ke
         if (last) {
 #pragma unroll
           for (int j = 0; j < CB; ++j) {
-            const float other = __shfl_xor(dotj[j][rt], 32);
-            if (half == 0) pm[(rt * 32 + pt) * 8 + wave * CB + j] = dotj[j][rt] + other;
+            const float both = cnr_pair32_sum(dotj[j][rt]);
+            if (half == 0) pm[(rt * 32 + pt) * 8 + wave * CB + j] = both;
           }
         } else {
-          const float other = __shfl_xor(red[rt], 32);
-          if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = fmaxf(red[rt], other);
+          const float both = cnr_pair32_max(red[rt]);
+          if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = both;
         }
       }
       lds_barrier();   // partial maxima visible; every wave is done reading the planes of this layer's input

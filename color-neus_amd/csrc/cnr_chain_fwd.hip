@@ -196,8 +196,8 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
             mx = fmaxf(fmaxf(a.x, a.y), mx);
           }
           if (!chain_end) {
-            const float other = __shfl_xor(mx, 32);
-            if (half == 0) pm[row_l * 8 + wave] = fmaxf(mx, other);
+            const float both = cnr_pair32_max(mx);
+            if (half == 0) pm[row_l * 8 + wave] = both;
           }
         }
       }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
             float dot = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dot = fmaf(acc[rt][r], wj[r >> 2][r & 3], dot);
-            dot += __shfl_xor(dot, 32);
+            dot = cnr_pair32_sum(dot);
             if (half == 0) hp[((rt * 32 + pt) * 8 + wave) * 4 + j] = dot;
           }
         }
@@ -514,9 +514,9 @@ __global__ __launch_bounds__(512, 1) void sdf_save_chain_kernel(const SdfSaveCha
       if (!is_top) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const float o = __shfl_xor(rmax[rt], 32);
-          if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = fmaxf(rmax[rt], o);
-          if (last_hidden) { const float od = __shfl_xor(rdot[rt], 32); if (half == 0) pd[(rt * 32 + pt) * 8 + wave] = rdot[rt] + od; }
+          const float o = cnr_pair32_max(rmax[rt]);
+          if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = o;
+          if (last_hidden) { const float od = cnr_pair32_sum(rdot[rt]); if (half == 0) pd[(rt * 32 + pt) * 8 + wave] = od; }
         }
       }
       lds_barrier();   // partial maxima / dots visible; every wave is done reading the planes of this step's input
@@ -800,8 +800,8 @@ __global__ __launch_bounds__(512, 1) void sdf_grad_chain_kernel(const SdfGradCha
         if (l > 0) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
-            const float o = __shfl_xor(rmax[rt], 32);
-            if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = fmaxf(rmax[rt], o);
+            const float o = cnr_pair32_max(rmax[rt]);
+            if (half == 0) pm[(rt * 32 + pt) * 8 + wave] = o;
           }
         }
       }

@@ -412,8 +412,7 @@ __global__ __launch_bounds__(512, 1) void layer_dw_kernel(const LayerGemm g_in, 
           qmin = e < qmin ? e : qmin;
         }
       }
-      { const int o = __shfl_xor(qmin, 16); qmin = o < qmin ? o : qmin; }
-      { const int o = __shfl_xor(qmin, 32); qmin = o < qmin ? o : qmin; }
+      qmin = cnr_pair32_min(cnr_pair16_min(qmin));   // (rows 16 apart, then the two halves: VALU lane swaps, not LDS-crossbar shuffles)
       if (lane == 0) info[ab * 4 + wd] = qmin;
     };
     auto d_dw = [&](int i, int ab) {

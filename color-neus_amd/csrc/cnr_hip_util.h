@@ -52,6 +52,42 @@ __device__ __forceinline__ float cnr_max16(float x) {
 #endif
   return x;
 }
+// Cross-half and cross-row exchanges as VALU ops (gfx950: v_permlane32_swap_b32 / v_permlane16_swap_b32) instead of __shfl_xor(.., 32) / (.., 16), which hipcc
+// lowers to ds_bpermute_b32 (an LDS-crossbar round trip each, and an s_waitcnt on the LDS counter in the middle of an epilogue).  permlane32_swap(x, x) returns
+// {(lo, lo), (hi, hi)} (lanes 0-31 | 32-63), permlane16_swap(x, x) {(r0, r0, r2, r2), (r1, r1, r3, r3)} (16-lane rows): the two results hold this lane's value and
+// its partner's, so max / min / sum of the pair are one more VALU op -- the same numbers as with the shuffle (max, min exact; a + b commutative).
+__device__ __forceinline__ float cnr_pair32_max(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#endif
+  return x;
+}
+__device__ __forceinline__ float cnr_pair32_sum(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+  return x;
+}
+__device__ __forceinline__ int cnr_pair32_min(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+  const int a = (int)r[0], b = (int)r[1];
+  x = a < b ? a : b;
+#endif
+  return x;
+}
+__device__ __forceinline__ int cnr_pair16_min(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+  const int a = (int)r[0], b = (int)r[1];
+  x = a < b ? a : b;
+#endif
+  return x;
+}
 #define CNR_LAUNCH_CHECK(where)                                   \
   do {                                                            \
     hipError_t e_ = hipGetLastError();                            \
