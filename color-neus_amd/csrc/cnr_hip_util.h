@@ -88,6 +88,33 @@ __device__ __forceinline__ int cnr_pair16_min(int x) {
 #endif
   return x;
 }
+// max over the 8 lanes of a half DPP row / min over the 16 lanes of a DPP row by DPP moves (see cnr_max16), and the pair exchanges of two values at once
+__device__ __forceinline__ float cnr_max8(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int v = __float_as_int(x);
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false))); v = __float_as_int(x);
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false))); v = __float_as_int(x);
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false)));
+#endif
+  return x;
+}
+__device__ __forceinline__ int cnr_min16(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int o;
+  o = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false); x = o < x ? o : x;
+  o = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false); x = o < x ? o : x;
+  o = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false); x = o < x ? o : x;
+  o = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false); x = o < x ? o : x;
+#endif
+  return x;
+}
+__device__ __forceinline__ int cnr_ror8_min(int x) {   // min with the lane 8 further in the 16-lane row (lane ^ 8)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int o = __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false);
+  x = o < x ? o : x;
+#endif
+  return x;
+}
 #define CNR_LAUNCH_CHECK(where)                                   \
   do {                                                            \
     hipError_t e_ = hipGetLastError();                            \

@@ -264,8 +264,20 @@ __global__ __launch_bounds__(512) void strip_bwd_kernel(const StripBwd p, long p
         v[u * NT + j] = fmaf(d[u].w, w[j].w, fmaf(d[u].z, w[j].z, fmaf(d[u].y, w[j].y, d[u].x * w[j].x)));
       }
     }
+    // halving exchange.  Steps 32 and 16 by VALU lane swaps: v_permlane32_swap(v[i], v[i + mk]) leaves {(lo of v[i], lo of v[i + mk]), (hi of v[i], hi of v[i + mk])},
+    // i.e. in every lane the value it keeps and the one its partner sends -- their sum is keep + recv of the shuffle form (a + b commutes: same bits)
 #pragma unroll
-    for (int mk = 32; mk >= 1; mk >>= 1) {
+    for (int i = 0; i < 32; ++i) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
+      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+      v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int mk = 8; mk >= 1; mk >>= 1) {
       const bool up = (lane & mk) != 0;
 #pragma unroll
       for (int i = 0; i < mk; ++i) {

@@ -218,8 +218,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void narrow_bwd_kernel(const NarrowB
     // ---- dW of this tile: rows c0 .. c0 + 31
     const int e_l = er[m];
     int Gt = e_l == -NB_EBIG ? NB_EBIG - 1 : e_l;        // (non-finite rows do not steer the exponent ...)
-#pragma unroll
-    for (int d = 1; d <= 16; d <<= 1) { const int o = __shfl_xor(Gt, d); Gt = o < Gt ? o : Gt; }
+    Gt = cnr_pair16_min(cnr_min16(Gt));   // (min over the 32 lanes of a half: DPP row moves + one row swap)
     Gt = __builtin_amdgcn_readfirstlane(Gt);
     if (Gt == NB_EBIG - 1) Gt = 0;                       // (... but a tile that has nothing else still has to carry them into the sums)
     if (Gt < NB_EBIG) {

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
       }
       u[q].x = live ? s1x * vx : 0.0f; u[q].y = live ? s1y * vy : 0.0f; u[q].z = live ? s1z * vz : 0.0f; u[q].w = live ? s1w * vw : 0.0f;
       float mx = ws_absmax4(u[q]);
-      mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+      mx = cnr_max8(mx);   // (the 8 lanes of a row piece: DPP moves, not LDS-crossbar shuffles)
       const float ss = ssr[rr];
       if (mx > 0.0f && mx < 3.0e38f && ss > 0.0f) {
         int e_; (void)frexpf(mx, &e_); if (e_ < -100) e_ = -100;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
       }
     }
     e_fetch(i + 1);
-    { int o = __shfl_xor(qmin, 8); qmin = o < qmin ? o : qmin; o = __shfl_xor(qmin, 16); qmin = o < qmin ? o : qmin; o = __shfl_xor(qmin, 32); qmin = o < qmin ? o : qmin; }
+    qmin = cnr_pair32_min(cnr_pair16_min(cnr_ror8_min(qmin)));
     qmin = __builtin_amdgcn_readfirstlane(qmin);
     if (qmin < S0_GBIG && qmin + 1 < G) {
       if (G < S0_GBIG) {
