@@ -10,7 +10,7 @@
 //   * the MFMA is issued TRANSPOSED (A operand = weights, B operand = activations): a lane then owns ONE point and 16 CONSECUTIVE
 //     output columns (the weight rows are dealt to the fragment so that register r <-> column c0 + 16 * half + r), so the fused
 //     epilogue (bias, softplus, skip concat, row max, f16 split) is plain per-lane code and the next layer's planes are written with
-//     16-byte LDS stores -- no transpose through LDS, one 32-lane shuffle per row for the row max;
+//     16-byte LDS stores -- no transpose through LDS, one exchange between the two 32-lane halves per row for the row max (a VALU lane swap, cnr_pair32_max);
 //   * two barriers per layer (row-max exchange, planes ready).
 // Arithmetic is the per-layer kernels' arithmetic (same split, same scales, same MFMA order; the epilogue uses fused multiply-adds),
 // so results agree with the unfused path to fp32 round-off.
