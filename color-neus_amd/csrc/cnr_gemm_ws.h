@@ -380,19 +380,30 @@ inline int ws_next_rev() { static std::atomic<unsigned> parity{0}; return (int)(
 // ================================================================================================
 // Branch-free forms of epi_fetch4 / epi_finish4 for an epilogue without split point and tail fill (the stream kernel's promise): a branch
 // between two memory operations costs the compiler its count of what is still in flight.
+// The epilogue's side inputs (pre-activations, ReLU masks, the cotangent a value-backward launch adds to) are read once per launch: as NON-TEMPORAL loads they do not
+// push the lines the launch re-reads (its own input tile, the weights) or hands to the next launch (its output rows) out of L2 / Infinity Cache: +0.2-0.3 % of the step,
+// same bits (profiles/r06_ab_nt_side_inputs.txt).  The STAGED tile must stay a plain load: non-temporal there costs 2 % (the fused launches read it twice).
+#ifndef WS_NT_SIDE
+#define WS_NT_SIDE 1
+#endif
+#if WS_NT_SIDE
+#define WS_NTLOAD(p_) __builtin_nontemporal_load(reinterpret_cast<const f4*>(p_))
+#else
+#define WS_NTLOAD(p_) (*reinterpret_cast<const f4*>(p_))
+#endif
 template <int EK>
 __device__ __forceinline__ EpiRaw4 epi_fetch4_plain(const Epi& e, long row, int col) {
   EpiRaw4 r;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   r.a = zero; r.b = zero;
   if constexpr (EK == EK_SWEEP) {
-    r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
-    r.b = *reinterpret_cast<const f4*>(e.v + row * e.ldv + col);   // ldv == 0: the broadcast row
+    r.a = WS_NTLOAD(e.z + row * e.ldz + col);
+    r.b = WS_NTLOAD(e.v + row * e.ldv + col);   // ldv == 0: the broadcast row
   } else if constexpr (EK == EK_VBACK) {
-    r.a = *reinterpret_cast<const f4*>(e.z + row * e.ldz + col);
-    r.b = *reinterpret_cast<const f4*>(e.o1 + row * e.ld1 + col);
+    r.a = WS_NTLOAD(e.z + row * e.ldz + col);
+    r.b = WS_NTLOAD(e.o1 + row * e.ld1 + col);
   } else if constexpr (EK == EK_RELU_MASK) {
-    r.a = *reinterpret_cast<const f4*>(e.aux + row * e.ldaux + col);
+    r.a = WS_NTLOAD(e.aux + row * e.ldaux + col);
   }
   return r;
 }
