@@ -33,6 +33,18 @@
 
 namespace cnr {
 
+// What the forward chains store for the backward pass is read again tens of launches later: as NON-TEMPORAL stores these rows do not displace the weight fragments
+// every tile streams from L2 (CH_NT_SAVE 0: plain stores, A/B builds)
+#ifndef CH_NT_SAVE
+#define CH_NT_SAVE 1
+#endif
+#if CH_NT_SAVE
+#define CH_SAVE_STORE(p_, v_) __builtin_nontemporal_store((v_), reinterpret_cast<f4*>(p_))
+#else
+#define CH_SAVE_STORE(p_, v_) (*reinterpret_cast<f4*>(p_) = (v_))
+#endif
+
+
 // the scale a row's consumers get (LayerGemm::rs_out convention): 0 for an all-zero row, NaN for a non-finite one
 __device__ __forceinline__ float chain_rs_value(float mx, float sc) { return (mx > 0.0f && mx < 3.0e38f) ? sc : (mx == 0.0f ? 0.0f : __builtin_nanf("")); }
 
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
               const int r = (lane >> 3) + 8 * i, ch = lane & 7;
               const f4 v = *reinterpret_cast<const f4*>(tb + r * 128 + ((ch ^ (r & 7)) << 4));
               const int row0 = rt * 32 + hpass * 16 + 8 * i;                         // first row of this 8-row group within the tile
-              if (row0 + (lane >> 3) < rows_left && !(CNR_ABLATION(c.dbg) & 8)) *reinterpret_cast<f4*>(save_tile + row0 * S.ld_save + sv_off) = v;
+              if (row0 + (lane >> 3) < rows_left && !(CNR_ABLATION(c.dbg) & 8)) CH_SAVE_STORE(save_tile + row0 * S.ld_save + sv_off, v);   // (read again only by the backward pass)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(512, 1) void relu_chain_fwd_kernel(const ReluChainF
 // 16 rows at a time (XOR-swizzled 16-byte chunks: conflict-free both ways), stored as 8 rows x 128 contiguous bytes per instruction.
 // dst_tile: first row of the tile (uniform) + the wave's first column; row_base: the block's first row within the tile.
 // ------------------------------------------------------------------------------------------------
+template <bool NT = false>
 __device__ __forceinline__ void chain_save_block(const f32x16& a, unsigned char* tb, float* dst_tile, int ld, int row_base, int rows_left, int lane) {
   const int half = lane >> 5, pt = lane & 31;
   const int sv_off = (lane >> 3) * ld + (lane & 7) * 4;
@@ -351,7 +364,7 @@ __device__ __forceinline__ void chain_save_block(const f32x16& a, unsigned char*
       const int r = (lane >> 3) + 8 * i, ch = lane & 7;
       const f4 v = *reinterpret_cast<const f4*>(tb + r * 128 + ((ch ^ (r & 7)) << 4));
       const int row0 = row_base + hpass * 16 + 8 * i;
-      if (row0 + (lane >> 3) < rows_left) *reinterpret_cast<f4*>(dst_tile + row0 * ld + sv_off) = v;
+      if (row0 + (lane >> 3) < rows_left) { if (NT) CH_SAVE_STORE(dst_tile + row0 * ld + sv_off, v); else *reinterpret_cast<f4*>(dst_tile + row0 * ld + sv_off) = v; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -483,7 +496,8 @@ __global__ __launch_bounds__(512, 1) void sdf_save_chain_kernel(const SdfSaveCha
               acc[rt][r] = ei < 0 ? acc[rt][r] : ((next_skip && ei < v.emb) ? ev[r] : 0.0f);
             }
           }
-          chain_save_block(acc[rt], tb, out_tile, out_ld, rt * 32, rows_left, lane);
+          if (is_top) chain_save_block<false>(acc[rt], tb, out_tile, out_ld, rt * 32, rows_left, lane);   // (the feature rows: the colour network reads them next)
+          else chain_save_block<true>(acc[rt], tb, out_tile, out_ld, rt * 32, rows_left, lane);           // (pre-activations: read again only by the gradient chain / backward pass)
           if (!is_top) {
             // a = softplus(z) (the tail columns keep e), / sqrt(2) in front of a skip layer ; row max ; partial dot with the sdf row
 #pragma unroll
