@@ -383,6 +383,10 @@ inline int ws_next_rev() { static std::atomic<unsigned> parity{0}; return (int)(
 // The epilogue's side inputs (pre-activations, ReLU masks, the cotangent a value-backward launch adds to) are read once per launch: as NON-TEMPORAL loads they do not
 // push the lines the launch re-reads (its own input tile, the weights) or hands to the next launch (its output rows) out of L2 / Infinity Cache: +0.2-0.3 % of the step,
 // same bits (profiles/r06_ab_nt_side_inputs.txt).  The STAGED tile must stay a plain load: non-temporal there costs 2 % (the fused launches read it twice).
+// ... and the second-order cotangent a sweep launch writes on z (picked up by the value-backward chain many launches later) as a non-temporal store: +0.2 %
+#ifndef WS_NT_SWEEP
+#define WS_NT_SWEEP 1
+#endif
 #ifndef WS_NT_SIDE
 #define WS_NT_SIDE 1
 #endif
@@ -416,7 +420,11 @@ __device__ __forceinline__ void epi_finish4_plain(const Epi& e, long row, int co
     o1.y = softplus100_d2(zz.y) * (vv.y * e.vscale) * acc.y; o2.y = softplus100_d1(zz.y) * acc.y;
     o1.z = softplus100_d2(zz.z) * (vv.z * e.vscale) * acc.z; o2.z = softplus100_d1(zz.z) * acc.z;
     o1.w = softplus100_d2(zz.w) * (vv.w * e.vscale) * acc.w; o2.w = softplus100_d1(zz.w) * acc.w;
+#if WS_NT_SWEEP
+    __builtin_nontemporal_store(o1, reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col));   // (the second-order cotangent on z: picked up by the value-backward chain many launches later)
+#else
     *reinterpret_cast<f4*>(e.o1 + row * e.ld1 + col) = o1;
+#endif
     *reinterpret_cast<f4*>(e.o2 + row * e.ld2 + col) = o2;
   } else if constexpr (EK == EK_VBACK) {
     const f4 zz = raw.a;

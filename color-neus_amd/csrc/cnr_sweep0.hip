@@ -170,7 +170,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void sweep0_dw_kernel(const LayerGem
       o1.w = softplus100_d2(zz.w) * vw * v.w; o2.w = s1w * v.w;
       const bool live = row < Pn;
       if (live) {
+#if WS_NT_SWEEP
+        __builtin_nontemporal_store(o1, reinterpret_cast<f4*>(g.E.o1 + row * g.E.ld1 + ecol));
+#else
         *reinterpret_cast<f4*>(g.E.o1 + row * g.E.ld1 + ecol) = o1;
+#endif
         *reinterpret_cast<f4*>(g.E.o2 + row * g.E.ld2 + ecol) = o2;
       }
       u[q].x = live ? s1x * vx : 0.0f; u[q].y = live ? s1y * vy : 0.0f; u[q].z = live ? s1z * vz : 0.0f; u[q].w = live ? s1w * vw : 0.0f;
